@@ -1,0 +1,79 @@
+"""ctypes binding of ``libbya_hip.so`` (C ABI declared in ``include/bya.h``).
+
+Loading fails LOUDLY: there is no CPU / PyTorch fallback for the product path.
+"""
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+_c = ctypes
+_vp, _i32, _i64, _f32 = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_float
+
+
+class GemmDesc(_c.Structure):
+    _fields_ = [("M", _i32), ("N", _i32), ("K", _i32), ("batch", _i32),
+                ("lda", _i32), ("ldw", _i32), ("ldc", _i32), ("ldres", _i32),
+                ("a_batch_stride", _i64), ("c_batch_stride", _i64), ("res_batch_stride", _i64),
+                ("gate_batch_stride", _i64), ("gate_split", _i32), ("act", _i32)]
+
+
+class AttnDesc(_c.Structure):
+    _fields_ = [("head_dim", _i32), ("heads", _i32), ("nb1", _i32), ("nb2", _i32), ("Sq", _i32), ("Skv", _i32),
+                ("q_s1", _i64), ("q_s2", _i64), ("q_row", _i64),
+                ("k_s1", _i64), ("k_s2", _i64), ("k_row", _i64),
+                ("v_s1", _i64), ("v_s2", _i64), ("v_row", _i64),
+                ("o_s1", _i64), ("o_s2", _i64), ("o_row", _i64),
+                ("scale", _f32)]
+
+
+# name -> argtypes (all return int32 status); mirrors include/bya.h one-to-one
+SIGNATURES = {
+    "bya_abi_version": [],
+    "bya_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
+    "bya_linear_small_m": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "bya_timestep_features": [_vp, _vp, _i32, _i32, _i32, _f32, _vp],
+    "bya_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,
+                      _f32, _vp],
+    "bya_qknorm_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _vp],
+    "bya_attn_fwd": [_vp, _vp, _vp, _vp, _c.POINTER(AttnDesc), _vp],
+    "bya_attn_tiny": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
+    "bya_router_scores": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp],
+    "bya_router_head": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp],
+    "bya_forcing_max_over_frames": [_vp, _vp, _i32, _i64, _i32, _vp],
+    "bya_masked_combine": [_vp, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _i64, _i32, _i64, _i64, _i64, _vp],
+    "bya_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "bya_unpatchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "bya_act_add": [_vp, _vp, _vp, _i64, _i32, _vp],
+}
+
+ERRORS = {-1: "BYA_ERR_SHAPE", -2: "BYA_ERR_ALIGN", -3: "BYA_ERR_LAUNCH", -4: "BYA_ERR_UNSUPPORTED"}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it is not built (run ``python -m ...build`` / ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the Bind-Your-Avatar MI355X engine has no fallback path. "
+            "Build it with `python -m bind_your_avatar_implementation_amd.build`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export what bya.h declares
+        fn.argtypes = argtypes
+        fn.restype = _i32
+    _lib = lib
+    return lib
+
+
+class ByaError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise ByaError(f"{what} failed: {ERRORS.get(rc, rc)}")

@@ -1,0 +1,249 @@
+// Flash-attention forward for gfx950, head_dim 64 / 128, no mask, arbitrary Sq / Skv (tails masked).
+//
+// Replaces F.scaled_dot_product_attention inside diffusers' CogVideoXAttnProcessor2_0 (joint 17776-token
+// self-attention, models/transformer.py:208,241), the default SDPA processor of the router's spatial
+// attention (models/router.py:476) and of the audio cross-attention (models/audio_model.py:253), and the
+// hand-rolled softmax attention of PerceiverCrossAttention / PerceiverAttention (models/router.py:264-270,
+// 68-71; their q*s, k*s with s = d^-1/4 is scale = d^-1/2 on the product).
+//
+// Structure (v1): block = 4 waves x 32 query rows = 128 rows of one (batch, head); K/V tiles of 64 keys
+// staged by global_load_lds_dwordx4 into a 2-deep LDS ring (source-side XOR swizzles: K for the
+// ds_read_b128 A-operand reads, V for the ds_read_b64_tr_b16 transposed reads).
+// QK^T is issued "swapped" (S^T = K.Q^T, v_mfma_f32_32x32x16_bf16) so a query row lives on one lane
+// (+ its partner lane+32): the online softmax is an in-register reduction plus one cross-half exchange,
+// and the S^T accumulator is directly the B operand of O^T += V^T.P^T (no LDS round trip for P).
+// Blocks of one (batch, head) are dealt to one XCD so its K/V stream is served by that XCD's L2.
+#include "bya_common.h"
+#include "../../include/bya.h"
+
+namespace {
+
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+    int heads, nb1, nb2, Sq, Skv, nqt;
+    long long q_s1, q_s2, q_row, k_s1, k_s2, k_row, v_s1, v_s2, v_row, o_s1, o_s2, o_row;
+    float scale_log2;  // scale * log2(e)
+};
+
+constexpr int KV_TILE = 64;
+constexpr int Q_PER_WAVE = 32;
+constexpr int Q_PER_BLOCK = 128;
+
+// Stage a [64 keys][D] bf16 tile (rows of D*2 bytes) into LDS, lane-linear image, swizzled source.
+// XOR applied to the 16-byte chunk index of LDS row `row` (both on the staging source and on the reads):
+//  K (ds_read_b128, 32 rows x one chunk per half-wave): 128-B rows -> (row>>1)&7, 256-B rows -> row&15
+//  V (ds_read_b64_tr_b16, 4 rows x 64 B per half-wave):  128-B rows -> ((row>>1)&1)<<2, 256-B rows -> (row&3)<<2
+template <int D> __device__ __forceinline__ int kswz(int row) { return D == 64 ? ((row >> 1) & 7) : (row & 15); }
+template <int D> __device__ __forceinline__ int vswz(int row) { return D == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }
+
+template <int D, bool IS_V>
+__device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ src, long long row_stride, int kv0, int kv_max,
+                                         char* lds_tile, int wave, int lane) {
+    constexpr int ROW_BYTES = D * 2;
+    constexpr int ROWS_PER_INSTR = 1024 / ROW_BYTES;        // 8 (D=64) or 4 (D=128)
+    constexpr int CHUNKS = ROW_BYTES / 16;                   // 8 or 16
+    constexpr int INSTR_PER_WAVE = (KV_TILE / ROWS_PER_INSTR) / 4;
+#pragma unroll
+    for (int q = 0; q < INSTR_PER_WAVE; ++q) {
+        const int rbase = (wave * INSTR_PER_WAVE + q) * ROWS_PER_INSTR;
+        const int rl = rbase + lane / CHUNKS;
+        const int slot = lane % CHUNKS;
+        const int chunk = slot ^ (IS_V ? vswz<D>(rl) : kswz<D>(rl));
+        int gr = kv0 + rl;
+        gr = gr < kv_max ? gr : kv_max;
+        const bf16_t* g = src + (long long)gr * row_stride + chunk * 8;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(lds_tile + rbase * ROW_BYTES), 16, 0, 0);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROW_BYTES = D * 2;
+    constexpr int TILE_BYTES = KV_TILE * ROW_BYTES;
+    constexpr int DSTEPS = D / 16;   // k-steps of the QK^T product
+    constexpr int DT = D / 32;       // 32-row tiles of O^T
+    // LDS ring: stage b holds K at smem + b*2*TILE_BYTES and V right behind it
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hf = lane >> 5;
+
+    // block -> (bh, q-tile): blocks with equal (blockIdx % 8) share an XCD; give each XCD whole (batch, head)s.
+    const int nbh = p.nb1 * p.nb2 * p.heads;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int bh = (j / p.nqt) * 8 + xcd;
+    const int qt = j % p.nqt;
+    if (bh >= nbh) return;
+    const int head = bh % p.heads;
+    const int b12 = bh / p.heads;
+    const int b1 = b12 / p.nb2, b2 = b12 % p.nb2;
+
+    const bf16_t* Q = p.q + b1 * p.q_s1 + b2 * p.q_s2 + (long long)head * D;
+    const bf16_t* K = p.k + b1 * p.k_s1 + b2 * p.k_s2 + (long long)head * D;
+    const bf16_t* V = p.v + b1 * p.v_s1 + b2 * p.v_s2 + (long long)head * D;
+    bf16_t* O = p.o + b1 * p.o_s1 + b2 * p.o_s2 + (long long)head * D;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane (r,hf) holds Q[q0+r][16s + 8hf .. +7]
+    const int q0 = qt * Q_PER_BLOCK + wave * Q_PER_WAVE;
+    int qrow = q0 + r;
+    const bool q_valid = qrow < p.Sq;
+    qrow = q_valid ? qrow : p.Sq - 1;
+    bf16x8 qf[DSTEPS];
+#pragma unroll
+    for (int s = 0; s < DSTEPS; ++s)
+        qf[s] = *reinterpret_cast<const bf16x8*>(Q + (long long)qrow * p.q_row + s * 16 + hf * 8);
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (p.Skv + KV_TILE - 1) / KV_TILE;
+    stage_kv<D, false>(K, p.k_row, 0, p.Skv - 1, smem, wave, lane);
+    stage_kv<D, true>(V, p.v_row, 0, p.Skv - 1, smem + TILE_BYTES, wave, lane);
+
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            stage_kv<D, false>(K, p.k_row, (t + 1) * KV_TILE, p.Skv - 1, smem + ((t + 1) & 1) * 2 * TILE_BYTES, wave, lane);
+            stage_kv<D, true>(V, p.v_row, (t + 1) * KV_TILE, p.Skv - 1, smem + ((t + 1) & 1) * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+        }
+        const char* kt = smem + (t & 1) * 2 * TILE_BYTES;
+        const char* vt = kt + TILE_BYTES;
+
+        // ---- S^T[u] (32 keys x 32 queries) = K[u] . Q^T
+        f32x16 sacc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[u][i] = 0.f;
+            const int krow = u * 32 + r;
+#pragma unroll
+            for (int s = 0; s < DSTEPS; ++s) {
+                const int chunk = 2 * s + hf;   // 16-byte chunk index within the row
+                const int off = krow * ROW_BYTES + ((chunk ^ kswz<D>(krow)) << 4);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + off);
+                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[u], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax over the 64 keys of this tile (this lane: 32 of them, partner lane^32 the rest)
+        const int kv_base = t * KV_TILE;
+        const bool tail = kv_base + KV_TILE > p.Skv;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float sv = sacc[u][i] * p.scale_log2;
+                if (tail) {
+                    const int kv = kv_base + u * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
+                    sv = kv < p.Skv ? sv : -INFINITY;
+                }
+                sacc[u][i] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);      // finite: every tile has >= 1 valid key
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pf[4];                               // B operand for k-steps (u,tt): regs 8tt..8tt+7 of sacc[u]
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(sacc[u][tt * 8 + e] - m_new);
+                    psum += pv;
+                    pf[u * 2 + tt][e] = (__bf16)pv;
+                }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+
+        // ---- O^T[d] (32 dims x 32 queries) += V^T[d] . P^T ; A operand by transposed LDS reads.
+        // k-step ks = 2u+tt covers tile keys 16ks + 8(e>>2) + 4hf + (e&3), e = 0..7.
+        const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int chunk = 4 * d + 2 * (g & 1) + (tp >> 1);
+                s16x4 lo, hi;
+                {
+                    const int row = 16 * ks + 4 * hf + tq;
+                    const int off = row * ROW_BYTES + ((chunk ^ vswz<D>(row)) << 4) + (tp & 1) * 8;
+                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)LDS_PTR(vt + off));
+                }
+                {
+                    const int row = 16 * ks + 8 + 4 * hf + tq;
+                    const int off = row * ROW_BYTES + ((chunk ^ vswz<D>(row)) << 4) + (tp & 1) * 8;
+                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)LDS_PTR(vt + off));
+                }
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], oacc[d], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (r,hf) holds d = 32dt + (i&3) + 8(i>>2) + 4hf
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_valid) {
+        bf16_t* orow = O + (long long)(q0 + r) * p.o_row;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                u32x2 w;
+                w[0] = pack2bf(oacc[d][gq * 4 + 0] * inv, oacc[d][gq * 4 + 1] * inv);
+                w[1] = pack2bf(oacc[d][gq * 4 + 2] * inv, oacc[d][gq * 4 + 3] * inv);
+                *reinterpret_cast<u32x2*>(orow + d * 32 + gq * 8 + hf * 4) = w;
+            }
+    }
+}
+
+template <int D>
+int launch_attn(const AttnArgs& a, hipStream_t s) {
+    const int nbh = a.nb1 * a.nb2 * a.heads;
+    const int groups = (nbh + 7) / 8;
+    dim3 grid(groups * 8 * a.nqt);
+    const size_t lds = 4 * KV_TILE * D * 2;
+    hipLaunchKernelGGL((attn_fwd_kernel<D>), grid, dim3(256), lds, s, a);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya_attn_desc* d,
+                            hipStream_t stream) {
+    if (!q || !k || !v || !o || !d) return BYA_ERR_SHAPE;
+    if (d->head_dim != 64 && d->head_dim != 128) return BYA_ERR_UNSUPPORTED;
+    if (d->heads <= 0 || d->nb1 <= 0 || d->nb2 <= 0 || d->Sq <= 0 || d->Skv <= 0) return BYA_ERR_SHAPE;
+    if ((d->q_row | d->k_row | d->v_row | d->q_s1 | d->q_s2 | d->k_s1 | d->k_s2 | d->v_s1 | d->v_s2) % 8) return BYA_ERR_ALIGN;
+    if ((d->o_row | d->o_s1 | d->o_s2) % 4) return BYA_ERR_ALIGN;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return BYA_ERR_ALIGN;
+    if ((uintptr_t)o & 7) return BYA_ERR_ALIGN;
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o;
+    a.heads = d->heads; a.nb1 = d->nb1; a.nb2 = d->nb2; a.Sq = d->Sq; a.Skv = d->Skv;
+    a.nqt = (d->Sq + Q_PER_BLOCK - 1) / Q_PER_BLOCK;
+    a.q_s1 = d->q_s1; a.q_s2 = d->q_s2; a.q_row = d->q_row;
+    a.k_s1 = d->k_s1; a.k_s2 = d->k_s2; a.k_row = d->k_row;
+    a.v_s1 = d->v_s1; a.v_s2 = d->v_s2; a.v_row = d->v_row;
+    a.o_s1 = d->o_s1; a.o_s2 = d->o_s2; a.o_row = d->o_row;
+    a.scale_log2 = d->scale * 1.4426950408889634f;
+    return d->head_dim == 64 ? launch_attn<64>(a, stream) : launch_attn<128>(a, stream);
+}

@@ -1,0 +1,288 @@
+// Small HBM-bound / index-only kernels of the denoise step: small-M linears (timestep embedding and all
+// AdaLN modulation vectors), sinusoidal timestep features, the router's masked combines (G1/G2), the
+// forcing max-over-frames, patchify / unpatchify and a generic activation(+add).
+#include "bya_common.h"
+#include "../../include/bya.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// out[m,n] = act( sum_k f(x[m,k]) * W[n,k] + bias[n] ), M <= 8.  One wave per output column n; the K axis is
+// split over the 64 lanes in 16-byte pieces (W is streamed exactly once: HBM-bound).
+template <int MAXM>
+__global__ __launch_bounds__(256) void linear_small_m_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+                                                             const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
+                                                             int M, int N, int K, int silu_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) acc[m] = 0.f;
+    const bf16_t* wrow = W + n * K;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+        float wv[8];
+        unpack8(*reinterpret_cast<const u32x4*>(wrow + k0), wv);
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) {
+            if (m < M) {
+                float xv[8];
+                unpack8(*reinterpret_cast<const u32x4*>(x + (long long)m * K + k0), xv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xe = xv[e];
+                    if (silu_in) xe = bf2f(f2bf(silu(xe)));  // SiLU output is a bf16 tensor in the reference
+                    acc[m] += xe * wv[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+        if (m < M) {
+            float v = wave_sum(acc[m]);
+            if (lane == 0) {
+                if (bias) v += bf2f(bias[n]);
+                if (act_out == BYA_ACT_SILU) v = silu(v);
+                out[(long long)m * N + n] = f2bf(v);
+            }
+        }
+    }
+}
+
+__global__ void timestep_features_kernel(const int64_t* __restrict__ t, bf16_t* __restrict__ out, int batch, int dim,
+                                         int flip, float shift) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * half) return;
+    const int b = idx / half, j = idx % half;
+    const float expo = -logf(10000.0f) * (float)j / ((float)half - shift);
+    const float ang = (float)t[b] * expf(expo);
+    const float s = sinf(ang), c = cosf(ang);
+    bf16_t* o = out + (long long)b * dim;
+    if (flip) { o[j] = f2bf(c); o[half + j] = f2bf(s); }
+    else { o[j] = f2bf(s); o[half + j] = f2bf(c); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Masked combine (G1 face / G2 audio).  One thread per 8 channels of one token.
+struct CombArgs {
+    bf16_t* x; const bf16_t* feat; const bf16_t* r; const bf16_t* af;
+    int mode, batch, n_id, D;
+    long long N, x_row, x_bs, r_bs;
+    float alpha;
+};
+
+__global__ __launch_bounds__(256) void masked_combine_kernel(CombArgs p) {
+    const int vec_per_row = p.D / 8;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.batch * p.N * vec_per_row;
+    if (gid >= total) return;
+    const int c8 = (int)(gid % vec_per_row);
+    const long long bn = gid / vec_per_row;
+    const long long n = bn % p.N;
+    const int b = (int)(bn / p.N);
+    const bf16_t* r = p.r + b * p.r_bs + n * p.n_id;
+    float w[4];
+    if (p.mode == 0) {
+        for (int i = 0; i < p.n_id; ++i) w[i] = bf2f(r[i]);
+    } else {  // n_id == 2: w[id] = 1 - (af @ r)[1 - id], every intermediate a bf16 tensor in the reference
+        const bf16_t* af = p.af + b * 4;
+        const float r0 = bf2f(r[0]), r1 = bf2f(r[1]);
+        const float av0 = bf2f(f2bf(bf2f(af[0]) * r0 + bf2f(af[1]) * r1));
+        const float av1 = bf2f(f2bf(bf2f(af[2]) * r0 + bf2f(af[3]) * r1));
+        w[0] = bf2f(f2bf(1.0f - av1));
+        w[1] = bf2f(f2bf(1.0f - av0));
+    }
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int i = 0; i < p.n_id; ++i) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(p.feat + (((long long)b * p.n_id + i) * p.N + n) * p.D + c8 * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(w[i], f[e], acc[e]);
+    }
+    bf16_t* xp = p.x + b * p.x_bs + n * p.x_row + c8 * 8;
+    float xv[8];
+    unpack8(*reinterpret_cast<const u32x4*>(xp), xv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float t = bf2f(f2bf(acc[e]));                 // bmm output is bf16
+        if (p.alpha != 1.0f) t = bf2f(f2bf(p.alpha * t));
+        xv[e] += t;
+    }
+    *reinterpret_cast<u32x4*>(xp) = pack8(xv);
+}
+
+__global__ void forcing_max_kernel(const bf16_t* __restrict__ f, bf16_t* __restrict__ out, int frames,
+                                   long long per_frame, int n_id) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (r, id)
+    const long long inner = per_frame * n_id;
+    if (idx >= inner) return;
+    float m = bf2f(f[idx]);
+    bf16_t mb = f[idx];
+    for (int t = 1; t < frames; ++t) {
+        const bf16_t vb = f[t * inner + idx];
+        const float v = bf2f(vb);
+        if (v > m) { m = v; mb = vb; }
+    }
+    for (int t = 0; t < frames; ++t) out[t * inner + idx] = mb;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void patchify_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ cols, int batch, int frames, int C,
+                                int H, int W) {
+    const int Ht = H / 2, Wt = W / 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, t, c, h, w), w fastest
+    const long long total = (long long)batch * frames * C * Ht * Wt;
+    if (idx >= total) return;
+    const int w = (int)(idx % Wt); long long rest = idx / Wt;
+    const int h = (int)(rest % Ht); rest /= Ht;
+    const int c = (int)(rest % C); rest /= C;
+    const int t = (int)(rest % frames);
+    const int b = (int)(rest / frames);
+    const bf16_t* src = x + ((((long long)b * frames + t) * C + c) * H + 2 * h) * W + 2 * w;
+    const uint32_t top = *reinterpret_cast<const uint32_t*>(src);
+    const uint32_t bot = *reinterpret_cast<const uint32_t*>(src + W);
+    const long long n = ((long long)t * Ht + h) * Wt + w;
+    u32x2 o; o[0] = top; o[1] = bot;
+    *reinterpret_cast<u32x2*>(cols + (((long long)b * frames * Ht * Wt + n) * C + c) * 4) = o;
+}
+
+__global__ void unpatchify_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ out, int batch, int frames, int C,
+                                  int H, int W) {
+    const int Ht = H / 2, Wt = W / 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, t, c, h, w), w fastest
+    const long long total = (long long)batch * frames * C * Ht * Wt;
+    if (idx >= total) return;
+    const int w = (int)(idx % Wt); long long rest = idx / Wt;
+    const int h = (int)(rest % Ht); rest /= Ht;
+    const int c = (int)(rest % C); rest /= C;
+    const int t = (int)(rest % frames);
+    const int b = (int)(rest / frames);
+    const long long n = ((long long)t * Ht + h) * Wt + w;
+    const u32x2 v = *reinterpret_cast<const u32x2*>(y + (((long long)b * frames * Ht * Wt + n) * C + c) * 4);
+    bf16_t* dst = out + ((((long long)b * frames + t) * C + c) * H + 2 * h) * W + 2 * w;
+    *reinterpret_cast<uint32_t*>(dst) = v[0];
+    *reinterpret_cast<uint32_t*>(dst + W) = v[1];
+}
+
+__global__ __launch_bounds__(256) void act_add_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ r,
+                                                      bf16_t* __restrict__ y, long long nvec, int act) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = v[e];
+            switch (act) {
+                case BYA_ACT_GELU_TANH: t = gelu_tanh(t); break;
+                case BYA_ACT_GELU_ERF: t = gelu_erf(t); break;
+                case BYA_ACT_RELU: t = t > 0.f ? t : 0.f; break;
+                case BYA_ACT_SILU: t = silu(t); break;
+                case BYA_ACT_LEAKY_RELU: t = t > 0.f ? t : 0.01f * t; break;
+                default: break;
+            }
+            v[e] = t;
+        }
+        if (r) {
+            float rv[8];
+            unpack8(*reinterpret_cast<const u32x4*>(r + i * 8), rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e])) + rv[e];
+        }
+        *reinterpret_cast<u32x4*>(y + i * 8) = pack8(v);
+    }
+}
+
+inline int ok() { return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH; }
+
+}  // namespace
+
+extern "C" int bya_abi_version(void) { return 1; }
+
+extern "C" int bya_linear_small_m(const void* x, const void* W, const void* bias, void* out, int32_t M, int32_t N,
+                                  int32_t K, int32_t silu_in, int32_t act_out, hipStream_t stream) {
+    if (!x || !W || !out || M <= 0 || M > 8 || N <= 0 || K <= 0) return BYA_ERR_SHAPE;
+    if (K % 8) return BYA_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)W) & 15) return BYA_ERR_ALIGN;
+    if (act_out != BYA_ACT_NONE && act_out != BYA_ACT_SILU) return BYA_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)((N + 3) / 4));
+    if (M <= 2)
+        hipLaunchKernelGGL((linear_small_m_kernel<2>), grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W,
+                           (const bf16_t*)bias, (bf16_t*)out, M, N, K, silu_in, act_out);
+    else
+        hipLaunchKernelGGL((linear_small_m_kernel<8>), grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W,
+                           (const bf16_t*)bias, (bf16_t*)out, M, N, K, silu_in, act_out);
+    return ok();
+}
+
+extern "C" int bya_timestep_features(const int64_t* timesteps, void* out, int32_t batch, int32_t dim,
+                                     int32_t flip_sin_to_cos, float freq_shift, hipStream_t stream) {
+    if (!timesteps || !out || batch <= 0 || dim <= 0 || dim % 2) return BYA_ERR_SHAPE;
+    const int total = batch * (dim / 2);
+    hipLaunchKernelGGL(timestep_features_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, timesteps,
+                       (bf16_t*)out, batch, dim, flip_sin_to_cos, freq_shift);
+    return ok();
+}
+
+extern "C" int bya_masked_combine(void* x, const void* feat, const void* r, const void* af, int32_t mode, float alpha,
+                                  int32_t batch, int32_t n_id, int64_t N, int32_t D, int64_t x_row,
+                                  int64_t x_batch_stride, int64_t r_batch_stride, hipStream_t stream) {
+    if (!x || !feat || !r || batch <= 0 || N <= 0 || D <= 0) return BYA_ERR_SHAPE;
+    if (mode != 0 && mode != 1) return BYA_ERR_UNSUPPORTED;
+    if (n_id < 1 || n_id > 4 || (mode == 1 && (n_id != 2 || !af))) return BYA_ERR_UNSUPPORTED;
+    if (D % 8 || x_row % 8 || x_batch_stride % 8) return BYA_ERR_ALIGN;
+    if (((uintptr_t)x | (uintptr_t)feat) & 15) return BYA_ERR_ALIGN;
+    CombArgs a;
+    a.x = (bf16_t*)x; a.feat = (const bf16_t*)feat; a.r = (const bf16_t*)r; a.af = (const bf16_t*)af;
+    a.mode = mode; a.batch = batch; a.n_id = n_id; a.D = D; a.N = N; a.x_row = x_row; a.x_bs = x_batch_stride;
+    a.r_bs = r_batch_stride; a.alpha = alpha;
+    const long long total = (long long)batch * N * (D / 8);
+    hipLaunchKernelGGL(masked_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    return ok();
+}
+
+extern "C" int bya_forcing_max_over_frames(const void* forcing, void* out, int32_t frames, int64_t per_frame,
+                                           int32_t n_id, hipStream_t stream) {
+    if (!forcing || !out || frames <= 0 || per_frame <= 0 || n_id <= 0) return BYA_ERR_SHAPE;
+    const long long inner = per_frame * n_id;
+    hipLaunchKernelGGL(forcing_max_kernel, dim3((unsigned)((inner + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t*)forcing, (bf16_t*)out, frames, (long long)per_frame, n_id);
+    return ok();
+}
+
+extern "C" int bya_patchify(const void* x, void* cols, int32_t batch, int32_t frames, int32_t channels, int32_t H,
+                            int32_t W, hipStream_t stream) {
+    if (!x || !cols || batch <= 0 || frames <= 0 || channels <= 0 || H <= 0 || W <= 0) return BYA_ERR_SHAPE;
+    if (H % 2 || W % 2) return BYA_ERR_SHAPE;
+    if (((uintptr_t)x & 3) || ((uintptr_t)cols & 7)) return BYA_ERR_ALIGN;
+    const long long total = (long long)batch * frames * channels * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
+                       (bf16_t*)cols, batch, frames, channels, H, W);
+    return ok();
+}
+
+extern "C" int bya_unpatchify(const void* y, void* out, int32_t batch, int32_t frames, int32_t channels, int32_t H,
+                              int32_t W, hipStream_t stream) {
+    if (!y || !out || batch <= 0 || frames <= 0 || channels <= 0 || H <= 0 || W <= 0) return BYA_ERR_SHAPE;
+    if (H % 2 || W % 2) return BYA_ERR_SHAPE;
+    if (((uintptr_t)out & 3) || ((uintptr_t)y & 7)) return BYA_ERR_ALIGN;
+    const long long total = (long long)batch * frames * channels * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t*)y, (bf16_t*)out, batch, frames, channels, H, W);
+    return ok();
+}
+
+extern "C" int bya_act_add(const void* x, const void* r, void* y, int64_t n, int32_t act, hipStream_t stream) {
+    if (!x || !y || n <= 0 || n % 8) return BYA_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)r) & 15) return BYA_ERR_ALIGN;
+    if (act < 0 || act > 5) return BYA_ERR_UNSUPPORTED;
+    const long long nvec = n / 8;
+    long long blocks = (nvec + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(act_add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x,
+                       (const bf16_t*)r, (bf16_t*)y, nvec, act);
+    return ok();
+}

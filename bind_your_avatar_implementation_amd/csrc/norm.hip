@@ -1,0 +1,212 @@
+// HBM-bound normalisation kernels: LayerNorm (+ affine, + AdaLN modulation) and the per-head
+// q/k LayerNorm(64) + RoPE.  One wave per row, 16-byte (8 x bf16) or 8-byte (4 x bf16) lane accesses,
+// the whole row held in registers (single HBM read), fp32 statistics, wave-shuffle reductions.
+//
+// Replaces: CogVideoXLayerNormZero (models/transformer.py:233,251), nn.LayerNorm norm_final + AdaLayerNorm
+// norm_out (:944,:948), PerceiverCrossAttention.norm1/norm2 (models/router.py:247-248), MultiIPRouter
+// norm_q/norm_k (:380,:382), SpatialTemporalAttentionBlock.norm1-4 (:475-491), AudioAwareModel norm_q
+// (models/audio_model.py:249), diffusers Attention.norm_q/norm_k + apply_rotary_emb (transformer.py:204-208).
+#include "bya_common.h"
+#include "../../include/bya.h"
+
+namespace {
+
+struct LnArgs {
+    const bf16_t* x; bf16_t* y; const bf16_t* w; const bf16_t* b;
+    const bf16_t* shift0; const bf16_t* scale0; const bf16_t* shift1; const bf16_t* scale1;
+    long long rows_per_batch, ldx, ldy, x_bs, y_bs, mod_bs, split;
+    int batch;
+    float eps;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const bf16_t* p, float* f) {
+    if constexpr (VEC == 8) {
+        unpack8(*reinterpret_cast<const u32x4*>(p), f);
+    } else {
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(p);
+        f[0] = bflo(raw[0]); f[1] = bfhi(raw[0]); f[2] = bflo(raw[1]); f[3] = bfhi(raw[1]);
+    }
+}
+
+// D = 64 * VEC * NV ; each lane owns NV vectors of VEC contiguous elements, vector v at column (v*64 + lane)*VEC
+template <int VEC, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
+    constexpr int D = 64 * VEC * NV;
+    const int lane = threadIdx.x & 63;
+    const long long row_lin = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long total = p.rows_per_batch * p.batch;
+    if (row_lin >= total) return;
+    const int z = (int)(row_lin / p.rows_per_batch);
+    const long long row = row_lin - (long long)z * p.rows_per_batch;
+    const bf16_t* x = p.x + z * p.x_bs + row * p.ldx;
+    bf16_t* y = p.y + z * p.y_bs + row * p.ldy;
+
+    float v[NV][VEC];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * VEC;
+        load_vec<VEC>(x + col, v[i]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sum += v[i][e];
+    }
+    const float mean = wave_sum(sum) * (1.0f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    const float rstd = rsqrtf(wave_sum(sq) * (1.0f / D) + p.eps);
+
+    const bf16_t* shift = nullptr; const bf16_t* scale = nullptr;
+    if (p.shift0) {
+        const bool first = row < p.split;
+        shift = (first ? p.shift0 : p.shift1) + z * p.mod_bs;
+        scale = (first ? p.scale0 : p.scale1) + z * p.mod_bs;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * VEC;
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = (v[i][e] - mean) * rstd;
+        if (p.w) {
+            float wv[VEC], bv[VEC];
+            load_vec<VEC>(p.w + col, wv);
+            if (p.b) load_vec<VEC>(p.b + col, bv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = o[e] * wv[e] + (p.b ? bv[e] : 0.f);
+        }
+        if (shift) {
+            float sc[VEC], sh[VEC];
+            load_vec<VEC>(scale + col, sc);
+            load_vec<VEC>(shift + col, sh);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = o[e] * (1.0f + sc[e]) + sh[e];
+        }
+        if constexpr (VEC == 8) {
+            *reinterpret_cast<u32x4*>(y + col) = pack8(o);
+        } else {
+            u32x2 w2; w2[0] = pack2bf(o[0], o[1]); w2[1] = pack2bf(o[2], o[3]);
+            *reinterpret_cast<u32x2*>(y + col) = w2;
+        }
+    }
+}
+
+template <int VEC, int NV>
+int launch_ln(const LnArgs& a, hipStream_t s) {
+    const long long total = a.rows_per_batch * a.batch;
+    dim3 grid((unsigned)((total + 3) / 4));
+    hipLaunchKernelGGL((layernorm_kernel<VEC, NV>), grid, dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+// ---- q/k per-head LayerNorm(64) + RoPE, in place.  8 lanes x 8 elements per (row, head); a wave covers
+// 8 consecutive heads of one row (1 KiB contiguous per wave access).
+struct QkArgs {
+    bf16_t* q; bf16_t* k; const bf16_t* qw; const bf16_t* qb; const bf16_t* kw; const bf16_t* kb;
+    const float* cos; const float* sin;
+    int batch, S, heads, text_rows;
+    long long ld, bs;
+    float eps;
+};
+
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int hgroups = p.heads / 8;                 // waves per (row, tensor)
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long total = (long long)p.batch * p.S * hgroups * 2;
+    if (wid >= total) return;
+    const int which = (int)(wid % 2);                // 0 = q, 1 = k
+    long long rest = wid / 2;
+    const int hg = (int)(rest % hgroups); rest /= hgroups;
+    const int s = (int)(rest % p.S);
+    const int z = (int)(rest / p.S);
+    const int head = hg * 8 + (lane >> 3);
+    const int d0 = (lane & 7) * 8;
+    bf16_t* base = (which ? p.k : p.q) + z * p.bs + (long long)s * p.ld + head * 64 + d0;
+    const bf16_t* w = (which ? p.kw : p.qw) + d0;
+    const bf16_t* b = (which ? p.kb : p.qb) + d0;
+
+    float v[8];
+    unpack8(*reinterpret_cast<const u32x4*>(base), v);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += v[e];
+    sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+    const float mean = sum * (1.0f / 64);
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] -= mean; sq += v[e] * v[e]; }
+    sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+    const float rstd = rsqrtf(sq * (1.0f / 64) + p.eps);
+    float wv[8], bv[8];
+    unpack8(*reinterpret_cast<const u32x4*>(w), wv);
+    unpack8(*reinterpret_cast<const u32x4*>(b), bv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * wv[e] + bv[e];
+    if (s >= p.text_rows) {
+        const float* c = p.cos + (long long)(s - p.text_rows) * 64 + d0;
+        const float* sn = p.sin + (long long)(s - p.text_rows) * 64 + d0;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sn), s1 = *reinterpret_cast<const f32x4*>(sn + 4);
+        const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {   // pair (2i, 2i+1): rot = (-x[2i+1], x[2i])
+            o[e] = v[e] * cc[e] - v[e + 1] * ss[e];
+            o[e + 1] = v[e + 1] * cc[e + 1] + v[e] * ss[e + 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = o[e];
+    }
+    *reinterpret_cast<u32x4*>(base) = pack8(v);
+}
+
+}  // namespace
+
+extern "C" int bya_layernorm(const void* x, void* y, const void* w, const void* b, const void* shift0,
+                             const void* scale0, const void* shift1, const void* scale1, int64_t rows_per_batch,
+                             int32_t batch, int32_t D, int64_t ldx, int64_t ldy, int64_t x_batch_stride,
+                             int64_t y_batch_stride, int64_t mod_batch_stride, int64_t split, float eps,
+                             hipStream_t stream) {
+    if (!x || !y || rows_per_batch <= 0 || batch <= 0) return BYA_ERR_SHAPE;
+    if ((shift0 == nullptr) != (scale0 == nullptr)) return BYA_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return BYA_ERR_ALIGN;
+    if ((ldx | ldy | x_batch_stride | y_batch_stride) % 8) return BYA_ERR_ALIGN;
+    LnArgs a;
+    a.x = (const bf16_t*)x; a.y = (bf16_t*)y; a.w = (const bf16_t*)w; a.b = (const bf16_t*)b;
+    a.shift0 = (const bf16_t*)shift0; a.scale0 = (const bf16_t*)scale0;
+    a.shift1 = (const bf16_t*)(shift1 ? shift1 : shift0); a.scale1 = (const bf16_t*)(scale1 ? scale1 : scale0);
+    a.rows_per_batch = rows_per_batch; a.ldx = ldx; a.ldy = ldy; a.x_bs = x_batch_stride; a.y_bs = y_batch_stride;
+    a.mod_bs = mod_batch_stride; a.split = split; a.batch = batch; a.eps = eps;
+    switch (D) {
+        case 512: return launch_ln<8, 1>(a, stream);
+        case 768: return launch_ln<4, 3>(a, stream);
+        case 1024: return launch_ln<8, 2>(a, stream);
+        case 2048: return launch_ln<8, 4>(a, stream);
+        case 3072: return launch_ln<8, 6>(a, stream);
+        default: return BYA_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb, const void* kw, const void* kb,
+                               const float* cos, const float* sin, int32_t batch, int32_t S, int32_t heads,
+                               int64_t ld, int64_t batch_stride, int32_t text_rows, float eps, hipStream_t stream) {
+    if (!q || !k || !qw || !qb || !kw || !kb || batch <= 0 || S <= 0 || heads <= 0) return BYA_ERR_SHAPE;
+    if (heads % 8) return BYA_ERR_UNSUPPORTED;
+    if (text_rows < S && (!cos || !sin)) return BYA_ERR_SHAPE;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)qw | (uintptr_t)kw |
+         (uintptr_t)qb | (uintptr_t)kb) & 15) return BYA_ERR_ALIGN;
+    if ((ld | batch_stride) % 8) return BYA_ERR_ALIGN;
+    QkArgs a;
+    a.q = (bf16_t*)q; a.k = (bf16_t*)k; a.qw = (const bf16_t*)qw; a.qb = (const bf16_t*)qb;
+    a.kw = (const bf16_t*)kw; a.kb = (const bf16_t*)kb; a.cos = cos; a.sin = sin;
+    a.batch = batch; a.S = S; a.heads = heads; a.text_rows = text_rows; a.ld = ld; a.bs = batch_stride; a.eps = eps;
+    const long long total = (long long)batch * S * (heads / 8) * 2;
+    dim3 grid((unsigned)((total + 3) / 4));
+    hipLaunchKernelGGL(qknorm_rope_kernel, grid, dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}

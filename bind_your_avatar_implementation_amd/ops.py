@@ -1,0 +1,206 @@
+"""Torch-tensor front end of the C-ABI kernels (``include/bya.h``).
+
+Every function enqueues hand-written HIP kernels on torch's current stream and returns ``out``.
+Tensors are bf16 device tensors unless stated; 2-D ``[rows, cols]`` or 3-D ``[batch, rows, cols]`` views
+with unit inner stride are accepted (no copies are made here).
+"""
+import ctypes
+
+import torch
+
+from . import _hip
+from ._hip import AttnDesc, GemmDesc, check
+
+ACT = {None: 0, "none": 0, "gelu_tanh": 1, "gelu_erf": 2, "relu": 3, "silu": 4, "leaky_relu": 5}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _mat(t, name):
+    """-> (batch, rows, cols, batch_stride, row_stride) of a 2-D/3-D view with unit inner stride."""
+    if t.dtype != torch.bfloat16:
+        raise TypeError(f"{name}: expected bf16, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a device tensor (the engine has no CPU path)")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: inner stride must be 1")
+    if t.dim() == 2:
+        return 1, t.shape[0], t.shape[1], 0, t.stride(0)
+    if t.dim() == 3:
+        return t.shape[0], t.shape[1], t.shape[2], t.stride(0), t.stride(1)
+    raise ValueError(f"{name}: expected 2-D or 3-D, got {t.dim()}-D")
+
+
+def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, gate_batch_stride=0, act=None):
+    """out = res + gate * act(a @ w.T + bias).  a: [(B,) M, K], w: [N, K], out/res: [(B,) M, N]."""
+    lib = _hip.load()
+    ab, M, K, a_bs, lda = _mat(a, "a")
+    ob, Mo, N, c_bs, ldc = _mat(out, "out")
+    if w.dim() != 2 or w.shape[1] != K or w.shape[0] != N or w.stride(1) != 1 or w.dtype != torch.bfloat16:
+        raise ValueError(f"w: expected bf16 [{N}, {K}], got {tuple(w.shape)} {w.dtype}")
+    if (ab, M) != (ob, Mo):
+        raise ValueError("a/out row mismatch")
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch = M, N, K, ab
+    d.lda, d.ldw, d.ldc = lda, w.stride(0), ldc
+    d.a_batch_stride, d.c_batch_stride = a_bs, c_bs
+    d.ldres, d.res_batch_stride = 0, 0
+    if res is not None:
+        rb, Mr, Nr, r_bs, ldres = _mat(res, "res")
+        if (Mr, Nr) != (M, N) or rb not in (1, ab):
+            raise ValueError("res shape mismatch")
+        d.ldres, d.res_batch_stride = ldres, (r_bs if rb == ab else 0)
+    d.gate_batch_stride, d.gate_split, d.act = gate_batch_stride, gate_split, ACT[act]
+    check(lib.bya_gemm_bf16(_p(a), _p(w), _p(bias), _p(out), _p(res), _p(gate0), _p(gate1), ctypes.byref(d),
+                            _stream()), "bya_gemm_bf16")
+    return out
+
+
+def linear_small_m(x, w, bias, out, silu_in=False, act_out=None):
+    """out[M<=8, N] = f(x) @ w.T + bias (weight-streaming kernel)."""
+    lib = _hip.load()
+    M, K = x.shape
+    N = w.shape[0]
+    assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and out.shape == (M, N)
+    assert x.dtype == w.dtype == out.dtype == torch.bfloat16 and w.shape[1] == K
+    check(lib.bya_linear_small_m(_p(x), _p(w), _p(bias), _p(out), M, N, K, int(silu_in), ACT[act_out], _stream()),
+          "bya_linear_small_m")
+    return out
+
+
+def timestep_features(timesteps, out, flip_sin_to_cos=True, freq_shift=0.0):
+    lib = _hip.load()
+    assert timesteps.dtype == torch.int64 and timesteps.is_cuda and out.dtype == torch.bfloat16
+    b, dim = out.shape
+    check(lib.bya_timestep_features(_p(timesteps), _p(out), b, dim, int(flip_sin_to_cos), float(freq_shift),
+                                    _stream()), "bya_timestep_features")
+    return out
+
+
+def layernorm(x, out, weight=None, bias=None, eps=1e-5, shift0=None, scale0=None, shift1=None, scale1=None,
+              split=0, mod_batch_stride=0):
+    """LayerNorm over the last dim (+ affine, + AdaLN modulation: rows < split use (shift0, scale0))."""
+    lib = _hip.load()
+    xb, rows, D, x_bs, ldx = _mat(x, "x")
+    ob, rows_o, Do, y_bs, ldy = _mat(out, "out")
+    assert (xb, rows, D) == (ob, rows_o, Do)
+    check(lib.bya_layernorm(_p(x), _p(out), _p(weight), _p(bias), _p(shift0), _p(scale0), _p(shift1), _p(scale1),
+                            rows, xb, D, ldx, ldy, x_bs, y_bs, mod_batch_stride, split, float(eps), _stream()),
+          "bya_layernorm")
+    return out
+
+
+def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6):
+    """In place on q, k [B, S, heads*64]."""
+    lib = _hip.load()
+    b, S, _, bs, ld = _mat(q, "q")
+    assert _mat(k, "k") == _mat(q, "q")
+    if cos is not None:
+        assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
+        assert cos.shape == (S - text_rows, 64)
+    check(lib.bya_qknorm_rope(_p(q), _p(k), _p(qw), _p(qb), _p(kw), _p(kb), _p(cos), _p(sin), b, S, heads, ld,
+                              bs if b > 1 else 0, text_rows, float(eps), _stream()), "bya_qknorm_rope")
+
+
+def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_strides, v_strides, o_strides,
+              scale):
+    """Flash attention with explicit (level-1, level-2, row) element strides for q, k, v, out."""
+    lib = _hip.load()
+    d = AttnDesc()
+    d.head_dim, d.heads, d.nb1, d.nb2, d.Sq, d.Skv = head_dim, heads, nb1, nb2, Sq, Skv
+    d.q_s1, d.q_s2, d.q_row = q_strides
+    d.k_s1, d.k_s2, d.k_row = k_strides
+    d.v_s1, d.v_s2, d.v_row = v_strides
+    d.o_s1, d.o_s2, d.o_row = o_strides
+    d.scale = float(scale)
+    for t in (q, k, v, out):
+        assert t.dtype == torch.bfloat16 and t.is_cuda
+    check(lib.bya_attn_fwd(_p(q), _p(k), _p(v), _p(out), ctypes.byref(d), _stream()), "bya_attn_fwd")
+    return out
+
+
+def self_attention(q, k, v, out, heads, head_dim=64, scale=None):
+    """q,k,v,out: [B, S, heads*head_dim] views (row-strided ok)."""
+    b, S, _, q_bs, q_ld = _mat(q, "q")
+    _, Skv, _, k_bs, k_ld = _mat(k, "k")
+    _, _, _, v_bs, v_ld = _mat(v, "v")
+    _, _, _, o_bs, o_ld = _mat(out, "out")
+    scale = head_dim ** -0.5 if scale is None else scale
+    return attention(q, k, v, out, head_dim=head_dim, heads=heads, nb1=b, nb2=1, Sq=S, Skv=Skv,
+                     q_strides=(q_bs, 0, q_ld), k_strides=(k_bs, 0, k_ld), v_strides=(v_bs, 0, v_ld),
+                     o_strides=(o_bs, 0, o_ld), scale=scale)
+
+
+def attn_tiny(q, k, v, out, L, heads, n_outer, n_inner, outer_stride, seq_stride, ld_qkv, ld_o, scale):
+    lib = _hip.load()
+    check(lib.bya_attn_tiny(_p(q), _p(k), _p(v), _p(out), L, heads, n_outer, n_inner, outer_stride, seq_stride,
+                            ld_qkv, ld_o, float(scale), _stream()), "bya_attn_tiny")
+    return out
+
+
+def router_scores(qr, kr, ln_w, ln_b, pos_emb, out, n_id, N, eps=1e-5):
+    lib = _hip.load()
+    for t in (qr, kr, ln_w, ln_b, pos_emb, out):
+        assert t.is_contiguous() and t.dtype == torch.bfloat16
+    check(lib.bya_router_scores(_p(qr), _p(kr), _p(ln_w), _p(ln_b), _p(pos_emb), _p(out), n_id, N, 16, 32,
+                                float(eps), _stream()), "bya_router_scores")
+    return out
+
+
+def router_head(x, w, b, r, n_id, N):
+    lib = _hip.load()
+    assert x.is_contiguous() and r.is_contiguous()
+    check(lib.bya_router_head(_p(x), _p(w), _p(b), _p(r), n_id, N, x.shape[-1], _stream()), "bya_router_head")
+    return r
+
+
+def forcing_max_over_frames(forcing, out, frames, per_frame, n_id):
+    lib = _hip.load()
+    assert forcing.is_contiguous() and out.is_contiguous() and forcing.dtype == out.dtype == torch.bfloat16
+    check(lib.bya_forcing_max_over_frames(_p(forcing), _p(out), frames, per_frame, n_id, _stream()),
+          "bya_forcing_max_over_frames")
+    return out
+
+
+def masked_combine(x, feat, r, af, mode, alpha=1.0):
+    """x [B, N, D] view (in place) += combine(feat [B, n_id, N, D], r [B or 1, N, n_id])."""
+    lib = _hip.load()
+    b, N, D, x_bs, x_row = _mat(x, "x")
+    assert feat.is_contiguous() and feat.shape[0] == b and feat.shape[2] == N and feat.shape[3] == D
+    n_id = feat.shape[1]
+    assert r.is_contiguous() and r.shape[-2:] == (N, n_id) and r.dtype == torch.bfloat16
+    r_bs = 0 if r.shape[0] == 1 else N * n_id
+    if af is not None:
+        assert af.is_contiguous() and af.dtype == torch.bfloat16 and af.shape == (b, n_id, n_id)
+    check(lib.bya_masked_combine(_p(x), _p(feat), _p(r), _p(af), {"face": 0, "audio": 1}[mode], float(alpha), b,
+                                 n_id, N, D, x_row, x_bs, r_bs, _stream()), "bya_masked_combine")
+    return x
+
+
+def patchify(x, cols):
+    lib = _hip.load()
+    b, t, c, h, w = x.shape
+    assert x.is_contiguous() and cols.is_contiguous() and x.dtype == cols.dtype == torch.bfloat16
+    check(lib.bya_patchify(_p(x), _p(cols), b, t, c, h, w, _stream()), "bya_patchify")
+    return cols
+
+
+def unpatchify(y, out):
+    lib = _hip.load()
+    b, t, c, h, w = out.shape
+    assert y.is_contiguous() and out.is_contiguous() and y.dtype == out.dtype == torch.bfloat16
+    check(lib.bya_unpatchify(_p(y), _p(out), b, t, c, h, w, _stream()), "bya_unpatchify")
+    return out
+
+
+def act_add(x, out, act=None, res=None):
+    lib = _hip.load()
+    assert x.is_contiguous() and out.is_contiguous() and (res is None or res.is_contiguous())
+    check(lib.bya_act_add(_p(x), _p(res), _p(out), x.numel(), ACT[act], _stream()), "bya_act_add")
+    return out

@@ -1,0 +1,168 @@
+/*
+ * bya.h -- C ABI of libbya_hip.so: the hand-written gfx950 (MI355X / CDNA4) kernels under the
+ * Bind-Your-Avatar per-denoise-step hot path.
+ *
+ * The reference (Yubo-Shankui/Bind-Your-Avatar-Implementation) is pure Python: its hot path is
+ * `BindyouravatarTransformer3DModel.forward` (models/transformer.py:615-964), called once per step by
+ * `BindyouravatarPipeline.__call__` (models/pipeline_bindyouravatar.py:910-923).  It has no FFI of its
+ * own; every op is a PyTorch dispatch.  This header is therefore the boundary a maintainer binds
+ * (ctypes stub in INTEGRATION.md) and each entry point cites the reference dispatches it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM); tensors are row-major, bf16 (raw uint16) unless noted;
+ *     fp32 for RoPE tables, fp32/int64 where stated.
+ *   - functions only enqueue work on `stream`; they never allocate, never synchronise, never throw.
+ *   - return value: 0 = ok, <0 = error (BYA_ERR_*): nothing was launched.
+ *   - "rows" of the joint sequence are [text rows (Tt=226) | video rows (N = T*Ht*Wt)], S = Tt + N.
+ */
+#ifndef BYA_H
+#define BYA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+enum { BYA_ACT_NONE = 0, BYA_ACT_GELU_TANH = 1, BYA_ACT_GELU_ERF = 2, BYA_ACT_RELU = 3, BYA_ACT_SILU = 4,
+       BYA_ACT_LEAKY_RELU = 5 };
+
+/* library / build identification: returns the ABI version (bumped when a signature changes). */
+int bya_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM:  C[z][m,n] = res[z][m,n] + gate[z][row-type(m)][n] * act( sum_k A[z][m,k] * W[n,k] + bias[n] )
+ * Replaces every nn.Linear / 2x2-stride Conv2d-as-GEMM on the path: attn1.to_q/k/v/to_out,
+ * ff.net.0.proj/ff.net.2 (models/transformer.py:241-260), perceiver to_q/to_out (models/router.py:253,275),
+ * router to_q/to_k and the SpatialTemporalAttentionBlock projections + mlp (models/router.py:381-383,
+ * 468-491), audio attn to_q/to_out (models/audio_model.py:253-256), patch_embed.proj/text_proj,
+ * proj_out (models/transformer.py:690,949), and the step-invariant LocalFacialExtractor /
+ * AudioProjModel linears (models/router.py:157-193, models/audio_model.py:78-114).
+ * bias/res/gate0 may be NULL.  gate1==NULL means gate0 for all rows; rows m < gate_split use gate0.
+ * Requirements: K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0, A/W 16-byte aligned.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct bya_gemm_desc {
+    int32_t M, N, K;          /* per batch entry */
+    int32_t batch;            /* grid.z; A/C/res/gate advance by the *_batch_stride (elements) */
+    int32_t lda, ldw, ldc, ldres;
+    int64_t a_batch_stride, c_batch_stride, res_batch_stride, gate_batch_stride;
+    int32_t gate_split;
+    int32_t act;              /* BYA_ACT_* applied to (acc + bias) */
+} bya_gemm_desc;
+
+int bya_gemm_bf16(const void* A, const void* W, const void* bias, void* C, const void* res,
+                  const void* gate0, const void* gate1, const bya_gemm_desc* desc, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small-M linear (M <= 8 rows):  out[m,n] = sum_k f(x[m,k]) * W[n,k] + bias[n],  f = identity or SiLU.
+ * HBM-bound weight stream.  Replaces TimestepEmbedding.linear_1/2, CogVideoXLayerNormZero.linear
+ * (models/transformer.py:198,212 -- all 2*num_layers of them in ONE launch over packed weights) and
+ * AdaLayerNorm.linear (models/transformer.py:420-426).  act_out applied after bias.
+ * --------------------------------------------------------------------------------------------- */
+int bya_linear_small_m(const void* x, const void* W, const void* bias, void* out, int32_t M, int32_t N,
+                       int32_t K, int32_t silu_in, int32_t act_out, hipStream_t stream);
+
+/* Sinusoidal timestep features (diffusers Timesteps, flip_sin_to_cos, shift 0) in fp32 then rounded
+ * to bf16: out[b, 0:dim/2] = cos(t*w_k), out[b, dim/2:] = sin(t*w_k)  (models/transformer.py:679-685). */
+int bya_timestep_features(const int64_t* timesteps, void* out, int32_t batch, int32_t dim,
+                          int32_t flip_sin_to_cos, float freq_shift, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim D (fp32 statistics), optional affine (w,b), optional AdaLN modulation
+ *   y = (LN(x)*w + b) * (1 + scale[z][type(row)]) + shift[z][type(row)]
+ * rows r < split use (shift0,scale0) else (shift1,scale1); mod pointers NULL = plain LayerNorm.
+ * Replaces CogVideoXLayerNormZero / AdaLayerNorm / nn.LayerNorm call sites
+ * (models/transformer.py:233,251,944,948; models/router.py:247-248,380-393,475-491;
+ * models/audio_model.py:249).  D in {512, 768, 1024, 2048, 3072}; rows_per_batch rows per z.
+ * --------------------------------------------------------------------------------------------- */
+int bya_layernorm(const void* x, void* y, const void* w, const void* b, const void* shift0, const void* scale0,
+                  const void* shift1, const void* scale1, int64_t rows_per_batch, int32_t batch, int32_t D,
+                  int64_t ldx, int64_t ldy, int64_t x_batch_stride, int64_t y_batch_stride,
+                  int64_t mod_batch_stride, int64_t split, float eps, hipStream_t stream);
+
+/* Per-head LayerNorm(64, eps, affine) on q and k followed by interleaved-pair RoPE on rows >= text_rows
+ * (diffusers CogVideoXAttnProcessor2_0 + apply_rotary_emb; models/transformer.py:204-208).  In place.
+ * q,k: [batch, S, heads*64] with row stride ld; cos,sin: fp32 [S - text_rows, 64]. */
+int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb, const void* kw, const void* kb,
+                    const float* cos, const float* sin, int32_t batch, int32_t S, int32_t heads, int64_t ld,
+                    int64_t batch_stride, int32_t text_rows, float eps, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Flash attention forward, head_dim 64 or 128, no mask, fp32 online softmax, bf16 P.V on MFMA.
+ *   O[b1,b2,i,h,:] = softmax_j( scale * Q[b1,b2,i,h,:].K[b1,b2,j,h,:] ) V[b1,b2,j,h,:]
+ * Two-level batch (b1 < nb1, b2 < nb2) with independent element strides so one kernel serves: the joint
+ * text+video self-attention (F.scaled_dot_product_attention inside CogVideoXAttnProcessor2_0,
+ * models/transformer.py:208), the router's spatial attention (models/router.py:476), the perceiver
+ * face cross-attention (models/router.py:264-270; q shared by both ids) and the per-frame audio
+ * cross-attention (models/audio_model.py:253-256).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct bya_attn_desc {
+    int32_t head_dim;       /* 64 or 128 */
+    int32_t heads;
+    int32_t nb1, nb2;
+    int32_t Sq, Skv;
+    int64_t q_s1, q_s2, q_row;   /* element strides: batch level 1, level 2, sequence row */
+    int64_t k_s1, k_s2, k_row;
+    int64_t v_s1, v_s2, v_row;
+    int64_t o_s1, o_s2, o_row;
+    float scale;
+} bya_attn_desc;
+
+int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya_attn_desc* desc,
+                 hipStream_t stream);
+
+/* Tiny-sequence self-attention (sequence length L <= 16, head_dim 64) used by the router's temporal
+ * (L = frames) and multi-ID (L = ids) attentions (models/router.py:482,488).  Element e of sequence
+ * `g` lives at row  g_outer(g)*outer_stride + e*seq_stride + g_inner(g)  of the [rows, ld] matrices,
+ * with g = g_outer * n_inner + g_inner. */
+int bya_attn_tiny(const void* q, const void* k, const void* v, void* o, int32_t L, int32_t heads,
+                  int64_t n_outer, int64_t n_inner, int64_t outer_stride, int64_t seq_stride, int64_t ld_qkv,
+                  int64_t ld_o, float scale, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Embedding-Router specific kernels (models/router.py:364-411).
+ * router_scores: s[id,n,tok*heads+h] = sum_d qr[n,h*128+d] * kr[id,tok,h*128+d]; LayerNorm(512, w,b);
+ *                + pos_emb[n]  ->  out[id,n,512]
+ * router_head:   r[n,id] = sigmoid(x[id,n,:].w + b)  ->  [N, n_id]  (the [1,N,n_id] routing logits)
+ * --------------------------------------------------------------------------------------------- */
+int bya_router_scores(const void* qr, const void* kr, const void* ln_w, const void* ln_b, const void* pos_emb,
+                      void* out, int32_t n_id, int64_t N, int32_t heads, int32_t face_tokens, float eps,
+                      hipStream_t stream);
+int bya_router_head(const void* x, const void* w, const void* b, void* r, int32_t n_id, int64_t N, int32_t D,
+                    hipStream_t stream);
+
+/* Forcing override (models/transformer.py:813-819): out[t,r,id] = max_t' forcing[t',r,id]. Bit-exact. */
+int bya_forcing_max_over_frames(const void* forcing, void* out, int32_t frames, int64_t per_frame,
+                                int32_t n_id, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Masked combines (models/transformer.py:821-822,831-832 and 860-863,895-900,925-926,935-936).
+ *  mode 0 (face):  x[b,n,:] += alpha * sum_id r[b][n,id] * feat[b,id,n,:]
+ *  mode 1 (audio): av[n,i] = bf16(sum_j af[b,i,j]*r[b][n,j]); w[n,id] = bf16(1 - av[n,1-id]);
+ *                  x[b,n,:] += sum_id w[n,id] * feat[b,id,n,:]
+ * r: [batch or 1, N, n_id] (r_batch_stride 0 = shared forcing mask); feat [batch, n_id, N, D]. In place.
+ * --------------------------------------------------------------------------------------------- */
+int bya_masked_combine(void* x, const void* feat, const void* r, const void* af, int32_t mode, float alpha,
+                       int32_t batch, int32_t n_id, int64_t N, int32_t D, int64_t x_row, int64_t x_batch_stride,
+                       int64_t r_batch_stride, hipStream_t stream);
+
+/* Patchify (im2col of the 2x2/stride-2 Conv2d of CogVideoXPatchEmbed, models/transformer.py:690):
+ *   cols[b, (t*Ht+h)*Wt+w, c*4+ph*2+pw] = x[b,t,c,2h+ph,2w+pw]
+ * and unpatchify (models/transformer.py:955-957):
+ *   out[b,t,c,2h+ph,2w+pw] = y[b,(t*Ht+h)*Wt+w, c*4+ph*2+pw].  Index-only, bit-exact. */
+int bya_patchify(const void* x, void* cols, int32_t batch, int32_t frames, int32_t channels, int32_t H, int32_t W,
+                 hipStream_t stream);
+int bya_unpatchify(const void* y, void* out, int32_t batch, int32_t frames, int32_t channels, int32_t H, int32_t W,
+                   hipStream_t stream);
+
+/* Elementwise helpers: y = act(x) (+ r) over n bf16 elements (n % 8 == 0). */
+int bya_act_add(const void* x, const void* r, void* y, int64_t n, int32_t act, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BYA_H */

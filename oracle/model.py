@@ -1,0 +1,453 @@
+"""CPU restatement of the reference-owned part of the denoise-step hot path.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  Each class cites the reference
+lines it follows.  Pinned against the reference itself (imported in the build
+container) by ``tests/golden/make_golden.py`` -> ``tests/golden/*.npz`` and
+``tests/test_oracle_golden.py``.
+
+The restatement is written size-agnostically (token grid (T, Ht, Wt) and the number
+of identities come from the inputs) so the same code can check the HIP engine at
+small sizes; at the reference's hard-coded geometry (13 x 30 x 45 tokens, 2 ids;
+models/transformer.py:739,815, models/router.py:312-314) it reproduces the
+reference exactly.  Generalisation rules (build-defined, DESIGN.md "geometry"):
+the router keeps the reference's swapped naming, i.e. its positional table is
+indexed ``[t, a, b]`` with ``a = r // Ht``, ``b = r % Ht`` for the within-frame token
+``r = h * Wt + w`` (at 30 x 45 that is the reference's ``(13, 45, 30)`` view).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .layers import (AdaLayerNorm, Attention, CogVideoXAttnProcessor2_0, CogVideoXLayerNormZero,
+                     CogVideoXPatchEmbed, FeedForward, TimestepEmbedding, Timesteps)
+
+
+def split_heads(x, heads):
+    """models/router.py:20-28: [b, n, h*d] -> [b, h, n, d]."""
+    b, n, _ = x.shape
+    return x.view(b, n, heads, -1).transpose(1, 2).reshape(b, heads, n, -1)
+
+
+def _ffn(dim, mult=4):
+    """models/router.py:10-17."""
+    inner = int(dim * mult)
+    return nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, inner, bias=False), nn.GELU(),
+                         nn.Linear(inner, dim, bias=False))
+
+
+class PerceiverAttention(nn.Module):
+    """models/router.py:31-75 (used by the LocalFacialExtractor only)."""
+
+    def __init__(self, *, dim, dim_head=64, heads=8, kv_dim=None):
+        super().__init__()
+        self.dim_head, self.heads = dim_head, heads
+        inner = dim_head * heads
+        self.norm1 = nn.LayerNorm(dim if kv_dim is None else kv_dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_kv = nn.Linear(dim if kv_dim is None else kv_dim, inner * 2, bias=False)
+        self.to_out = nn.Linear(inner, dim, bias=False)
+
+    def forward(self, x, latents):
+        x, latents = self.norm1(x), self.norm2(latents)
+        b, n, _ = latents.shape
+        q = split_heads(self.to_q(latents), self.heads)
+        k, v = self.to_kv(torch.cat((x, latents), dim=-2)).chunk(2, dim=-1)
+        k, v = split_heads(k, self.heads), split_heads(v, self.heads)
+        s = 1 / math.sqrt(math.sqrt(self.dim_head))
+        w = (q * s) @ (k * s).transpose(-2, -1)
+        w = torch.softmax(w.float(), dim=-1).type(w.dtype)
+        out = (w @ v).permute(0, 2, 1, 3).reshape(b, n, -1)
+        return self.to_out(out)
+
+
+class LocalFacialExtractor(nn.Module):
+    """models/router.py:78-193 (step-invariant face tokens)."""
+
+    def __init__(self, dim=1024, depth=10, dim_head=64, heads=16, num_id_token=5, num_queries=32,
+                 output_dim=2048, ff_mult=4):
+        super().__init__()
+        assert depth % 5 == 0
+        self.num_id_token, self.dim, self.num_queries, self.depth = num_id_token, dim, num_queries, depth // 5
+        scale = dim ** -0.5
+        self.latents = nn.Parameter(torch.randn(1, num_queries, dim) * scale)
+        self.proj_out = nn.Parameter(scale * torch.randn(dim, output_dim))
+        self.layers = nn.ModuleList([
+            nn.ModuleList([PerceiverAttention(dim=dim, dim_head=dim_head, heads=heads), _ffn(dim, ff_mult)])
+            for _ in range(depth)])
+
+        def mapper(d_in, d_out):
+            return nn.Sequential(nn.Linear(d_in, 1024), nn.LayerNorm(1024), nn.LeakyReLU(),
+                                 nn.Linear(1024, 1024), nn.LayerNorm(1024), nn.LeakyReLU(),
+                                 nn.Linear(1024, d_out))
+
+        for i in range(5):
+            setattr(self, f"mapping_{i}", mapper(1024, dim))
+        self.id_embedding_mapping = mapper(1280, dim * num_id_token)
+
+    def forward(self, x, y):
+        latents = self.latents.repeat(x.size(0), 1, 1)
+        x = self.id_embedding_mapping(x).reshape(-1, self.num_id_token, self.dim)
+        latents = torch.cat((latents, x), dim=1)
+        for i in range(5):
+            ctx = torch.cat((x, getattr(self, f"mapping_{i}")(y[i])), dim=1)
+            for attn, ff in self.layers[i * self.depth:(i + 1) * self.depth]:
+                latents = attn(ctx, latents) + latents
+                latents = ff(latents) + latents
+        return latents[:, :self.num_queries] @ self.proj_out
+
+
+class PerceiverCrossAttention(nn.Module):
+    """models/router.py:196-275: face tokens (kv) attended by every video token (q)."""
+
+    def __init__(self, *, dim=3072, dim_head=128, heads=16, kv_dim=2048):
+        super().__init__()
+        self.dim_head, self.heads = dim_head, heads
+        inner = dim_head * heads
+        self.norm1 = nn.LayerNorm(dim if kv_dim is None else kv_dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_kv = nn.Linear(dim if kv_dim is None else kv_dim, inner * 2, bias=False)
+        self.to_out = nn.Linear(inner, dim, bias=False)
+
+    def forward(self, x, latents):
+        x, latents = self.norm1(x), self.norm2(latents)
+        b, n, _ = latents.shape
+        q = split_heads(self.to_q(latents), self.heads)
+        k, v = self.to_kv(x).chunk(2, dim=-1)
+        k, v = split_heads(k, self.heads), split_heads(v, self.heads)
+        q_out, k_out = q.clone(), k.clone()          # UN-scaled copies go to the router (:260-261)
+        s = 1 / math.sqrt(math.sqrt(self.dim_head))
+        w = (q * s) @ (k * s).transpose(-2, -1)
+        w_out = w.clone()
+        w = torch.softmax(w.float(), dim=-1).type(w.dtype)
+        out = (w @ v).permute(0, 2, 1, 3).reshape(b, n, -1)
+        return self.to_out(out), w_out, q_out, k_out
+
+
+class SpatialTemporalAttentionBlock(nn.Module):
+    """models/router.py:425-493."""
+
+    def __init__(self, dim, num_heads=8, mlp_ratio=4):
+        super().__init__()
+        mk = lambda: Attention(query_dim=dim, heads=num_heads, dim_head=dim // num_heads, bias=True)
+        self.spatial_attn, self.temporal_attn, self.multi_id_attn = mk(), mk(), mk()
+        self.norm1, self.norm2, self.norm3, self.norm4 = (nn.LayerNorm(dim) for _ in range(4))
+        hid = int(dim * mlp_ratio)
+        self.mlp = nn.Sequential(nn.Linear(dim, hid), nn.GELU(), nn.Linear(hid, dim))
+
+    def forward(self, x):
+        i, t, a, b, c = x.shape
+        x = x + self.spatial_attn(self.norm1(x.reshape(i * t, a * b, c))).reshape(i, t, a, b, c)
+        xt = self.norm2(x.permute(0, 2, 3, 1, 4).reshape(i * a * b, t, c))
+        x = x + self.temporal_attn(xt).reshape(i, a, b, t, c).permute(0, 3, 1, 2, 4)
+        xi = self.norm3(x.permute(2, 3, 1, 0, 4).reshape(a * b * t, i, c))
+        x = x + self.multi_id_attn(xi).reshape(a, b, t, i, c).permute(3, 2, 0, 1, 4)
+        x = x + self.mlp(self.norm4(x.reshape(-1, c))).reshape(i, t, a, b, c)
+        return x
+
+
+def router_pos_emb(frames, height, width, feat_dim):
+    """models/router.py:334-362 (three sin/cos thirds + zero pad)."""
+    third = feat_dim // 3
+    div = torch.pow(10000, torch.arange(0, third, 2).float() / third)
+
+    def axis(n):
+        e = torch.arange(n).float().unsqueeze(-1) / div
+        return torch.stack([torch.sin(e), torch.cos(e)], dim=-1).flatten(-2)
+
+    t = axis(frames)[:, None, None, :].expand(-1, height, width, -1)
+    h = axis(height)[None, :, None, :].expand(frames, -1, width, -1)
+    w = axis(width)[None, None, :, :].expand(frames, height, -1, -1)
+    pe = torch.cat([t, h, w], dim=-1)
+    if pe.size(-1) < feat_dim:
+        pe = torch.cat([pe, torch.zeros(frames, height, width, feat_dim - pe.size(-1))], dim=-1)
+    return pe.contiguous()
+
+
+class MultiIPRouter(nn.Module):
+    """models/router.py:280-411.  ``frames/height/width`` default to the reference's constants."""
+
+    def __init__(self, *, num_id_token=32, num_heads=16, inner_dim1=256, inner_dim2=128, inner_dim3=32,
+                 addtional_dim=3, num_layers=21, q_k_dim=2048, frames=13, height=45, width=30):
+        super().__init__()
+        wdim = num_id_token * num_heads
+        self.heads = num_heads
+        self.norm = nn.LayerNorm(wdim)
+        self.norm_q = nn.LayerNorm(q_k_dim)
+        self.norm_k = nn.LayerNorm(q_k_dim)
+        self.to_q = nn.ModuleList([nn.Linear(q_k_dim, q_k_dim, bias=False) for _ in range(num_layers)])
+        self.to_k = nn.ModuleList([nn.Linear(q_k_dim, q_k_dim, bias=False) for _ in range(num_layers)])
+        self.layer_merge = nn.ModuleList([  # dead parameters, kept so checkpoints load (:304-309)
+            nn.Sequential(nn.Linear(wdim + addtional_dim, inner_dim1, bias=True), nn.ReLU(),
+                          nn.Linear(inner_dim1, inner_dim2, bias=False), nn.ReLU())
+            for _ in range(num_layers)])
+        self.frames, self.height, self.width, self.feat_dim = frames, height, width, wdim
+        self.register_buffer("pos_emb", router_pos_emb(frames, height, width, wdim))
+        self.spatial_temporal_layers = nn.ModuleList(
+            [SpatialTemporalAttentionBlock(dim=wdim, num_heads=8, mlp_ratio=1) for _ in range(4)])
+        self.final_proj = nn.Sequential(nn.Linear(wdim, 1), nn.Sigmoid())
+
+    def forward(self, weight, q_out, k_out, layer_idx, is_teacher_forcing=False):
+        n_id = q_out.size(0)
+        q = q_out.permute(0, 2, 3, 1)
+        q = q.reshape(q.size(0), q.size(1), -1)          # feature index d*heads + h
+        k = k_out.permute(0, 2, 3, 1)
+        k = k.reshape(k.size(0), k.size(1), -1)
+        q = self.to_q[layer_idx](self.norm_q(q))
+        k = self.to_k[layer_idx](self.norm_k(k))
+        q, k = split_heads(q, self.heads), split_heads(k, self.heads)   # re-interpreted as h'*128 + d'
+        s = (q @ k.transpose(-2, -1)).permute(0, 2, 3, 1)
+        s = self.norm(s.reshape(s.size(0), s.size(1), -1))               # index tok*heads + h'
+        s = s.reshape(n_id, self.frames, self.height, self.width, -1) + self.pos_emb
+        for layer in self.spatial_temporal_layers:
+            s = layer(s)
+        out = self.final_proj(s.reshape(n_id, -1, self.feat_dim))
+        return out.permute(2, 1, 0)                                       # [1, N, n_id]
+
+
+class AudioProjModel(nn.Module):
+    """models/audio_model.py:43-114."""
+
+    def __init__(self, seq_len=5, blocks=12, channels=768, intermediate_dim=512, output_dim=768,
+                 context_tokens=32):
+        super().__init__()
+        self.context_tokens, self.output_dim = context_tokens, output_dim
+        self.proj1 = nn.Linear(seq_len * blocks * channels, intermediate_dim)
+        self.proj2 = nn.Linear(intermediate_dim, intermediate_dim)
+        self.proj3 = nn.Linear(intermediate_dim, context_tokens * output_dim)
+        self.norm = nn.LayerNorm(output_dim)
+        self.conv1 = nn.Conv1d(context_tokens * output_dim, context_tokens * output_dim, kernel_size=2, stride=2)
+
+    def forward(self, audio_embeds):
+        bz, f = audio_embeds.shape[:2]
+        x = audio_embeds.reshape(bz * f, -1)
+        x = torch.relu(self.proj2(torch.relu(self.proj1(x))))
+        x = self.proj3(x).reshape(bz, f, -1)                      # [bz, f, 32*768]
+        c = x.shape[-1]
+        for _ in range(2):                                        # 49 -> 25 -> 13 (first frame kept)
+            x = x.permute(0, 2, 1)
+            if x.shape[-1] % 2 == 1:
+                first, rest = x[..., 0], x[..., 1:]
+                if rest.shape[-1] > 0:
+                    rest = self.conv1(rest)
+                x = torch.cat([first[..., None], rest], dim=-1)
+            else:
+                x = self.conv1(x)
+            x = x.reshape(bz, c, x.shape[-1]).permute(0, 2, 1)
+        x = x.reshape(bz, x.shape[1], self.context_tokens, self.output_dim)
+        return self.norm(x)
+
+
+class AudioAwareModel(nn.Module):
+    """models/audio_model.py:130-261."""
+
+    def __init__(self, dim=3072, audio_dim=768, num_attention_heads=48, attention_head_dim=64, window_size=5,
+                 window_stride=1, norm_elementwise_affine=True, norm_eps=1e-5, num_layers=42,
+                 audio_cross_attn_scale=0.05):
+        super().__init__()
+        self.window_size, self.window_stride = window_size, window_stride
+        self.learnable_scale = nn.Parameter(torch.tensor([0.01]))      # dead parameter
+        self.audio_proj_model = AudioProjModel()
+        self.layers = nn.ModuleList([
+            nn.ModuleDict({
+                "norm_q": nn.LayerNorm(dim, norm_eps, norm_elementwise_affine),
+                "attn": Attention(query_dim=dim, cross_attention_dim=audio_dim, dim_head=attention_head_dim,
+                                  heads=num_attention_heads, bias=True)})
+            for _ in range(num_layers)])
+        self.mute_learnable_tokens = nn.Parameter(torch.zeros(1, 32, 768))
+
+    def sliding_windows(self, audio_embeds, num_frames):
+        assert 1 + (num_frames - 1) * 4 + (self.window_size - self.window_stride) == audio_embeds.shape[1], \
+            f"audio length {audio_embeds.shape[1]} does not match {num_frames} latent frames"
+        return audio_embeds.unfold(1, self.window_size, self.window_stride).permute(0, 1, 4, 2, 3)
+
+    def proj_in(self, audio_embeds):
+        return self.audio_proj_model(audio_embeds)
+
+    def forward(self, audio_ctx, hidden_states, num_frames, layer_index):
+        layer = self.layers[layer_index]
+        b, n, d = hidden_states.shape
+        h = layer["norm_q"](hidden_states.reshape(b * num_frames, n // num_frames, d))
+        a = audio_ctx.reshape(b * num_frames, -1, audio_ctx.shape[-1])
+        return layer["attn"](hidden_states=h, encoder_hidden_states=a).reshape(b, n, d)
+
+
+class CogVideoXBlock(nn.Module):
+    """models/transformer.py:143-262."""
+
+    def __init__(self, dim, num_attention_heads, attention_head_dim, time_embed_dim, dropout=0.0,
+                 activation_fn="gelu-approximate", attention_bias=False, qk_norm=True,
+                 norm_elementwise_affine=True, norm_eps=1e-5, final_dropout=True, ff_inner_dim=None,
+                 ff_bias=True, attention_out_bias=True):
+        super().__init__()
+        self.norm1 = CogVideoXLayerNormZero(time_embed_dim, dim, norm_elementwise_affine, norm_eps, bias=True)
+        self.attn1 = Attention(query_dim=dim, dim_head=attention_head_dim, heads=num_attention_heads,
+                               qk_norm="layer_norm" if qk_norm else None, eps=1e-6, bias=attention_bias,
+                               out_bias=attention_out_bias, processor=CogVideoXAttnProcessor2_0())
+        self.norm2 = CogVideoXLayerNormZero(time_embed_dim, dim, norm_elementwise_affine, norm_eps, bias=True)
+        self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn, final_dropout=final_dropout,
+                              inner_dim=ff_inner_dim, bias=ff_bias)
+
+    def forward(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb=None):
+        t_len = encoder_hidden_states.size(1)
+        nh, ne, gate, e_gate = self.norm1(hidden_states, encoder_hidden_states, temb)
+        ah, ae = self.attn1(hidden_states=nh, encoder_hidden_states=ne, image_rotary_emb=image_rotary_emb)
+        hidden_states = hidden_states + gate * ah
+        encoder_hidden_states = encoder_hidden_states + e_gate * ae
+        nh, ne, gate, e_gate = self.norm2(hidden_states, encoder_hidden_states, temb)
+        ff = self.ff(torch.cat([ne, nh], dim=1))
+        hidden_states = hidden_states + gate * ff[:, t_len:]
+        encoder_hidden_states = encoder_hidden_states + e_gate * ff[:, :t_len]
+        return hidden_states, encoder_hidden_states
+
+
+def forcing_over_frames(forcing, grid):
+    """models/transformer.py:813-819: OR (max) over the frame axis, broadcast back."""
+    t, ht, wt = grid
+    f = forcing.view(1, t, ht, wt, forcing.shape[-1])
+    return f.max(dim=1).values.unsqueeze(1).repeat(1, t, 1, 1, 1).reshape(1, t * ht * wt, -1)
+
+
+def masked_combine(weights, feats):
+    """models/transformer.py:821-822 / 925-926: out[n] = sum_id weights[0,n,id] * feats[id,n,:]."""
+    return (weights.transpose(1, 0) @ feats.transpose(1, 0)).transpose(1, 0)
+
+
+class OracleTransformer(nn.Module):
+    """Inference branch of ``BindyouravatarTransformer3DModel`` (models/transformer.py:265-964).
+
+    Same constructor keywords and state-dict keys as the reference class; ``forward`` restates
+    models/transformer.py:615-964 with ``index_mask=None`` (training branches omitted).
+    ``taps`` (optional dict) receives intermediate tensors for the parity tests.
+    """
+
+    def __init__(self, num_attention_heads=48, attention_head_dim=64, in_channels=16, out_channels=16,
+                 flip_sin_to_cos=True, freq_shift=0, time_embed_dim=512, text_embed_dim=4096, num_layers=30,
+                 dropout=0.0, attention_bias=True, sample_width=90, sample_height=60, sample_frames=49,
+                 patch_size=2, temporal_compression_ratio=4, max_text_seq_length=226,
+                 activation_fn="gelu-approximate", timestep_activation_fn="silu", norm_elementwise_affine=True,
+                 norm_eps=1e-5, spatial_interpolation_scale=1.875, temporal_interpolation_scale=1.0,
+                 use_rotary_positional_embeddings=False, use_learned_positional_embeddings=False,
+                 is_train_face=True, is_kps=False, cross_attn_interval=1, LFE_num_tokens=32, LFE_output_dim=768,
+                 LFE_heads=12, local_face_scale=1.0, is_train_audio=False, audio_attn_interval=1, **ignored):
+        super().__init__()
+        inner = num_attention_heads * attention_head_dim
+        self.cfg = dict(patch_size=patch_size, use_rotary=use_rotary_positional_embeddings)
+        self.patch_embed = CogVideoXPatchEmbed(
+            patch_size=patch_size, in_channels=in_channels, embed_dim=inner, text_embed_dim=text_embed_dim,
+            bias=True, sample_width=sample_width, sample_height=sample_height, sample_frames=sample_frames,
+            temporal_compression_ratio=temporal_compression_ratio, max_text_seq_length=max_text_seq_length,
+            spatial_interpolation_scale=spatial_interpolation_scale,
+            temporal_interpolation_scale=temporal_interpolation_scale,
+            use_positional_embeddings=not use_rotary_positional_embeddings,
+            use_learned_positional_embeddings=use_learned_positional_embeddings)
+        self.time_proj = Timesteps(inner, flip_sin_to_cos, freq_shift)
+        self.time_embedding = TimestepEmbedding(inner, time_embed_dim, timestep_activation_fn)
+        self.transformer_blocks = nn.ModuleList([
+            CogVideoXBlock(dim=inner, num_attention_heads=num_attention_heads,
+                           attention_head_dim=attention_head_dim, time_embed_dim=time_embed_dim, dropout=dropout,
+                           activation_fn=activation_fn, attention_bias=attention_bias,
+                           norm_elementwise_affine=norm_elementwise_affine, norm_eps=norm_eps)
+            for _ in range(num_layers)])
+        self.norm_final = nn.LayerNorm(inner, norm_eps, norm_elementwise_affine)
+        self.norm_out = AdaLayerNorm(embedding_dim=time_embed_dim, output_dim=2 * inner,
+                                     norm_elementwise_affine=norm_elementwise_affine, norm_eps=norm_eps,
+                                     chunk_dim=1)
+        self.proj_out = nn.Linear(inner, patch_size * patch_size * out_channels)
+        self.is_train_face, self.is_train_audio = is_train_face, is_train_audio
+        frames = (sample_frames - 1) // temporal_compression_ratio + 1
+        ht, wt = sample_height // patch_size, sample_width // patch_size
+        if is_train_face:
+            self.cross_attn_interval = cross_attn_interval
+            self.num_ca = num_layers // cross_attn_interval
+            self.local_face_scale = local_face_scale
+            self.local_facial_extractor = LocalFacialExtractor()
+            self.perceiver_cross_attention = nn.ModuleList([
+                PerceiverCrossAttention(dim=inner, dim_head=128, heads=16, kv_dim=int(inner / 3 * 2))
+                for _ in range(self.num_ca)])
+            self.router = MultiIPRouter(num_layers=self.num_ca, frames=frames, height=wt, width=ht)
+        if is_train_audio:
+            self.audio_attn_interval = audio_attn_interval
+            self.audio_model = AudioAwareModel(dim=inner, num_attention_heads=num_attention_heads,
+                                               attention_head_dim=attention_head_dim,
+                                               norm_elementwise_affine=norm_elementwise_affine, norm_eps=norm_eps,
+                                               num_layers=num_layers // audio_attn_interval)
+
+    @torch.no_grad()
+    def forward(self, hidden_states, encoder_hidden_states, timestep, timestep_cond=None, image_rotary_emb=None,
+                attention_kwargs=None, id_cond=None, id_vit_hidden=None, index_mask=None, return_dict=True,
+                audio_embeds=None, af_matrix=None, denoise_step=None, index_mask_drop_prob=0.0,
+                routing_logits_zeros_flag=False, routing_logits_forcing=None, taps=None):
+        assert index_mask is None, "the oracle restates the inference branch only"
+        taps = {} if taps is None else taps
+        n_id = 2
+        if self.is_train_face:
+            assert id_cond is not None and id_vit_hidden is not None
+            embs = [self.local_facial_extractor(id_cond[i], id_vit_hidden[i]) for i in range(n_id)]
+            face = [torch.stack([e[j] for e in embs]) for j in range(embs[0].shape[0])]   # per sample [n_id,32,2048]
+            taps["face_emb"] = torch.stack(face)
+        b, t, c, h, w = hidden_states.shape
+        p = self.cfg["patch_size"]
+        grid = (t, h // p, w // p)
+        n_tok = grid[0] * grid[1] * grid[2]
+
+        use_audio = self.is_train_audio and audio_embeds is not None
+        if use_audio:
+            a = audio_embeds.to(hidden_states.dtype)
+            assert a.ndim == 5, "single-stream audio needs tests/input/ae_mute.pt, absent from the reference"
+            bs, ni, fr, blk, ad = a.shape
+            a = self.audio_model.sliding_windows(a.view(bs * ni, fr, blk, ad), t)
+            ctx = self.audio_model.proj_in(a)
+            ctx = ctx.view(bs, ni, *ctx.shape[-3:])                                       # [B, n_id, T, 32, 768]
+            taps["audio_ctx"] = ctx
+
+        emb = self.time_embedding(self.time_proj(timestep).to(hidden_states.dtype), timestep_cond)
+        taps["emb"] = emb
+        x = self.patch_embed(encoder_hidden_states, hidden_states)
+        t_len = encoder_hidden_states.shape[1]
+        enc, hid = x[:, :t_len], x[:, t_len:]
+        taps["embed"] = x
+
+        ca_idx = 0
+        routing = None
+        for i, block in enumerate(self.transformer_blocks):
+            hid, enc = block(hid, enc, emb, image_rotary_emb)
+            taps[f"block{i}"] = torch.cat([enc, hid], dim=1)
+            if self.is_train_face and i % self.cross_attn_interval == 0:
+                routing, feats = [], []
+                for j in range(b):
+                    sub = hid[j].repeat(n_id, 1, 1)
+                    id_feat, w_out, q_out, k_out = self.perceiver_cross_attention[ca_idx](face[j], sub)
+                    r = self.router(w_out, q_out, k_out, ca_idx)
+                    taps[f"router{ca_idx}_b{j}"] = r
+                    if routing_logits_forcing is not None:
+                        r = forcing_over_frames(routing_logits_forcing.to(r.dtype), grid)
+                    routing.append(r)
+                    feats.append(masked_combine(r, id_feat))
+                    if j == 0:
+                        taps[f"id_feat{ca_idx}"] = id_feat
+                hid = hid + self.local_face_scale * torch.cat(feats)
+                taps[f"face{i}"] = hid
+                ca_idx += 1
+            if use_audio and i % self.audio_attn_interval == 0:
+                r_all = torch.cat(routing, dim=0).to(hid.dtype)
+                av = (af_matrix.to(hid.dtype) @ r_all.transpose(-2, -1)).transpose(-2, -1)   # [B, N, n_id]
+                feats = []
+                for j in range(b):
+                    sub = hid[j].repeat(n_id, 1, 1)
+                    af = self.audio_model(ctx[j], sub, t, i // self.audio_attn_interval)
+                    wgt = 1 - av[j].unsqueeze(0)[:, :, [1, 0]]
+                    feats.append(masked_combine(wgt, af))
+                hid = hid + torch.cat(feats)
+                taps[f"audio{i}"] = hid
+
+        if not self.cfg["use_rotary"]:
+            hid = self.norm_final(hid)
+        else:
+            hid = self.norm_final(torch.cat([enc, hid], dim=1))[:, t_len:]
+        hid = self.proj_out(self.norm_out(hid, temb=emb))
+        out = hid.reshape(b, t, h // p, w // p, -1, p, p).permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+        return (out, None, None, None, None)
