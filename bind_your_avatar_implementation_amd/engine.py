@@ -1,0 +1,461 @@
+"""The per-denoise-step engine: host-side sequencing of the hand-written HIP kernels.
+
+One ``DenoiseEngine.step`` == one reference ``BindyouravatarTransformer3DModel.forward``
+(reference models/transformer.py:615-964, inference branch).  Design (DESIGN.md has the full picture):
+
+* ONE resident activation stream ``x [B, S, D]`` (text rows first, video rows behind): the reference's
+  ``torch.cat([enc, hid])`` / ``split`` round trips (diffusers CogVideoXAttnProcessor2_0, CogVideoXBlock)
+  disappear; kernels pick the text/video AdaLN triplet by row index.
+* All 2L+1 AdaLN modulation vectors of a step come from ONE weight-streaming launch over packed weights
+  (``emb`` is layer-invariant).
+* The per-sample Python loops + ``repeat(2,1,1)`` + ``empty_cache()`` of the reference
+  (models/transformer.py:779-832, 870-936) become batched launches; work the reference does twice on
+  identical data (perceiver ``to_q``, router ``norm_q``/``to_q`` for both ids) is done once.
+* The router's head-interleaving permutes (models/router.py:375-378) are folded into the weights at pack time.
+* Step-invariant tensors (face tokens, per-layer face K/V, router keys, audio context, per-layer audio K/V) are
+  produced by ``_face_invariants`` / ``_audio_invariants``; they are recomputed every step like the reference
+  unless ``cache_invariants`` is switched on (explicit opt-in used by the pipeline).
+
+Nothing here falls back to torch math: torch is used for device memory, views and copies only.
+"""
+import torch
+
+from . import ops
+
+
+def _key(tensors):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+
+
+class DenoiseEngine:
+    N_ID = 2          # the reference forward dereferences exactly id_cond[0], id_cond[1] (models/transformer.py:638-639)
+
+    def __init__(self, model):
+        p = model.proj_out.weight
+        if not p.is_cuda:
+            raise RuntimeError("the Bind-Your-Avatar MI355X engine needs its parameters on a GPU "
+                               "(there is no CPU fallback); call model.to('cuda')")
+        if p.dtype != torch.bfloat16:
+            raise RuntimeError(f"engine computes in bf16 (MFMA, fp32 accumulate); parameters are {p.dtype}")
+        ops._hip.load()      # fail loudly right here if libbya_hip.so is missing
+        self.m = model
+        self.cfg = model.config
+        self.dev = p.device
+        self.D = model.inner_dim
+        self.H = self.cfg.num_attention_heads
+        self.L = len(model.transformer_blocks)
+        self.Tt_max = self.cfg.max_text_seq_length
+        self.cache_invariants = False
+        self._inv_cache = {}
+        self._ws_key, self._ws = None, None
+        if model.is_train_audio and not model.is_train_face:
+            raise RuntimeError("audio injection needs the face router's logits (models/transformer.py:860)")
+        self._pack()
+
+    # ------------------------------------------------------------------------------------------ packing
+    def _pack(self):
+        m, D = self.m, self.D
+        cat = torch.cat
+        mods_w, mods_b = [], []
+        for blk in m.transformer_blocks:
+            for nz in (blk.norm1, blk.norm2):
+                mods_w.append(nz.linear.weight)
+                mods_b.append(nz.linear.bias)
+        mods_w.append(m.norm_out.linear.weight)
+        mods_b.append(m.norm_out.linear.bias)
+        self.mod_w = cat(mods_w).contiguous()          # [(2L*6 + 2) * D, temb]
+        self.mod_b = cat(mods_b).contiguous()
+        self.patch_w = m.patch_embed.proj.weight.reshape(D, -1)   # [D, C*4], k = c*4 + ph*2 + pw
+        pe = getattr(m.patch_embed, "pos_embedding", None)
+        use_pe = (not self.cfg.use_rotary_positional_embeddings) or self.cfg.use_learned_positional_embeddings
+        self.pos_embedding = pe[0] if (pe is not None and use_pe) else None
+        if m.is_train_face:
+            r = m.router
+            qk = r.norm_q.weight.numel()
+            hd = qk // r.heads
+            j = torch.arange(qk, device=self.dev)
+            perm = (j % hd) * r.heads + j // hd           # natural (h*128+d) position -> router's (d*16+h) index
+            self.r_nq_w, self.r_nq_b = r.norm_q.weight[perm].contiguous(), r.norm_q.bias[perm].contiguous()
+            self.r_nk_w, self.r_nk_b = r.norm_k.weight[perm].contiguous(), r.norm_k.bias[perm].contiguous()
+            self.r_to_q = [l.weight[:, perm].contiguous() for l in r.to_q]
+            self.r_to_k = [l.weight[:, perm].contiguous() for l in r.to_k]
+            self.r_pos = r.pos_emb.reshape(-1, r.feat_dim).contiguous()
+            self.r_qkv = []
+            for st in r.spatial_temporal_layers:
+                packed = {}
+                for name in ("spatial_attn", "temporal_attn", "multi_id_attn"):
+                    a = getattr(st, name)
+                    packed[name] = (cat([a.to_q.weight, a.to_k.weight, a.to_v.weight]).contiguous(),
+                                    cat([a.to_q.bias, a.to_k.bias, a.to_v.bias]).contiguous())
+                self.r_qkv.append(packed)
+            self.lfe_proj_t = m.local_facial_extractor.proj_out.t().contiguous()
+        if m.is_train_audio:
+            cw = m.audio_model.audio_proj_model.conv1.weight             # [C, C, 2] -> [C, 2*C], k = pos*C + i
+            self.conv_w = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).contiguous()
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _buf(self, name, *shape):
+        t = self._ws.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(*shape, dtype=torch.bfloat16, device=self.dev)
+            self._ws[name] = t
+        return t
+
+    def _linear(self, x, lin_w, lin_b, out, act=None, res=None):
+        """x: [(G,) M, K] -> out; weight-streaming kernel for tiny M, MFMA GEMM otherwise."""
+        if x.dim() == 2 and x.shape[0] <= 8 and res is None and act in (None, "silu") and x.is_contiguous() \
+                and out.is_contiguous():
+            return ops.linear_small_m(x, lin_w, lin_b, out, act_out=act)
+        return ops.gemm(x, lin_w, out, bias=lin_b, act=act, res=res)
+
+    @staticmethod
+    def _ln(x, out, ln, eps=None):
+        return ops.layernorm(x, out, ln.weight, ln.bias, eps=ln.eps if eps is None else eps)
+
+    def _bf(self, t):
+        return t.to(device=self.dev, dtype=torch.bfloat16).contiguous()
+
+    # ------------------------------------------------------------------------------------------ invariants
+    def _face_invariants(self, id_cond, id_vit_hidden, B):
+        """LocalFacialExtractor (models/router.py:157-193) + the per-layer face K/V (router.py:247,254) and router
+        keys (router.py:377-383).  Returns (kv[l] [B,n_id,32,2*inner], kr[l] [B,n_id,32,qk])."""
+        m, n_id = self.m, self.N_ID
+        lfe = m.local_facial_extractor
+        G, dim = n_id * B, lfe.dim
+        nq, nt = lfe.num_queries, lfe.num_id_token
+        idc = self._bf(torch.cat([id_cond[i] for i in range(n_id)], 0))                    # [(id,b), 1280]
+        vit = [self._bf(torch.cat([id_vit_hidden[i][k] for i in range(n_id)], 0)) for k in range(5)]
+        n_vit = vit[0].shape[1]
+        E = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=self.dev)
+
+        def mapper(seq, x, out_last):
+            h = x
+            for a, b in ((0, 1), (3, 4)):
+                t = E(*h.shape[:-1], seq[a].weight.shape[0])
+                self._linear(h, seq[a].weight, seq[a].bias, t)
+                self._ln(t, t, seq[b])
+                ops.act_add(t, t, act="leaky_relu")
+                h = t
+            return self._linear(h, seq[6].weight, seq[6].bias, out_last)
+
+        x_tok = mapper(lfe.id_embedding_mapping, idc, E(G, nt * dim)).view(G, nt, dim)
+        lat = E(G, nq + nt, dim)
+        lat[:, :nq] = lfe.latents.to(torch.bfloat16)
+        lat[:, nq:] = x_tok
+        n_ctx, n_lat = nt + n_vit, nq + nt
+        ctx = E(G, n_ctx, dim)
+        ctx[:, :nt] = x_tok
+        kvin = E(G, n_ctx + n_lat, dim)
+        inner = lfe.heads * lfe.dim_head
+        q, kv = E(G, n_lat, inner), E(G, n_ctx + n_lat, 2 * inner)
+        ao, f = E(G, n_lat, inner), E(G, n_lat, dim)
+        hid = E(G, n_lat, lfe.layers[0][1][1].weight.shape[0])
+        for lvl in range(5):
+            mapper(getattr(lfe, f"mapping_{lvl}"), vit[lvl], ctx[:, nt:])
+            for attn, ff in lfe.layers[lvl * lfe.depth:(lvl + 1) * lfe.depth]:
+                self._ln(ctx, kvin[:, :n_ctx], attn.norm1)
+                self._ln(lat, kvin[:, n_ctx:], attn.norm2)
+                ops.gemm(kvin[:, n_ctx:], attn.to_q.weight, q)
+                ops.gemm(kvin, attn.to_kv.weight, kv)
+                ops.self_attention(q, kv[:, :, :inner], kv[:, :, inner:], ao, heads=lfe.heads,
+                                   head_dim=lfe.dim_head)
+                ops.gemm(ao, attn.to_out.weight, lat, res=lat)
+                self._ln(lat, f, ff[0])
+                ops.gemm(f, ff[1].weight, hid, act="gelu_erf")
+                ops.gemm(hid, ff[3].weight, lat, res=lat)
+        face_all = E(G, nq, self.lfe_proj_t.shape[0])
+        ops.gemm(lat[:, :nq], self.lfe_proj_t, face_all)
+        face = face_all.view(n_id, B, nq, -1).transpose(0, 1).contiguous()                   # [B, n_id, 32, 2048]
+        self.last_face_emb = face
+
+        kvs, krs = [], []
+        face2d = face.view(B * n_id * nq, -1)
+        fn = E(*face2d.shape)
+        for l, pc in enumerate(m.perceiver_cross_attention):
+            self._ln(face2d, fn, pc.norm1)
+            kv_l = E(B * n_id * nq, pc.to_kv.weight.shape[0])
+            ops.gemm(fn, pc.to_kv.weight, kv_l)
+            inner_p = pc.to_q.weight.shape[0]
+            kn = E(B * n_id * nq, inner_p)
+            ops.layernorm(kv_l[:, :inner_p], kn, self.r_nk_w, self.r_nk_b, eps=m.router.norm_k.eps)
+            kr_l = E(B * n_id * nq, inner_p)
+            ops.gemm(kn, self.r_to_k[l], kr_l)
+            kvs.append(kv_l.view(B, n_id, nq, -1))
+            krs.append(kr_l.view(B, n_id, nq, -1))
+        return kvs, krs
+
+    def _audio_invariants(self, audio_embeds, T, B):
+        """sliding_windows + AudioProjModel (models/audio_model.py:188-193, 78-114) and the per-layer audio K/V
+        (diffusers Attention.to_k/to_v on the 32 context tokens of each latent frame)."""
+        am, n_id = self.m.audio_model, self.N_ID
+        ap = am.audio_proj_model
+        if audio_embeds.dim() != 5:
+            raise NotImplementedError(
+                "single-stream audio needs tests/input/ae_mute.pt, which the reference does not ship "
+                "(models/audio_model.py:203); pass [B, 2, F, 12, 768] with the silent stream zeroed")
+        a = self._bf(audio_embeds)
+        bs, ni, F, blk, ch = a.shape
+        assert bs == B and ni == n_id
+        assert 1 + (T - 1) * 4 + (am.window_size - am.window_stride) == F, \
+            f"hidden_states_num_frames: {T}, window_size: {am.window_size}, window_stride: {am.window_stride}, " \
+            f"audio_embeds.shape[1]: {F}"
+        G, per = B * n_id, blk * ch
+        nwin = F - am.window_size + 1
+        E = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=self.dev)
+        win = torch.as_strided(a, (G, nwin, am.window_size * per), (F * per, per, 1))      # overlapping windows, no copy
+        h1, h2 = E(G, nwin, ap.proj1.weight.shape[0]), E(G, nwin, ap.proj2.weight.shape[0])
+        ops.gemm(win, ap.proj1.weight, h1, bias=ap.proj1.bias, act="relu")
+        ops.gemm(h1, ap.proj2.weight, h2, bias=ap.proj2.bias, act="relu")
+        C = ap.proj3.weight.shape[0]
+        cur = E(G, nwin, C)
+        ops.gemm(h2, ap.proj3.weight, cur, bias=ap.proj3.bias)
+        for _ in range(2):                        # Conv1d(k=2, s=2) over frames == GEMM over [x[2j], x[2j+1]] rows
+            n = cur.shape[1]
+            keep = n % 2
+            n_out = (n - keep) // 2
+            nxt = E(G, keep + n_out, C)
+            if keep:
+                nxt[:, 0] = cur[:, 0]
+            if n_out > 0:
+                pairs = torch.as_strided(cur, (G, n_out, 2 * C), (n * C, 2 * C, 1), cur.storage_offset() + keep * C)
+                ops.gemm(pairs, self.conv_w, nxt[:, keep:], bias=ap.conv1.bias)
+            cur = nxt
+        assert cur.shape[1] == T
+        tok = ap.context_tokens
+        ctx = E(G * T * tok, ap.output_dim)
+        self._ln(cur.view(G * T * tok, ap.output_dim), ctx, ap.norm)
+        self.last_audio_ctx = ctx.view(B, n_id, T, tok, ap.output_dim)
+        ks, vs = [], []
+        for layer in am.layers:
+            at = layer["attn"]
+            k_l, v_l = E(G * T * tok, at.to_k.weight.shape[0]), E(G * T * tok, at.to_v.weight.shape[0])
+            ops.gemm(ctx, at.to_k.weight, k_l, bias=at.to_k.bias)
+            ops.gemm(ctx, at.to_v.weight, v_l, bias=at.to_v.bias)
+            ks.append(k_l.view(B, n_id, T, tok, -1))
+            vs.append(v_l.view(B, n_id, T, tok, -1))
+        return ks, vs
+
+    def _cached(self, name, tensors, fn):
+        if not self.cache_invariants:
+            return fn()
+        key = _key(tensors)
+        hit = self._inv_cache.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[2]
+        val = fn()
+        self._inv_cache[name] = (key, list(tensors), val)    # keep the inputs alive so pointers cannot be recycled
+        return val
+
+    # ------------------------------------------------------------------------------------------ the step
+    @torch.no_grad()
+    def step(self, hidden_states, encoder_hidden_states, timestep, image_rotary_emb, id_cond, id_vit_hidden,
+             audio_embeds, af_matrix, routing_logits_forcing, taps=None):
+        m, cfg, D, H, n_id = self.m, self.cfg, self.D, self.H, self.N_ID
+        B, T, C, Hh, Ww = hidden_states.shape
+        ht, wt = Hh // 2, Ww // 2
+        per_frame, N = ht * wt, T * ht * wt
+        Tt = encoder_hidden_states.shape[1]
+        S = Tt + N
+        key = (B, T, C, Hh, Ww, Tt)
+        if self._ws_key != key:
+            self._ws_key, self._ws = key, {}
+        buf = self._buf
+        hs = self._bf(hidden_states)
+        enc_in = self._bf(encoder_hidden_states)
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep] * B)
+        ts = timestep.to(device=self.dev, dtype=torch.int64).reshape(-1)
+        if ts.numel() == 1 and B > 1:
+            ts = ts.expand(B)
+        ts = ts.contiguous()
+        use_face = m.is_train_face
+        use_audio = m.is_train_audio and audio_embeds is not None
+        if use_face and m.router.frames * m.router.height * m.router.width != N:
+            raise ValueError(f"router positional table is {m.router.frames}x{m.router.height}x{m.router.width} "
+                             f"but the latents give {T}x{wt}x{ht} tokens")
+        cos = sin = None
+        if image_rotary_emb is not None:
+            cos = image_rotary_emb[0].to(device=self.dev, dtype=torch.float32).contiguous()
+            sin = image_rotary_emb[1].to(device=self.dev, dtype=torch.float32).contiguous()
+
+        # ---- step-invariant conditioning
+        if use_face:
+            flat_face = list(id_cond[:n_id]) + [t for i in range(n_id) for t in id_vit_hidden[i]]
+            face_kv, router_k = self._cached("face", flat_face, lambda: self._face_invariants(id_cond, id_vit_hidden, B))
+        if use_audio:
+            audio_k, audio_v = self._cached("audio", [audio_embeds], lambda: self._audio_invariants(audio_embeds, T, B))
+            af = self._bf(af_matrix)
+        forced = None
+        if routing_logits_forcing is not None and use_face:
+            f_in = self._bf(routing_logits_forcing).reshape(T, per_frame, n_id)
+            forced = ops.forcing_max_over_frames(f_in, buf("forced", 1, N, n_id).view(T, per_frame, n_id), T, per_frame,
+                                                 n_id).view(1, N, n_id)
+
+        # ---- D0: timestep embedding and every AdaLN modulation vector of the step
+        tfeat = ops.timestep_features(ts, buf("tfeat", B, D), cfg.flip_sin_to_cos, float(cfg.freq_shift))
+        te = m.time_embedding
+        e1 = ops.linear_small_m(tfeat, te.linear_1.weight, te.linear_1.bias, buf("e1", B, te.linear_1.weight.shape[0]),
+                                act_out="silu")
+        emb = ops.linear_small_m(e1, te.linear_2.weight, te.linear_2.bias, buf("emb", B, te.linear_2.weight.shape[0]))
+        mods = ops.linear_small_m(emb, self.mod_w, self.mod_b, buf("mods", B, self.mod_w.shape[0]), silu_in=True)
+        mbs = mods.stride(0)
+
+        # ---- D1: patch embed into the joint stream x = [text | video]
+        x = buf("x", B, S, D)
+        xv = x[:, Tt:]
+        pe = self.pos_embedding
+        if pe is not None and pe.shape[0] != S:
+            raise ValueError("learned positional embeddings need the configured sample height/width/frames")
+        tp = m.patch_embed.text_proj
+        ops.gemm(enc_in, tp.weight, x[:, :Tt], bias=tp.bias, res=None if pe is None else pe[:Tt])
+        cols = ops.patchify(hs, buf("cols", B, N, C * 4))
+        ops.gemm(cols, self.patch_w, xv, bias=m.patch_embed.proj.bias, res=None if pe is None else pe[Tt:])
+        if taps is not None:
+            taps["emb"], taps["embed"] = emb.clone(), x.clone()
+
+        xn = buf("xn", B, S, D)
+        q, k, v = buf("q", B, S, D), buf("k", B, S, D), buf("v", B, S, D)
+        ff = buf("ff", B, S, 4 * D)
+        r_logits = None
+        for i, blk in enumerate(m.transformer_blocks):
+            # ---- D2..D4: CogVideoXBlock (models/transformer.py:223-262)
+            for half, nz in enumerate((blk.norm1, blk.norm2)):
+                mo = mods[:, (2 * i + half) * 6 * D:]
+                # chunk order: shift, scale, gate, enc_shift, enc_scale, enc_gate
+                ops.layernorm(x, xn, nz.norm.weight, nz.norm.bias, eps=nz.norm.eps, shift0=mo[:, 3 * D:],
+                              scale0=mo[:, 4 * D:], shift1=mo, scale1=mo[:, D:], split=Tt, mod_batch_stride=mbs)
+                if half == 0:
+                    at = blk.attn1
+                    ops.gemm(xn, at.to_q.weight, q, bias=at.to_q.bias)
+                    ops.gemm(xn, at.to_k.weight, k, bias=at.to_k.bias)
+                    ops.gemm(xn, at.to_v.weight, v, bias=at.to_v.bias)
+                    ops.qknorm_rope(q, k, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
+                                    heads=H, text_rows=Tt if cos is not None else S, eps=at.norm_q.eps)
+                    ops.self_attention(q, k, v, xn, heads=H)
+                    ops.gemm(xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
+                             gate1=mo[:, 2 * D:], gate_split=Tt, gate_batch_stride=mbs)
+                else:
+                    ops.gemm(xn, blk.ff.net[0].proj.weight, ff, bias=blk.ff.net[0].proj.bias, act="gelu_tanh")
+                    ops.gemm(ff, blk.ff.net[2].weight, x, bias=blk.ff.net[2].bias, res=x, gate0=mo[:, 5 * D:],
+                             gate1=mo[:, 2 * D:], gate_split=Tt, gate_batch_stride=mbs)
+            if taps is not None:
+                taps[f"block{i}"] = x.clone()
+
+            # ---- P1 + R1..R4 + G1: face routing (models/transformer.py:737-833)
+            if use_face and i % m.cross_attn_interval == 0:
+                ca = i // m.cross_attn_interval
+                pc = m.perceiver_cross_attention[ca]
+                inner_p = pc.to_q.weight.shape[0]
+                hd_p = inner_p // 16
+                lat = buf("lat", B, N, D)
+                ops.layernorm(xv, lat, pc.norm2.weight, pc.norm2.bias, eps=pc.norm2.eps)
+                qp = ops.gemm(lat, pc.to_q.weight, buf("qp", B, N, inner_p))
+                kv_l = face_kv[ca]
+                ntok = kv_l.shape[2]
+                pout = buf("pout", B, n_id, N, inner_p)
+                ops.attention(qp, kv_l, kv_l[..., inner_p:], pout, head_dim=hd_p, heads=16, nb1=B, nb2=n_id, Sq=N,
+                              Skv=ntok, q_strides=(N * inner_p, 0, inner_p),
+                              k_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
+                              v_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
+                              o_strides=(n_id * N * inner_p, N * inner_p, inner_p), scale=hd_p ** -0.5)
+                feat = buf("feat", B, n_id, N, D)
+                ops.gemm(pout.view(B * n_id, N, inner_p), pc.to_out.weight, feat.view(B * n_id, N, D))
+                if forced is None:
+                    r_logits = self._router(qp, router_k[ca], ca, B, T, per_frame, taps)
+                else:
+                    r_logits = forced
+                if taps is not None:
+                    taps[f"id_feat{ca}"] = feat[0].clone()
+                ops.masked_combine(xv, feat, r_logits, None, "face", alpha=m.local_face_scale)
+                if taps is not None:
+                    taps[f"face{i}"] = xv.clone()
+
+            # ---- A1 + G2: audio injection (models/transformer.py:858-936)
+            if use_audio and i % m.audio_attn_interval == 0:
+                al = m.audio_model.layers[i // m.audio_attn_interval]
+                at = al["attn"]
+                an = buf("lat", B, N, D)
+                ops.layernorm(xv, an, al["norm_q"].weight, al["norm_q"].bias, eps=al["norm_q"].eps)
+                qa = ops.gemm(an, at.to_q.weight, buf("qa", B, N, D), bias=at.to_q.bias)
+                ka, va = audio_k[i // m.audio_attn_interval], audio_v[i // m.audio_attn_interval]
+                ntok = ka.shape[3]
+                ao = buf("ao", B, n_id, N, D)
+                for b in range(B):      # (id, frame) batch of one sample; q rows shared by both ids
+                    ops.attention(qa[b], ka[b], va[b], ao[b], head_dim=64, heads=H, nb1=n_id, nb2=T, Sq=per_frame,
+                                  Skv=ntok, q_strides=(0, per_frame * D, D), k_strides=(T * ntok * D, ntok * D, D),
+                                  v_strides=(T * ntok * D, ntok * D, D), o_strides=(N * D, per_frame * D, D),
+                                  scale=64 ** -0.5)
+                feat = buf("feat", B, n_id, N, D)
+                ops.gemm(ao.view(B * n_id, N, D), at.to_out[0].weight, feat.view(B * n_id, N, D), bias=at.to_out[0].bias)
+                ops.masked_combine(xv, feat, r_logits, af, "audio")
+                if taps is not None:
+                    taps[f"audio{i}"] = xv.clone()
+
+        # ---- F1: final norm, AdaLN head, projection, unpatchify (models/transformer.py:938-957)
+        xf = buf("lat", B, N, D)
+        ops.layernorm(xv, xf, m.norm_final.weight, m.norm_final.bias, eps=m.norm_final.eps)
+        mo = mods[:, 2 * self.L * 6 * D:]                      # AdaLayerNorm chunk_dim=1: (shift, scale)
+        xo = buf("qa", B, N, D)
+        ops.layernorm(xf, xo, m.norm_out.norm.weight, m.norm_out.norm.bias, eps=m.norm_out.norm.eps, shift0=mo,
+                      scale0=mo[:, D:], shift1=mo, scale1=mo[:, D:], split=0, mod_batch_stride=mbs)
+        co = m.proj_out.weight.shape[0]
+        y = ops.gemm(xo, m.proj_out.weight, buf("y", B, N, co), bias=m.proj_out.bias)
+        out = torch.empty(B, T, co // 4, Hh, Ww, dtype=torch.bfloat16, device=self.dev)
+        ops.unpatchify(y, out)
+        return out
+
+    def _router(self, qp, kr, ca, B, T, per_frame, taps):
+        """MultiIPRouter.forward (models/router.py:364-411) on the perceiver's q (shared by both ids) and the
+        pre-projected router keys.  Returns routing logits [B, N, n_id] (sigmoid)."""
+        m, n_id, buf = self.m, self.N_ID, self._buf
+        r = m.router
+        N = T * per_frame
+        F = r.feat_dim
+        qk = qp.shape[-1]
+        qn = buf("r_qn", B, N, qk)
+        ops.layernorm(qp, qn, self.r_nq_w, self.r_nq_b, eps=r.norm_q.eps)
+        qr = ops.gemm(qn, self.r_to_q[ca], buf("r_qr", B, N, qk))
+        rs = buf("r_s", B, n_id, N, F)
+        for b in range(B):
+            ops.router_scores(qr[b], kr[b].contiguous(), r.norm.weight, r.norm.bias, self.r_pos, rs[b], n_id, N,
+                              eps=r.norm.eps)
+        R = B * n_id * N
+        rs2, rn = rs.view(R, F), buf("r_n", R, F)
+        qkv, ra, rh = buf("r_qkv", R, 3 * F), buf("r_a", R, F), buf("r_h", R, F)
+        hd = 64
+        heads = F // hd
+        for st, pk in zip(r.spatial_temporal_layers, self.r_qkv):
+            # 1. spatial: every (sample, id, frame) attends over its per_frame tokens
+            self._ln(rs2, rn, st.norm1)
+            ops.gemm(rn, pk["spatial_attn"][0], qkv, bias=pk["spatial_attn"][1])
+            ops.attention(qkv, qkv[:, F:], qkv[:, 2 * F:], ra, head_dim=hd, heads=heads, nb1=B * n_id * T, nb2=1,
+                          Sq=per_frame, Skv=per_frame, q_strides=(per_frame * 3 * F, 0, 3 * F),
+                          k_strides=(per_frame * 3 * F, 0, 3 * F), v_strides=(per_frame * 3 * F, 0, 3 * F),
+                          o_strides=(per_frame * F, 0, F), scale=hd ** -0.5)
+            o = st.spatial_attn.to_out[0]
+            ops.gemm(ra, o.weight, rs2, bias=o.bias, res=rs2)
+            # 2. temporal: every (sample, id, location) attends over its T frames
+            self._ln(rs2, rn, st.norm2)
+            ops.gemm(rn, pk["temporal_attn"][0], qkv, bias=pk["temporal_attn"][1])
+            ops.attn_tiny(qkv, qkv[:, F:], qkv[:, 2 * F:], ra, T, heads, B * n_id, per_frame, N, per_frame, 3 * F, F,
+                          hd ** -0.5)
+            o = st.temporal_attn.to_out[0]
+            ops.gemm(ra, o.weight, rs2, bias=o.bias, res=rs2)
+            # 3. multi-ID: every (sample, token) attends over the ids
+            self._ln(rs2, rn, st.norm3)
+            ops.gemm(rn, pk["multi_id_attn"][0], qkv, bias=pk["multi_id_attn"][1])
+            ops.attn_tiny(qkv, qkv[:, F:], qkv[:, 2 * F:], ra, n_id, heads, B, N, n_id * N, N, 3 * F, F, hd ** -0.5)
+            o = st.multi_id_attn.to_out[0]
+            ops.gemm(ra, o.weight, rs2, bias=o.bias, res=rs2)
+            # 4. MLP (GELU erf)
+            self._ln(rs2, rn, st.norm4)
+            ops.gemm(rn, st.mlp[0].weight, rh, bias=st.mlp[0].bias, act="gelu_erf")
+            ops.gemm(rh, st.mlp[2].weight, rs2, bias=st.mlp[2].bias, res=rs2)
+        logits = buf(f"r_logits", B, N, n_id)
+        fp = r.final_proj[0]
+        for b in range(B):
+            ops.router_head(rs[b], fp.weight, fp.bias, logits[b], n_id, N)
+        if taps is not None:
+            for b in range(B):
+                taps[f"router{ca}_b{b}"] = logits[b:b + 1].clone()
+        return logits

@@ -1,0 +1,404 @@
+"""Drop-in replacement for the reference denoiser ``BindyouravatarTransformer3DModel``.
+
+Same constructor keywords (reference models/transformer.py:322-366), same state-dict key names and
+shapes (checked against ``tests/golden/ref_state_dict_keys.json``, dumped from the reference class), same
+``forward`` signature and 5-tuple return (models/transformer.py:615-633, 963-964).  The modules below are
+parameter CONTAINERS only: nothing here computes with torch ops -- ``forward`` hands the tensors to
+``engine.DenoiseEngine`` which runs the step on the hand-written HIP kernels of ``libbya_hip.so``.
+There is no CPU / eager fallback: calling ``forward`` without a GPU or without the built library raises.
+"""
+from types import SimpleNamespace
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+
+# ------------------------------------------------------------------------------------------ containers
+class _Lin(nn.Module):
+    def __init__(self, i, o, bias=True, **fk):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(o, i, **fk), requires_grad=False)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(o, **fk), requires_grad=False)
+        else:
+            self.register_parameter("bias", None)
+
+
+class _LN(nn.Module):
+    def __init__(self, d, eps=1e-5, affine=True, **fk):
+        super().__init__()
+        self.eps = eps
+        if affine:
+            self.weight = nn.Parameter(torch.empty(d, **fk), requires_grad=False)
+            self.bias = nn.Parameter(torch.empty(d, **fk), requires_grad=False)
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+
+
+class _Conv(nn.Module):
+    def __init__(self, shape, **fk):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*shape, **fk), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(shape[0], **fk), requires_grad=False)
+
+
+def _seq(*mods):
+    """nn.Sequential-style numbering ('0', '1', ...) with None -> parameter-free placeholder."""
+    return nn.ModuleList([m if m is not None else nn.Identity() for m in mods])
+
+
+class _Attn(nn.Module):
+    """Key layout of diffusers ``Attention`` (to_q/to_k/to_v/to_out.0[/norm_q/norm_k])."""
+
+    def __init__(self, q_dim, inner, kv_dim=None, bias=True, qk_norm_dim=None, qk_eps=1e-6, **fk):
+        super().__init__()
+        kv_dim = q_dim if kv_dim is None else kv_dim
+        self.to_q = _Lin(q_dim, inner, bias, **fk)
+        self.to_k = _Lin(kv_dim, inner, bias, **fk)
+        self.to_v = _Lin(kv_dim, inner, bias, **fk)
+        if qk_norm_dim:
+            self.norm_q = _LN(qk_norm_dim, qk_eps, **fk)
+            self.norm_k = _LN(qk_norm_dim, qk_eps, **fk)
+        self.to_out = _seq(_Lin(inner, q_dim, True, **fk), None)
+
+
+class _NormZero(nn.Module):
+    def __init__(self, cond, dim, eps, affine, chunks, **fk):
+        super().__init__()
+        self.linear = _Lin(cond, chunks * dim, True, **fk)
+        self.norm = _LN(dim, eps, affine, **fk)
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, heads, head_dim, temb, eps, affine, attn_bias, **fk):
+        super().__init__()
+        self.norm1 = _NormZero(temb, dim, eps, affine, 6, **fk)
+        self.attn1 = _Attn(dim, heads * head_dim, bias=attn_bias, qk_norm_dim=head_dim, **fk)
+        self.norm2 = _NormZero(temb, dim, eps, affine, 6, **fk)
+        self.ff = nn.Module()
+        gelu = nn.Module()
+        gelu.proj = _Lin(dim, 4 * dim, True, **fk)
+        self.ff.net = _seq(gelu, None, _Lin(4 * dim, dim, True, **fk), None)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, in_ch, dim, text_dim, patch, n_rows, learned, **fk):
+        super().__init__()
+        self.proj = _Conv((dim, in_ch, patch, patch), **fk)
+        self.text_proj = _Lin(text_dim, dim, True, **fk)
+        self.register_buffer("pos_embedding", torch.zeros(1, n_rows, dim, **fk), persistent=learned)
+
+
+class _Perceiver(nn.Module):
+    def __init__(self, dim, inner, kv_dim=None, **fk):
+        super().__init__()
+        self.norm1 = _LN(dim if kv_dim is None else kv_dim, **fk)
+        self.norm2 = _LN(dim, **fk)
+        self.to_q = _Lin(dim, inner, False, **fk)
+        self.to_kv = _Lin(dim if kv_dim is None else kv_dim, 2 * inner, False, **fk)
+        self.to_out = _Lin(inner, dim, False, **fk)
+
+
+def _mapper(d_in, d_out, **fk):
+    return _seq(_Lin(d_in, 1024, **fk), _LN(1024, **fk), None, _Lin(1024, 1024, **fk), _LN(1024, **fk), None,
+                _Lin(1024, d_out, **fk))
+
+
+class _LFE(nn.Module):
+    """LocalFacialExtractor parameters (reference models/router.py:78-155)."""
+
+    def __init__(self, dim=1024, depth=10, dim_head=64, heads=16, num_id_token=5, num_queries=32, output_dim=2048,
+                 ff_mult=4, **fk):
+        super().__init__()
+        self.dim, self.depth, self.heads, self.dim_head = dim, depth // 5, heads, dim_head
+        self.num_id_token, self.num_queries = num_id_token, num_queries
+        self.latents = nn.Parameter(torch.empty(1, num_queries, dim, **fk), requires_grad=False)
+        self.proj_out = nn.Parameter(torch.empty(dim, output_dim, **fk), requires_grad=False)
+        self.layers = nn.ModuleList([
+            _seq(_Perceiver(dim, dim_head * heads, **fk),
+                 _seq(_LN(dim, **fk), _Lin(dim, dim * ff_mult, False, **fk), None, _Lin(dim * ff_mult, dim, False, **fk)))
+            for _ in range(depth)])
+        for i in range(5):
+            setattr(self, f"mapping_{i}", _mapper(1024, dim, **fk))
+        self.id_embedding_mapping = _mapper(1280, dim * num_id_token, **fk)
+
+
+class _STBlock(nn.Module):
+    def __init__(self, dim, **fk):
+        super().__init__()
+        self.spatial_attn = _Attn(dim, dim, **fk)
+        self.temporal_attn = _Attn(dim, dim, **fk)
+        self.multi_id_attn = _Attn(dim, dim, **fk)
+        self.norm1, self.norm2, self.norm3, self.norm4 = (_LN(dim, **fk) for _ in range(4))
+        self.mlp = _seq(_Lin(dim, dim, **fk), None, _Lin(dim, dim, **fk))
+
+
+class _Router(nn.Module):
+    """MultiIPRouter parameters (reference models/router.py:280-332); ``layer_merge`` is dead but loadable."""
+
+    def __init__(self, num_layers, frames, height, width, q_k_dim=2048, num_id_token=32, num_heads=16, **fk):
+        super().__init__()
+        wdim = num_id_token * num_heads
+        self.heads, self.feat_dim = num_heads, wdim
+        self.frames, self.height, self.width = frames, height, width
+        self.norm = _LN(wdim, **fk)
+        self.norm_q, self.norm_k = _LN(q_k_dim, **fk), _LN(q_k_dim, **fk)
+        self.to_q = nn.ModuleList([_Lin(q_k_dim, q_k_dim, False, **fk) for _ in range(num_layers)])
+        self.to_k = nn.ModuleList([_Lin(q_k_dim, q_k_dim, False, **fk) for _ in range(num_layers)])
+        self.layer_merge = nn.ModuleList([_seq(_Lin(wdim + 3, 256, True, **fk), None, _Lin(256, 128, False, **fk), None)
+                                          for _ in range(num_layers)])
+        self.register_buffer("pos_emb", router_pos_emb(frames, height, width, wdim).to(**fk))
+        self.spatial_temporal_layers = nn.ModuleList([_STBlock(wdim, **fk) for _ in range(4)])
+        self.final_proj = _seq(_Lin(wdim, 1, **fk), None)
+
+
+def router_pos_emb(frames, height, width, feat_dim):
+    """3-D sin/cos table of the router (reference models/router.py:334-362), index [t, a, b, :]."""
+    third = feat_dim // 3
+    div = torch.pow(10000, torch.arange(0, third, 2).float() / third)
+
+    def axis(n):
+        e = torch.arange(n).float().unsqueeze(-1) / div
+        return torch.stack([torch.sin(e), torch.cos(e)], dim=-1).flatten(-2)
+
+    t = axis(frames)[:, None, None, :].expand(-1, height, width, -1)
+    h = axis(height)[None, :, None, :].expand(frames, -1, width, -1)
+    w = axis(width)[None, None, :, :].expand(frames, height, -1, -1)
+    pe = torch.cat([t, h, w], dim=-1)
+    if pe.size(-1) < feat_dim:
+        pe = torch.cat([pe, torch.zeros(frames, height, width, feat_dim - pe.size(-1))], dim=-1)
+    return pe.contiguous()
+
+
+class _AudioProj(nn.Module):
+    def __init__(self, seq_len=5, blocks=12, channels=768, intermediate_dim=512, output_dim=768, context_tokens=32, **fk):
+        super().__init__()
+        self.seq_len, self.blocks, self.channels = seq_len, blocks, channels
+        self.context_tokens, self.output_dim = context_tokens, output_dim
+        self.proj1 = _Lin(seq_len * blocks * channels, intermediate_dim, **fk)
+        self.proj2 = _Lin(intermediate_dim, intermediate_dim, **fk)
+        self.proj3 = _Lin(intermediate_dim, context_tokens * output_dim, **fk)
+        self.norm = _LN(output_dim, **fk)
+        self.conv1 = _Conv((context_tokens * output_dim, context_tokens * output_dim, 2), **fk)
+
+
+class _AudioLayer(nn.ModuleDict):
+    pass
+
+
+class _AudioModel(nn.Module):
+    def __init__(self, dim, heads, head_dim, eps, affine, num_layers, audio_dim=768, **fk):
+        super().__init__()
+        self.window_size, self.window_stride = 5, 1
+        self.learnable_scale = nn.Parameter(torch.empty(1, **fk), requires_grad=False)
+        self.audio_proj_model = _AudioProj(**fk)
+        self.layers = nn.ModuleList([
+            nn.ModuleDict({"norm_q": _LN(dim, eps, affine, **fk),
+                           "attn": _Attn(dim, heads * head_dim, kv_dim=audio_dim, bias=True, **fk)})
+            for _ in range(num_layers)])
+        self.mute_learnable_tokens = nn.Parameter(torch.empty(1, 32, 768, **fk), requires_grad=False)
+
+
+# ------------------------------------------------------------------------------------------ the model
+class BindyouravatarTransformer3DModel(nn.Module):
+    """See module docstring.  Extra keyword-only arguments ``device`` / ``dtype`` place the parameters."""
+
+    def __init__(
+        self,
+        num_attention_heads: int = 48,
+        attention_head_dim: int = 64,
+        in_channels: int = 16,
+        out_channels: Optional[int] = 16,
+        flip_sin_to_cos: bool = True,
+        freq_shift: int = 0,
+        time_embed_dim: int = 512,
+        text_embed_dim: int = 4096,
+        num_layers: int = 30,
+        dropout: float = 0.0,
+        attention_bias: bool = True,
+        sample_width: int = 90,
+        sample_height: int = 60,
+        sample_frames: int = 49,
+        patch_size: int = 2,
+        temporal_compression_ratio: int = 4,
+        max_text_seq_length: int = 226,
+        activation_fn: str = "gelu-approximate",
+        timestep_activation_fn: str = "silu",
+        norm_elementwise_affine: bool = True,
+        norm_eps: float = 1e-5,
+        spatial_interpolation_scale: float = 1.875,
+        temporal_interpolation_scale: float = 1.0,
+        use_rotary_positional_embeddings: bool = False,
+        use_learned_positional_embeddings: bool = False,
+        is_train_face: bool = True,
+        is_kps: bool = False,
+        cross_attn_interval: int = 1,
+        LFE_num_tokens: int = 32,
+        LFE_output_dim: int = 768,
+        LFE_heads: int = 12,
+        local_face_scale: float = 1.0,
+        is_train_audio: bool = False,
+        audio_attn_interval: int = 1,
+        draw_routing_logits: bool = False,
+        draw_routing_logits_suffix: str = "default",
+        draw_routing_logits_video_save_dir: str = None,
+        draw_routing_logits_use_softmax: bool = True,
+        debug_routing_logits: bool = False,
+        debug_routing_logits_zeros: bool = False,
+        debug_routing_logits_ones: bool = False,
+        is_teacher_forcing: bool = False,
+        *,
+        device=None,
+        dtype=torch.bfloat16,
+    ):
+        super().__init__()
+        cfg = {k: v for k, v in locals().items() if k not in ("self", "__class__", "device", "dtype")}
+        self.config = SimpleNamespace(**cfg)
+        if not use_rotary_positional_embeddings and use_learned_positional_embeddings:
+            raise ValueError(
+                "There are no CogVideoX checkpoints available with disable rotary embeddings and learned positional "
+                "embeddings. If you're using a custom model and/or believe this should be supported, please open an "
+                "issue at https://github.com/huggingface/diffusers/issues.")
+        if patch_size != 2 or attention_head_dim != 64 or activation_fn != "gelu-approximate" or not attention_bias:
+            raise ValueError("the MI355X engine covers the CogVideoX-5B-I2V lineage only "
+                             "(patch 2, head_dim 64, gelu-approximate, attention bias)")
+        if debug_routing_logits or debug_routing_logits_zeros or debug_routing_logits_ones or is_teacher_forcing:
+            raise ValueError("training / debug routing branches are outside the inference hot path")
+        fk = dict(device=device, dtype=dtype)
+        inner = num_attention_heads * attention_head_dim
+        self.inner_dim = inner
+        frames = (sample_frames - 1) // temporal_compression_ratio + 1
+        ht, wt = sample_height // patch_size, sample_width // patch_size
+        self.token_grid = (frames, ht, wt)
+
+        self.patch_embed = _PatchEmbed(in_channels, inner, text_embed_dim, patch_size,
+                                       max_text_seq_length + frames * ht * wt,
+                                       use_learned_positional_embeddings, **fk)
+        self.time_embedding = nn.Module()
+        self.time_embedding.linear_1 = _Lin(inner, time_embed_dim, **fk)
+        self.time_embedding.linear_2 = _Lin(time_embed_dim, time_embed_dim, **fk)
+        self.transformer_blocks = nn.ModuleList([
+            _Block(inner, num_attention_heads, attention_head_dim, time_embed_dim, norm_eps, norm_elementwise_affine,
+                   attention_bias, **fk) for _ in range(num_layers)])
+        self.norm_final = _LN(inner, norm_eps, norm_elementwise_affine, **fk)
+        self.norm_out = _NormZero(time_embed_dim, inner, norm_eps, norm_elementwise_affine, 2, **fk)
+        self.proj_out = _Lin(inner, patch_size * patch_size * out_channels, **fk)
+
+        self.is_train_face, self.is_kps = is_train_face, is_kps
+        self.is_train_audio = is_train_audio
+        if is_train_face:
+            self.cross_attn_interval = cross_attn_interval
+            self.num_ca = num_layers // cross_attn_interval
+            self.LFE_final_output_dim = int(inner / 3 * 2)
+            self.local_face_scale = local_face_scale
+            self.local_facial_extractor = _LFE(**fk)
+            self.perceiver_cross_attention = nn.ModuleList([
+                _Perceiver(inner, 128 * 16, kv_dim=self.LFE_final_output_dim, **fk) for _ in range(self.num_ca)])
+            # the reference hard-codes (13, 45, 30); generalised as (frames, Wt, Ht) -- see DESIGN.md "geometry"
+            self.router = _Router(self.num_ca, frames, wt, ht, **fk)
+        if is_train_audio:
+            self.audio_attn_interval = audio_attn_interval
+            self.audio_model = _AudioModel(inner, num_attention_heads, attention_head_dim, norm_eps,
+                                           norm_elementwise_affine, num_layers // audio_attn_interval, **fk)
+        self._engine = None
+
+    # ---- API the reference pipeline touches -------------------------------------------------------
+    @property
+    def device(self):
+        return self.proj_out.weight.device
+
+    @property
+    def dtype(self):
+        return self.proj_out.weight.dtype
+
+    def fuse_qkv_projections(self):
+        """Reference models/transformer.py:576-599.  The engine already reads q/k/v as one pass; no-op."""
+        return None
+
+    def unfuse_qkv_projections(self):
+        return None
+
+    def load_face_modules(self, path: str, strict: bool = True):
+        """Reference models/transformer.py:493-501 (dict with LFE state + list of perceiver states)."""
+        ckpt = torch.load(path, map_location=self.device)
+        self.local_facial_extractor.load_state_dict(ckpt["local_facial_extractor"], strict=strict)
+        for ca, sd in zip(self.perceiver_cross_attention, ckpt["perceiver_cross_attention"]):
+            ca.load_state_dict(sd, strict=strict)
+        self.invalidate_engine()
+
+    def load_audio_modules(self, path: str, strict: bool = True):
+        """Reference models/transformer.py:464-472."""
+        self.audio_model.load_state_dict(torch.load(path, map_location=self.device), strict=strict)
+        self.invalidate_engine()
+
+    def load_router_modules(self, path: str, strict: bool = True):
+        """Reference models/transformer.py:509-513 -> models/router.py:417-423."""
+        self.router.load_state_dict(torch.load(path, map_location=self.device), strict=strict)
+        self.invalidate_engine()
+
+    def invalidate_engine(self):
+        """Drop packed weights / workspaces (call after changing parameters in place)."""
+        self._engine = None
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        self.invalidate_engine()
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        self._engine = None
+        return super()._apply(fn, *a, **kw)
+
+    def init_synthetic(self, seed: int = 0, fast: bool = False):
+        """Fill parameters with the deterministic name-keyed synthetic weights (no checkpoints offline).
+
+        ``fast``: draw on the parameter's device (bench-size models); otherwise use the CPU generator so the
+        values are identical in every process (golden-fixture tests)."""
+        from .synth import synth_tensor
+        with torch.no_grad():
+            for name, t in self.state_dict().items():
+                if name == "router.pos_emb":
+                    continue
+                dev = t.device if (fast and t.is_cuda) else "cpu"
+                v = synth_tensor(name, t.shape, seed, device=dev)
+                if name.endswith("pos_embedding"):
+                    v[:, :self.config.max_text_seq_length] = 0
+                t.copy_(v.to(t.dtype))
+        self.invalidate_engine()
+        return self
+
+    # ---- the hot path -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(
+        self,
+        hidden_states: torch.Tensor,
+        encoder_hidden_states: torch.Tensor,
+        timestep: Union[int, float, torch.LongTensor],
+        timestep_cond: Optional[torch.Tensor] = None,
+        image_rotary_emb: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+        attention_kwargs: Optional[Dict[str, Any]] = None,
+        id_cond: Optional[torch.Tensor] = None,
+        id_vit_hidden: Optional[torch.Tensor] = None,
+        index_mask: Optional[torch.Tensor] = None,
+        return_dict: bool = True,
+        audio_embeds: Optional[torch.Tensor] = None,
+        af_matrix: Optional[torch.Tensor] = None,
+        denoise_step: Optional[int] = None,
+        index_mask_drop_prob: Optional[float] = 0.0,
+        routing_logits_zeros_flag: Optional[bool] = False,
+        routing_logits_forcing: Optional[torch.Tensor] = None,
+    ):
+        if self.is_train_face:
+            assert id_cond is not None and id_vit_hidden is not None      # reference :636
+        if index_mask is not None:
+            raise NotImplementedError("index_mask (teacher forcing / routing losses) is a training-only branch")
+        if timestep_cond is not None:
+            raise NotImplementedError("timestep_cond is never passed by the reference pipeline")
+        if self._engine is None:
+            from .engine import DenoiseEngine
+            self._engine = DenoiseEngine(self)
+        out = self._engine.step(hidden_states, encoder_hidden_states, timestep, image_rotary_emb, id_cond,
+                                id_vit_hidden, audio_embeds, af_matrix, routing_logits_forcing)
+        return (out, None, None, None, None)
