@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoise-steps/sec of the Bind-Your-Avatar hot path on MI355X.
+
+A "step" = one ``BindyouravatarTransformer3DModel.forward`` (reference models/transformer.py:615-964) on
+synthetic inputs of BASELINE.json configs[1]: 49 frames x 480 x 720 (13 x 30 x 45 latent tokens + 226 text
+tokens), 2 talking characters (2 ID embeddings + 2 audio streams), bf16, batch 1, all 42 DiT layers, 21 face
+routing layers, 42 audio layers, random-init weights of the real architecture (8.6 B parameters).
+Inputs are resident in HBM when the timed region starts; step-invariant conditioning (face extractor, audio
+projector) is RECOMPUTED every step exactly like the reference does (no cached outputs).
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched through torch.distributed.run)
+
+N > 1 shards the token axis of the same step across ranks (sequence parallel, K/V all-gather over RCCL):
+total work is fixed => "scaling": "strong".
+
+Prints ONE JSON line (rank 0).  Extra objects: ``roofline`` for the dominant kernel (measured live with HIP
+events on the launch stream) and ``cpu_baseline`` (the CPU oracle timed on this box's host cores, rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODEL_KW = dict(num_attention_heads=48, attention_head_dim=64, in_channels=48, out_channels=16, num_layers=42,
+                use_rotary_positional_embeddings=True, use_learned_positional_embeddings=True,
+                is_train_face=True, cross_attn_interval=2, local_face_scale=1.0, is_train_audio=True,
+                audio_attn_interval=1)
+TFLOP_PER_STEP = 443.9          # algorithmic, BASELINE.md section 2 (B = 1)
+ATTN_TFLOP_PER_LAUNCH = 4 * 17776 ** 2 * 3072 / 1e12     # joint self-attention, one layer, B = 1
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def cpu_baseline(threads):
+    """Bounded CPU sample: ONE CogVideoXBlock (the oracle's restatement, bf16, 17776 tokens) = 7.9 of the
+    443.9 TFLOP of a step, extrapolated linearly by FLOPs.  Baseline only -- never the thing measured."""
+    from oracle.model import CogVideoXBlock
+    from oracle.layers import get_3d_rotary_pos_embed
+    torch.set_num_threads(threads)
+    with torch.no_grad():
+        blk = CogVideoXBlock(dim=3072, num_attention_heads=48, attention_head_dim=64, time_embed_dim=512,
+                             attention_bias=True).to(torch.bfloat16).eval()
+        hid = torch.randn(1, 17550, 3072).to(torch.bfloat16)
+        enc = torch.randn(1, 226, 3072).to(torch.bfloat16)
+        temb = torch.randn(1, 512).to(torch.bfloat16)
+        rope = get_3d_rotary_pos_embed(64, ((0, 0), (30, 45)), (30, 45), 13)
+        t0 = time.time()
+        blk(hid, enc, temb, rope)
+        dt = time.time() - t0
+    block_tflop = 7.9
+    steps_per_s = 1.0 / (dt * TFLOP_PER_STEP / block_tflop)
+    return {"value": steps_per_s, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"1 CogVideoXBlock forward (7.9 of 443.9 TFLOP/step) at 17776 tokens, bf16, torch CPU, "
+                      f"{dt:.1f} s; extrapolated linearly by FLOPs to a full step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=42, help="debug only: anything but 42 is not the headline config")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel, ops
+    from bind_your_avatar_implementation_amd.synth import synth_inputs
+
+    kw = dict(MODEL_KW, num_layers=args.layers)
+    model = BindyouravatarTransformer3DModel(**kw, device=dev).init_synthetic(seed=0, fast=True)
+    if world > 1:
+        from bind_your_avatar_implementation_amd.parallel import shard_sequence
+        shard_sequence(model, dist.group.WORLD)
+    inp = synth_inputs(batch=1, seed=0, device="cpu")
+    inp = {k: (v.to(dev, torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else
+               (v.to(dev) if torch.is_tensor(v) else v)) for k, v in inp.items()}
+    inp["image_rotary_emb"] = tuple(t.to(dev, torch.float32) for t in inp["image_rotary_emb"])
+    inp["id_cond"] = [t.to(dev, torch.bfloat16) for t in inp["id_cond"]]
+    inp["id_vit_hidden"] = [[t.to(dev, torch.bfloat16) for t in l] for l in inp["id_vit_hidden"]]
+
+    def step():
+        return model(return_dict=False, denoise_step=0, **inp)[0]
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all(), "non-finite output"
+
+    timers = None if args.no_kernel_timers else ops.enable_kernel_timers()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ktimes = ops.collect_kernel_timers() if timers is not None else {}
+
+    if rank == 0:
+        sec_per_step = dt / args.steps
+        value = 1.0 / sec_per_step
+        res = {
+            "metric": "denoise-steps/sec", "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "latent_frames_per_sec": 13 * value,
+            "mfma_roofline_frac_whole_step": TFLOP_PER_STEP * (args.layers / 42) * value / (world * PEAK_BF16_TFLOPS),
+            "config": {"workload": "BASELINE.json configs[1]: full transformer.forward, 49x480x720 (13x30x45 latent "
+                                   "tokens + 226 text), 2 characters (2 ID + 2 audio), batch 1, random-init 8.6B-param "
+                                   "architecture", "layers": args.layers, "tokens": 17776,
+                       "parallelism": "single GPU" if world == 1 else f"sequence-parallel x{world} (K/V all-gather)"},
+        }
+        if ktimes:
+            tot = {k: sum(v) for k, v in ktimes.items()}
+            per_step = {k: tot[k] / args.steps for k in tot}
+            res["kernel_ms_per_step"] = {k: round(v * 1e3, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
+            attn = [t for t in ktimes.get("bya_attn_fwd:joint", [])]
+            if attn:
+                avg = sum(attn) / len(attn)
+                ach = ATTN_TFLOP_PER_LAUNCH / world / avg
+                res["roofline"] = {"kernel": "attn_fwd_kernel<64> (joint 17776-token self-attention)",
+                                   "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                                   "avg_launch_ms": avg * 1e3, "launches": len(attn)}
+            gemm = ktimes.get("bya_gemm_bf16", [])
+            if gemm:
+                gflop = ops.kernel_timer_flops().get("bya_gemm_bf16", 0.0)
+                res["gemm_roofline"] = {"kernel": "gemm_bf16_kernel<128,128>", "bound": "mfma",
+                                        "achieved": gflop / 1e12 / sum(gemm), "peak": PEAK_BF16_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": gflop / 1e12 / sum(gemm) / PEAK_BF16_TFLOPS,
+                                        "launches": len(gemm)}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -221,7 +221,7 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
     const int groups = (nbh + 7) / 8;
     dim3 grid(groups * 8 * a.nqt);
     const size_t lds = 4 * KV_TILE * D * 2;
-    hipLaunchKernelGGL((attn_fwd_kernel<D>), grid, dim3(256), lds, s, a);
+    BYA_LAUNCH((attn_fwd_kernel<D>), grid, dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 

@@ -20,6 +20,10 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #define BYA_ERR_LAUNCH (-3)
 #define BYA_ERR_UNSUPPORTED (-4)
 
+// hipGetLastError() is sticky across unrelated runtime calls of the host process (torch's own event queries
+// etc.); clear it before the launch so the status we return describes THIS launch only.
+#define BYA_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 

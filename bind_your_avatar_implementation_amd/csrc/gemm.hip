@@ -172,7 +172,7 @@ int launch(const GemmArgs& a, int batch, hipStream_t s) {
             return BYA_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN>), grid, dim3(256), lds, s, a);
+    BYA_LAUNCH((gemm_bf16_kernel<BM, BN>), grid, dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 

@@ -210,10 +210,10 @@ extern "C" int bya_linear_small_m(const void* x, const void* W, const void* bias
     if (act_out != BYA_ACT_NONE && act_out != BYA_ACT_SILU) return BYA_ERR_UNSUPPORTED;
     dim3 grid((unsigned)((N + 3) / 4));
     if (M <= 2)
-        hipLaunchKernelGGL((linear_small_m_kernel<2>), grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W,
+        BYA_LAUNCH((linear_small_m_kernel<2>), grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W,
                            (const bf16_t*)bias, (bf16_t*)out, M, N, K, silu_in, act_out);
     else
-        hipLaunchKernelGGL((linear_small_m_kernel<8>), grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W,
+        BYA_LAUNCH((linear_small_m_kernel<8>), grid, dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)W,
                            (const bf16_t*)bias, (bf16_t*)out, M, N, K, silu_in, act_out);
     return ok();
 }
@@ -222,7 +222,7 @@ extern "C" int bya_timestep_features(const int64_t* timesteps, void* out, int32_
                                      int32_t flip_sin_to_cos, float freq_shift, hipStream_t stream) {
     if (!timesteps || !out || batch <= 0 || dim <= 0 || dim % 2) return BYA_ERR_SHAPE;
     const int total = batch * (dim / 2);
-    hipLaunchKernelGGL(timestep_features_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, timesteps,
+    BYA_LAUNCH(timestep_features_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, timesteps,
                        (bf16_t*)out, batch, dim, flip_sin_to_cos, freq_shift);
     return ok();
 }
@@ -240,7 +240,7 @@ extern "C" int bya_masked_combine(void* x, const void* feat, const void* r, cons
     a.mode = mode; a.batch = batch; a.n_id = n_id; a.D = D; a.N = N; a.x_row = x_row; a.x_bs = x_batch_stride;
     a.r_bs = r_batch_stride; a.alpha = alpha;
     const long long total = (long long)batch * N * (D / 8);
-    hipLaunchKernelGGL(masked_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    BYA_LAUNCH(masked_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
     return ok();
 }
 
@@ -248,7 +248,7 @@ extern "C" int bya_forcing_max_over_frames(const void* forcing, void* out, int32
                                            int32_t n_id, hipStream_t stream) {
     if (!forcing || !out || frames <= 0 || per_frame <= 0 || n_id <= 0) return BYA_ERR_SHAPE;
     const long long inner = per_frame * n_id;
-    hipLaunchKernelGGL(forcing_max_kernel, dim3((unsigned)((inner + 255) / 256)), dim3(256), 0, stream,
+    BYA_LAUNCH(forcing_max_kernel, dim3((unsigned)((inner + 255) / 256)), dim3(256), 0, stream,
                        (const bf16_t*)forcing, (bf16_t*)out, frames, (long long)per_frame, n_id);
     return ok();
 }
@@ -259,7 +259,7 @@ extern "C" int bya_patchify(const void* x, void* cols, int32_t batch, int32_t fr
     if (H % 2 || W % 2) return BYA_ERR_SHAPE;
     if (((uintptr_t)x & 3) || ((uintptr_t)cols & 7)) return BYA_ERR_ALIGN;
     const long long total = (long long)batch * frames * channels * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
+    BYA_LAUNCH(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
                        (bf16_t*)cols, batch, frames, channels, H, W);
     return ok();
 }
@@ -270,7 +270,7 @@ extern "C" int bya_unpatchify(const void* y, void* out, int32_t batch, int32_t f
     if (H % 2 || W % 2) return BYA_ERR_SHAPE;
     if (((uintptr_t)out & 3) || ((uintptr_t)y & 7)) return BYA_ERR_ALIGN;
     const long long total = (long long)batch * frames * channels * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+    BYA_LAUNCH(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                        (const bf16_t*)y, (bf16_t*)out, batch, frames, channels, H, W);
     return ok();
 }
@@ -282,7 +282,7 @@ extern "C" int bya_act_add(const void* x, const void* r, void* y, int64_t n, int
     const long long nvec = n / 8;
     long long blocks = (nvec + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(act_add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x,
+    BYA_LAUNCH(act_add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x,
                        (const bf16_t*)r, (bf16_t*)y, nvec, act);
     return ok();
 }

@@ -98,7 +98,7 @@ template <int VEC, int NV>
 int launch_ln(const LnArgs& a, hipStream_t s) {
     const long long total = a.rows_per_batch * a.batch;
     dim3 grid((unsigned)((total + 3) / 4));
-    hipLaunchKernelGGL((layernorm_kernel<VEC, NV>), grid, dim3(256), 0, s, a);
+    BYA_LAUNCH((layernorm_kernel<VEC, NV>), grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
@@ -207,6 +207,6 @@ extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb,
     a.batch = batch; a.S = S; a.heads = heads; a.text_rows = text_rows; a.ld = ld; a.bs = batch_stride; a.eps = eps;
     const long long total = (long long)batch * S * (heads / 8) * 2;
     dim3 grid((unsigned)((total + 3) / 4));
-    hipLaunchKernelGGL(qknorm_rope_kernel, grid, dim3(256), 0, stream, a);
+    BYA_LAUNCH(qknorm_rope_kernel, grid, dim3(256), 0, stream, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

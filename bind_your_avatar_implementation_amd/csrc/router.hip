@@ -171,7 +171,7 @@ extern "C" int bya_router_scores(const void* qr, const void* kr, const void* ln_
     if (((uintptr_t)qr | (uintptr_t)kr | (uintptr_t)ln_w | (uintptr_t)ln_b | (uintptr_t)pos_emb | (uintptr_t)out) & 15)
         return BYA_ERR_ALIGN;
     const long long waves = ((N + 15) / 16) * n_id;
-    hipLaunchKernelGGL(router_scores_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream,
+    BYA_LAUNCH(router_scores_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream,
                        (const bf16_t*)qr, (const bf16_t*)kr, (const bf16_t*)ln_w, (const bf16_t*)ln_b,
                        (const bf16_t*)pos_emb, (bf16_t*)out, n_id, (long long)N, eps);
     return ok();
@@ -182,7 +182,7 @@ extern "C" int bya_router_head(const void* x, const void* w, const void* b, void
     if (!x || !w || !b || !r || n_id <= 0 || N <= 0 || D <= 0 || D % 512) return BYA_ERR_SHAPE;
     if (((uintptr_t)x | (uintptr_t)w) & 15) return BYA_ERR_ALIGN;
     const long long rows = (long long)N * n_id;
-    hipLaunchKernelGGL(router_head_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)x,
+    BYA_LAUNCH(router_head_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)x,
                        (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)r, n_id, (long long)N, D);
     return ok();
 }
@@ -194,15 +194,15 @@ extern "C" int bya_attn_tiny(const void* q, const void* k, const void* v, void* 
     const long long waves = (long long)n_outer * n_inner * heads;
     dim3 grid((unsigned)((waves + 3) / 4));
     if (L <= 2)
-        hipLaunchKernelGGL((attn_tiny_kernel<2>), grid, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+        BYA_LAUNCH((attn_tiny_kernel<2>), grid, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, (bf16_t*)o, L, heads, (long long)n_outer, (long long)n_inner,
                            (long long)outer_stride, (long long)seq_stride, (long long)ld_qkv, (long long)ld_o, scale);
     else if (L <= 4)
-        hipLaunchKernelGGL((attn_tiny_kernel<4>), grid, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+        BYA_LAUNCH((attn_tiny_kernel<4>), grid, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, (bf16_t*)o, L, heads, (long long)n_outer, (long long)n_inner,
                            (long long)outer_stride, (long long)seq_stride, (long long)ld_qkv, (long long)ld_o, scale);
     else
-        hipLaunchKernelGGL((attn_tiny_kernel<16>), grid, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+        BYA_LAUNCH((attn_tiny_kernel<16>), grid, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, (bf16_t*)o, L, heads, (long long)n_outer, (long long)n_inner,
                            (long long)outer_stride, (long long)seq_stride, (long long)ld_qkv, (long long)ld_o, scale);
     return ok();

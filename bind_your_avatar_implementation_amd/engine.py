@@ -331,7 +331,7 @@ class DenoiseEngine:
                     ops.gemm(xn, at.to_v.weight, v, bias=at.to_v.bias)
                     ops.qknorm_rope(q, k, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
                                     heads=H, text_rows=Tt if cos is not None else S, eps=at.norm_q.eps)
-                    ops.self_attention(q, k, v, xn, heads=H)
+                    ops.self_attention(q, k, v, xn, heads=H, tag="joint")
                     ops.gemm(xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
                              gate1=mo[:, 2 * D:], gate_split=Tt, gate_batch_stride=mbs)
                 else:

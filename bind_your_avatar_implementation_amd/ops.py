@@ -18,6 +18,46 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- optional per-entry-point timers (HIP events recorded on the launch stream; used by bench.py) -------------
+_TIMERS = None
+_FLOPS = {}
+
+
+def enable_kernel_timers():
+    global _TIMERS, _FLOPS
+    _TIMERS, _FLOPS = {}, {}
+    return _TIMERS
+
+
+def _begin(name, flops=0.0):
+    if _TIMERS is None:
+        return None
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()           # torch's CURRENT stream == the stream every kernel here is launched on
+    _FLOPS[name] = _FLOPS.get(name, 0.0) + flops
+    return (name, s, e)
+
+
+def _end(tok):
+    if tok is not None:
+        tok[2].record()
+        _TIMERS.setdefault(tok[0], []).append((tok[1], tok[2]))
+
+
+def collect_kernel_timers():
+    """-> {name: [seconds per launch]}; synchronises, then disables the timers."""
+    global _TIMERS
+    torch.cuda.synchronize()
+    out = {k: [s.elapsed_time(e) * 1e-3 for s, e in v] for k, v in (_TIMERS or {}).items()}
+    _TIMERS = None
+    return out
+
+
+def kernel_timer_flops():
+    return dict(_FLOPS)
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -57,8 +97,10 @@ def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, g
             raise ValueError("res shape mismatch")
         d.ldres, d.res_batch_stride = ldres, (r_bs if rb == ab else 0)
     d.gate_batch_stride, d.gate_split, d.act = gate_batch_stride, gate_split, ACT[act]
+    tok = _begin("bya_gemm_bf16", 2.0 * ab * M * N * K)
     check(lib.bya_gemm_bf16(_p(a), _p(w), _p(bias), _p(out), _p(res), _p(gate0), _p(gate1), ctypes.byref(d),
                             _stream()), "bya_gemm_bf16")
+    _end(tok)
     return out
 
 
@@ -69,8 +111,10 @@ def linear_small_m(x, w, bias, out, silu_in=False, act_out=None):
     N = w.shape[0]
     assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and out.shape == (M, N)
     assert x.dtype == w.dtype == out.dtype == torch.bfloat16 and w.shape[1] == K
+    tok = _begin("bya_linear_small_m")
     check(lib.bya_linear_small_m(_p(x), _p(w), _p(bias), _p(out), M, N, K, int(silu_in), ACT[act_out], _stream()),
           "bya_linear_small_m")
+    _end(tok)
     return out
 
 
@@ -78,8 +122,10 @@ def timestep_features(timesteps, out, flip_sin_to_cos=True, freq_shift=0.0):
     lib = _hip.load()
     assert timesteps.dtype == torch.int64 and timesteps.is_cuda and out.dtype == torch.bfloat16
     b, dim = out.shape
+    tok = _begin("bya_timestep_features")
     check(lib.bya_timestep_features(_p(timesteps), _p(out), b, dim, int(flip_sin_to_cos), float(freq_shift),
                                     _stream()), "bya_timestep_features")
+    _end(tok)
     return out
 
 
@@ -90,9 +136,11 @@ def layernorm(x, out, weight=None, bias=None, eps=1e-5, shift0=None, scale0=None
     xb, rows, D, x_bs, ldx = _mat(x, "x")
     ob, rows_o, Do, y_bs, ldy = _mat(out, "out")
     assert (xb, rows, D) == (ob, rows_o, Do)
+    tok = _begin("bya_layernorm")
     check(lib.bya_layernorm(_p(x), _p(out), _p(weight), _p(bias), _p(shift0), _p(scale0), _p(shift1), _p(scale1),
                             rows, xb, D, ldx, ldy, x_bs, y_bs, mod_batch_stride, split, float(eps), _stream()),
           "bya_layernorm")
+    _end(tok)
     return out
 
 
@@ -104,12 +152,14 @@ def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6):
     if cos is not None:
         assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
         assert cos.shape == (S - text_rows, 64)
+    tok = _begin("bya_qknorm_rope")
     check(lib.bya_qknorm_rope(_p(q), _p(k), _p(qw), _p(qb), _p(kw), _p(kb), _p(cos), _p(sin), b, S, heads, ld,
                               bs if b > 1 else 0, text_rows, float(eps), _stream()), "bya_qknorm_rope")
+    _end(tok)
 
 
 def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_strides, v_strides, o_strides,
-              scale):
+              scale, tag="other"):
     """Flash attention with explicit (level-1, level-2, row) element strides for q, k, v, out."""
     lib = _hip.load()
     d = AttnDesc()
@@ -121,11 +171,13 @@ def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_
     d.scale = float(scale)
     for t in (q, k, v, out):
         assert t.dtype == torch.bfloat16 and t.is_cuda
+    tok = _begin("bya_attn_fwd:" + tag, 4.0 * nb1 * nb2 * heads * Sq * Skv * head_dim)
     check(lib.bya_attn_fwd(_p(q), _p(k), _p(v), _p(out), ctypes.byref(d), _stream()), "bya_attn_fwd")
+    _end(tok)
     return out
 
 
-def self_attention(q, k, v, out, heads, head_dim=64, scale=None):
+def self_attention(q, k, v, out, heads, head_dim=64, scale=None, tag="other"):
     """q,k,v,out: [B, S, heads*head_dim] views (row-strided ok)."""
     b, S, _, q_bs, q_ld = _mat(q, "q")
     _, Skv, _, k_bs, k_ld = _mat(k, "k")
@@ -134,13 +186,15 @@ def self_attention(q, k, v, out, heads, head_dim=64, scale=None):
     scale = head_dim ** -0.5 if scale is None else scale
     return attention(q, k, v, out, head_dim=head_dim, heads=heads, nb1=b, nb2=1, Sq=S, Skv=Skv,
                      q_strides=(q_bs, 0, q_ld), k_strides=(k_bs, 0, k_ld), v_strides=(v_bs, 0, v_ld),
-                     o_strides=(o_bs, 0, o_ld), scale=scale)
+                     o_strides=(o_bs, 0, o_ld), scale=scale, tag=tag)
 
 
 def attn_tiny(q, k, v, out, L, heads, n_outer, n_inner, outer_stride, seq_stride, ld_qkv, ld_o, scale):
     lib = _hip.load()
+    tok = _begin("bya_attn_tiny")
     check(lib.bya_attn_tiny(_p(q), _p(k), _p(v), _p(out), L, heads, n_outer, n_inner, outer_stride, seq_stride,
                             ld_qkv, ld_o, float(scale), _stream()), "bya_attn_tiny")
+    _end(tok)
     return out
 
 
@@ -148,23 +202,29 @@ def router_scores(qr, kr, ln_w, ln_b, pos_emb, out, n_id, N, eps=1e-5):
     lib = _hip.load()
     for t in (qr, kr, ln_w, ln_b, pos_emb, out):
         assert t.is_contiguous() and t.dtype == torch.bfloat16
+    tok = _begin("bya_router_scores")
     check(lib.bya_router_scores(_p(qr), _p(kr), _p(ln_w), _p(ln_b), _p(pos_emb), _p(out), n_id, N, 16, 32,
                                 float(eps), _stream()), "bya_router_scores")
+    _end(tok)
     return out
 
 
 def router_head(x, w, b, r, n_id, N):
     lib = _hip.load()
     assert x.is_contiguous() and r.is_contiguous()
+    tok = _begin("bya_router_head")
     check(lib.bya_router_head(_p(x), _p(w), _p(b), _p(r), n_id, N, x.shape[-1], _stream()), "bya_router_head")
+    _end(tok)
     return r
 
 
 def forcing_max_over_frames(forcing, out, frames, per_frame, n_id):
     lib = _hip.load()
     assert forcing.is_contiguous() and out.is_contiguous() and forcing.dtype == out.dtype == torch.bfloat16
+    tok = _begin("bya_forcing_max_over_frames")
     check(lib.bya_forcing_max_over_frames(_p(forcing), _p(out), frames, per_frame, n_id, _stream()),
           "bya_forcing_max_over_frames")
+    _end(tok)
     return out
 
 
@@ -178,8 +238,10 @@ def masked_combine(x, feat, r, af, mode, alpha=1.0):
     r_bs = 0 if r.shape[0] == 1 else N * n_id
     if af is not None:
         assert af.is_contiguous() and af.dtype == torch.bfloat16 and af.shape == (b, n_id, n_id)
+    tok = _begin("bya_masked_combine")
     check(lib.bya_masked_combine(_p(x), _p(feat), _p(r), _p(af), {"face": 0, "audio": 1}[mode], float(alpha), b,
                                  n_id, N, D, x_row, x_bs, r_bs, _stream()), "bya_masked_combine")
+    _end(tok)
     return x
 
 
@@ -187,7 +249,9 @@ def patchify(x, cols):
     lib = _hip.load()
     b, t, c, h, w = x.shape
     assert x.is_contiguous() and cols.is_contiguous() and x.dtype == cols.dtype == torch.bfloat16
+    tok = _begin("bya_patchify")
     check(lib.bya_patchify(_p(x), _p(cols), b, t, c, h, w, _stream()), "bya_patchify")
+    _end(tok)
     return cols
 
 
@@ -195,12 +259,16 @@ def unpatchify(y, out):
     lib = _hip.load()
     b, t, c, h, w = out.shape
     assert y.is_contiguous() and out.is_contiguous() and y.dtype == out.dtype == torch.bfloat16
+    tok = _begin("bya_unpatchify")
     check(lib.bya_unpatchify(_p(y), _p(out), b, t, c, h, w, _stream()), "bya_unpatchify")
+    _end(tok)
     return out
 
 
 def act_add(x, out, act=None, res=None):
     lib = _hip.load()
     assert x.is_contiguous() and out.is_contiguous() and (res is None or res.is_contiguous())
+    tok = _begin("bya_act_add")
     check(lib.bya_act_add(_p(x), _p(res), _p(out), x.numel(), ACT[act], _stream()), "bya_act_add")
+    _end(tok)
     return out
