@@ -57,6 +57,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # ONE HIP runtime per process: torch must map its (bundled) libamdhip64 first so that this library binds to
+    # the same runtime that owns torch's device pointers and streams.  Loading in the other order gives two
+    # runtimes and hipErrorNoDevice at the first launch.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the Bind-Your-Avatar MI355X engine has no fallback path. "

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void attn_tiny_kernel(const bf16_t* __restrict
     }
 }
 
-inline int ok() { return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH; }
+inline int ok() { const hipError_t e = hipGetLastError(); return e == hipSuccess ? BYA_OK : -(1000 + (int)e); }
 
 }  // namespace
 
