@@ -39,7 +39,10 @@ def build_hip_library(force=False, verbose=True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(build_dir, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        # -amdgpu-mfma-vgpr-form: MFMA results stay in arch VGPRs (gfx950's register file is unified), which removes
+        # the v_accvgpr_read/write traffic hipcc otherwise inserts wherever VALU code touches an accumulator.
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+               "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -56,6 +56,128 @@ __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ src, long lo
     }
 }
 
+// ds_read_b64_tr_b16 through inline asm: the builtin makes hipcc drain the in-flight LDS-DMA of the NEXT tile
+// (s_waitcnt vmcnt(0)) in the middle of the loop; an asm read is invisible to that bookkeeping.  Waits for these
+// reads are counted by hand (lgkmcnt), always followed by sched_barrier(0) so no MFMA is hoisted above the wait.
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr_read(uint32_t addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int D>
+struct VFrag {
+    s16x4 lo[D / 32], hi[D / 32];
+};
+
+template <int D, int KS>
+__device__ __forceinline__ void v_issue(VFrag<D>& f, const uint32_t (&vbase)[D / 32]) {
+    constexpr int RB = D * 2;
+#pragma unroll
+    for (int d = 0; d < D / 32; ++d) {
+        f.lo[d] = lds_tr_read<KS * 16 * RB>(vbase[d]);
+        f.hi[d] = lds_tr_read<KS * 16 * RB + 8 * RB>(vbase[d]);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void pv_mfma(const VFrag<D>& f, const bf16x8& pf, f32x16 (&oacc)[D / 32]) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+    for (int d = 0; d < D / 32; ++d) {
+        const s16x8 both = {f.lo[d][0], f.lo[d][1], f.lo[d][2], f.lo[d][3], f.hi[d][0], f.hi[d][1], f.hi[d][2], f.hi[d][3]};
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf, oacc[d], 0, 0, 0);
+    }
+}
+
+constexpr float RESCALE_THR = 6.0f;   // skip the O rescale while the running max grows by < 2^6 (P stays < 64)
+
+// One 64-key tile: S^T = K.Q^T, online softmax, O^T += V^T.P^T.
+// TAIL: only the first kv_valid keys of the tile exist (scores of the rest are forced to -inf -> P = 0).
+template <int D, bool TAIL>
+__device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase)[D / 32], const bf16x8 (&qf)[D / 16],
+                                          f32x16 (&oacc)[D / 32], float& m_run, float& l_run, float c, int kv_valid,
+                                          int r, int hf) {
+    constexpr int ROW_BYTES = D * 2, DSTEPS = D / 16, DT = D / 32;
+    f32x16 sacc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[u][i] = 0.f;
+        const int krow = u * 32 + r;
+#pragma unroll
+        for (int s = 0; s < DSTEPS; ++s) {
+            const int chunk = 2 * s + hf;
+            const int off = krow * ROW_BYTES + ((chunk ^ kswz<D>(krow)) << 4);
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + off);
+            sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[u], 0, 0, 0);
+        }
+    }
+    // first V fragments can fly while the softmax runs
+    VFrag<D> fa, fb;
+    v_issue<D, 0>(fa, vbase);
+
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (TAIL) {
+                const int kv = u * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
+                if (kv >= kv_valid) sacc[u][i] = -INFINITY;
+            }
+            mx = fmaxf(mx, sacc[u][i]);
+        }
+    {   // partner lane (lane ^ 32) holds the other 32 keys of this query row: one v_permlane32_swap, no LDS
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * c;     // c > 0: max commutes with the scale
+    }
+    if (__builtin_amdgcn_ballot_w64(mx > m_run + RESCALE_THR) != 0) {   // wave-uniform; always taken on the first tile
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+    }
+    float psum = 0.f;
+    bf16x8 pf[4];
+    const float neg_m = -m_run;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[u][tt * 8 + e], c, neg_m));
+                psum += pv;
+                pf[u * 2 + tt][e] = (__bf16)pv;
+            }
+    l_run += psum;
+
+    // O^T += V^T . P^T, k-step ks covers tile keys 16ks + 8(e>>2) + 4hf + (e&3); reads run one step ahead.
+    v_issue<D, 1>(fb, vbase);
+    lgkm_wait<2 * DT>();
+    pv_mfma<D>(fa, pf[0], oacc);
+    v_issue<D, 2>(fa, vbase);
+    lgkm_wait<2 * DT>();
+    pv_mfma<D>(fb, pf[1], oacc);
+    v_issue<D, 3>(fb, vbase);
+    lgkm_wait<2 * DT>();
+    pv_mfma<D>(fa, pf[2], oacc);
+    lgkm_wait<0>();
+    pv_mfma<D>(fb, pf[3], oacc);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,11 +223,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
+    // per-lane LDS byte offsets of the transposed V reads inside a V tile (everything but the k-step is
+    // lane-constant; the k-step and the lo/hi half go into the instruction's immediate offset)
+    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    uint32_t voff[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        const int row = 4 * hf + tq;
+        const int chunk = 4 * d + 2 * (g & 1) + (tp >> 1);
+        voff[d] = row * ROW_BYTES + ((chunk ^ vswz<D>(row)) << 4) + (tp & 1) * 8;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+
     const int ntiles = (p.Skv + KV_TILE - 1) / KV_TILE;
+    const int nfull = p.Skv / KV_TILE;
     stage_kv<D, false>(K, p.k_row, 0, p.Skv - 1, smem, wave, lane);
     stage_kv<D, true>(V, p.v_row, 0, p.Skv - 1, smem + TILE_BYTES, wave, lane);
 
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = 0; t < nfull; ++t) {                     // full tiles: no masking code in the hot loop
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < ntiles) {
@@ -113,93 +248,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             stage_kv<D, true>(V, p.v_row, (t + 1) * KV_TILE, p.Skv - 1, smem + ((t + 1) & 1) * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
         }
         const char* kt = smem + (t & 1) * 2 * TILE_BYTES;
-        const char* vt = kt + TILE_BYTES;
-
-        // ---- S^T[u] (32 keys x 32 queries) = K[u] . Q^T
-        f32x16 sacc[2];
+        uint32_t vbase[DT];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int d = 0; d < DT; ++d) vbase[d] = lds0 + (t & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
+        attn_tile<D, false>(kt, vbase, qf, oacc, m_run, l_run, p.scale_log2, KV_TILE, r, hf);
+    }
+    if (nfull < ntiles) {                                 // ragged last tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* kt = smem + (nfull & 1) * 2 * TILE_BYTES;
+        uint32_t vbase[DT];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[u][i] = 0.f;
-            const int krow = u * 32 + r;
-#pragma unroll
-            for (int s = 0; s < DSTEPS; ++s) {
-                const int chunk = 2 * s + hf;   // 16-byte chunk index within the row
-                const int off = krow * ROW_BYTES + ((chunk ^ kswz<D>(krow)) << 4);
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + off);
-                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[u], 0, 0, 0);
-            }
-        }
-
-        // ---- online softmax over the 64 keys of this tile (this lane: 32 of them, partner lane^32 the rest)
-        const int kv_base = t * KV_TILE;
-        const bool tail = kv_base + KV_TILE > p.Skv;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float sv = sacc[u][i] * p.scale_log2;
-                if (tail) {
-                    const int kv = kv_base + u * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
-                    sv = kv < p.Skv ? sv : -INFINITY;
-                }
-                sacc[u][i] = sv;
-                mx = fmaxf(mx, sv);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);      // finite: every tile has >= 1 valid key
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
-        m_run = m_new;
-        float psum = 0.f;
-        bf16x8 pf[4];                               // B operand for k-steps (u,tt): regs 8tt..8tt+7 of sacc[u]
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(sacc[u][tt * 8 + e] - m_new);
-                    psum += pv;
-                    pf[u * 2 + tt][e] = (__bf16)pv;
-                }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
-
-        // ---- O^T[d] (32 dims x 32 queries) += V^T[d] . P^T ; A operand by transposed LDS reads.
-        // k-step ks = 2u+tt covers tile keys 16ks + 8(e>>2) + 4hf + (e&3), e = 0..7.
-        const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int d = 0; d < DT; ++d) {
-                const int chunk = 4 * d + 2 * (g & 1) + (tp >> 1);
-                s16x4 lo, hi;
-                {
-                    const int row = 16 * ks + 4 * hf + tq;
-                    const int off = row * ROW_BYTES + ((chunk ^ vswz<D>(row)) << 4) + (tp & 1) * 8;
-                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)LDS_PTR(vt + off));
-                }
-                {
-                    const int row = 16 * ks + 8 + 4 * hf + tq;
-                    const int off = row * ROW_BYTES + ((chunk ^ vswz<D>(row)) << 4) + (tp & 1) * 8;
-                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)LDS_PTR(vt + off));
-                }
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
-                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], oacc[d], 0, 0, 0);
-            }
-        }
+        for (int d = 0; d < DT; ++d) vbase[d] = lds0 + (nfull & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
+        attn_tile<D, true>(kt, vbase, qf, oacc, m_run, l_run, p.scale_log2, p.Skv - nfull * KV_TILE, r, hf);
     }
 
     // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (r,hf) holds d = 32dt + (i&3) + 8(i>>2) + 4hf
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    const float l_tot = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
     const float inv = 1.0f / l_tot;
     if (q_valid) {
         bf16_t* orow = O + (long long)(q0 + r) * p.o_row;

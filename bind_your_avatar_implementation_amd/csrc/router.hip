@@ -159,6 +159,80 @@ __global__ __launch_bounds__(256) void attn_tiny_kernel(const bf16_t* __restrict
     }
 }
 
+
+// Fast path of the tiny attention for 8 heads x 64 dims per wave: lane = (head, 8-element chunk), so one wave reads
+// whole 1-KiB q/k/v rows (fully coalesced), the per-(i,j) dot product is 4 x v_dot2c_f32_bf16 + a 3-step DPP
+// reduction inside each 8-lane head group, and P.V stays lane-local.  Exact sequence length L is a template
+// parameter (K and V of the whole sequence live in registers as packed bf16).
+__device__ __forceinline__ float reduce8(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, t);
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, t);
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true);      // row_half_mirror
+    return v + __builtin_bit_cast(float, t);
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void attn_tiny8_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                         const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
+                                                         int hgroups, long long n_outer, long long n_inner,
+                                                         long long outer_stride, long long seq_stride, long long ld_qkv,
+                                                         long long ld_o, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= n_outer * n_inner * hgroups) return;
+    const int hgrp = (int)(wid % hgroups);
+    const long long gseq = wid / hgroups;
+    const long long row0 = (gseq / n_inner) * outer_stride + (gseq % n_inner);
+    const int col = hgrp * 512 + lane * 8;
+    uint32_t kq[L][4], vq[L][4], qq[L][4];      // plain scalars: bit_cast of an ext_vector element miscompiles
+#pragma unroll
+    for (int e = 0; e < L; ++e) {
+        const long long off = (row0 + e * seq_stride) * ld_qkv + col;
+        const u32x4 a = *reinterpret_cast<const u32x4*>(q + off);
+        const u32x4 b = *reinterpret_cast<const u32x4*>(k + off);
+        const u32x4 c = *reinterpret_cast<const u32x4*>(v + off);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { qq[e][w] = a[w]; kq[e][w] = b[w]; vq[e][w] = c[w]; }
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        float s[L];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            float d = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+            {
+                const uint32_t qa = qq[i][w], kb = kq[j][w];
+                d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, qa), __builtin_bit_cast(bf16x2, kb), d,
+                                                    false);
+            }
+            s[j] = reduce8(d) * scale;
+            mx = fmaxf(mx, s[j]);
+        }
+        float den = 0.f, acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const float pj = __expf(s[j] - mx);
+            den += pj;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                acc[2 * w] = fmaf(pj, bflo(vq[j][w]), acc[2 * w]);
+                acc[2 * w + 1] = fmaf(pj, bfhi(vq[j][w]), acc[2 * w + 1]);
+            }
+        }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= inv;
+        *reinterpret_cast<u32x4*>(o + (row0 + i * seq_stride) * ld_o + col) = pack8(acc);
+    }
+}
+
 inline int ok() { const hipError_t e = hipGetLastError(); return e == hipSuccess ? BYA_OK : -(1000 + (int)e); }
 
 }  // namespace
@@ -191,6 +265,21 @@ extern "C" int bya_attn_tiny(const void* q, const void* k, const void* v, void* 
                              int64_t n_outer, int64_t n_inner, int64_t outer_stride, int64_t seq_stride,
                              int64_t ld_qkv, int64_t ld_o, float scale, hipStream_t stream) {
     if (!q || !k || !v || !o || L <= 0 || L > 16 || heads <= 0 || n_outer <= 0 || n_inner <= 0) return BYA_ERR_SHAPE;
+    if (heads % 8 == 0 && (L == 2 || L == 13) && ld_qkv % 8 == 0 && ld_o % 8 == 0 &&
+        !(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)) {
+        const int hgroups = heads / 8;
+        const long long w8 = (long long)n_outer * n_inner * hgroups;
+        dim3 g8((unsigned)((w8 + 3) / 4));
+        if (L == 2)
+            BYA_LAUNCH((attn_tiny8_kernel<2>), g8, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (bf16_t*)o, hgroups, (long long)n_outer, (long long)n_inner,
+                       (long long)outer_stride, (long long)seq_stride, (long long)ld_qkv, (long long)ld_o, scale);
+        else
+            BYA_LAUNCH((attn_tiny8_kernel<13>), g8, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (bf16_t*)o, hgroups, (long long)n_outer, (long long)n_inner,
+                       (long long)outer_stride, (long long)seq_stride, (long long)ld_qkv, (long long)ld_o, scale);
+        return ok();
+    }
     const long long waves = (long long)n_outer * n_inner * heads;
     dim3 grid((unsigned)((waves + 3) / 4));
     if (L <= 2)
