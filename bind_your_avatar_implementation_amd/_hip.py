@@ -15,7 +15,8 @@ class GemmDesc(_c.Structure):
     _fields_ = [("M", _i32), ("N", _i32), ("K", _i32), ("batch", _i32),
                 ("lda", _i32), ("ldw", _i32), ("ldc", _i32), ("ldres", _i32),
                 ("a_batch_stride", _i64), ("c_batch_stride", _i64), ("res_batch_stride", _i64),
-                ("gate_batch_stride", _i64), ("gate_split", _i32), ("act", _i32)]
+                ("gate_batch_stride", _i64), ("gate_split", _i32), ("act", _i32),
+                ("n_split", _i32), ("c_split_stride", _i64)]
 
 
 class AttnDesc(_c.Structure):

@@ -14,6 +14,7 @@
 // Epilogue: + bias -> activation -> * gate[row-type] -> + residual -> bf16.
 #include "bya_common.h"
 #include "../../include/bya.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,15 +27,17 @@ struct GemmArgs {
     int gate_split;
     int act;
     float leaky;
+    int n_split;            // > 0: output column n goes to C + (n / n_split) * c_split_stride, column n % n_split
+    long long c_split_stride;
 };
 
 constexpr int BK = 64;  // bf16 elements per K tile = 128-byte LDS rows
 
-template <int ROWS>
+template <int ROWS, int NWAVES>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int ld, int row0, int row_max, int k0,
                                            char* lds_tile, int wave, int lane) {
-    // ROWS x 64 bf16 tile, 8 rows (1 KiB) per wave-instruction, ROWS/32 instructions per wave.
-    constexpr int PER_WAVE = ROWS / 4;
+    // ROWS x 64 bf16 tile, 8 rows (1 KiB) per wave-instruction, ROWS/(8*NWAVES) instructions per wave.
+    constexpr int PER_WAVE = ROWS / NWAVES;
 #pragma unroll
     for (int q = 0; q < PER_WAVE / 8; ++q) {
         const int rbase = wave * PER_WAVE + q * 8;
@@ -52,22 +55,59 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int chunk)
     return *reinterpret_cast<const bf16x8*>(tile + off);
 }
 
-__device__ __forceinline__ float apply_act(float v, int act, float leaky) {
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v, float leaky) {
+    if constexpr (ACT == 1) return gelu_tanh(v);
+    else if constexpr (ACT == 2) return gelu_erf(v);
+    else if constexpr (ACT == 3) return v > 0.f ? v : 0.f;
+    else if constexpr (ACT == 4) return silu(v);
+    else if constexpr (ACT == 5) return v > 0.f ? v : v * leaky;
+    else return v;
+}
+
+
+// Epilogue for 4 consecutive output columns n4..n4+3 of row m: + bias -> act -> * gate[row type] -> + residual -> bf16
+template <int V> struct IntTag { static constexpr int value = V; };
+template <typename F>
+__device__ __forceinline__ void dispatch_act(int act, F&& f) {
     switch (act) {
-        case 1: return gelu_tanh(v);
-        case 2: return gelu_erf(v);
-        case 3: return v > 0.f ? v : 0.f;
-        case 4: return silu(v);
-        case 5: return v > 0.f ? v : v * leaky;
-        default: return v;
+        case 1: f(IntTag<1>{}); break;
+        case 2: f(IntTag<2>{}); break;
+        case 3: f(IntTag<3>{}); break;
+        case 4: f(IntTag<4>{}); break;
+        case 5: f(IntTag<5>{}); break;
+        default: f(IntTag<0>{}); break;
     }
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
+template <int ACT>
+__device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n4, const f32x4 acc, const float (&b4)[4]) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(acc[e] + b4[e], p.leaky);
+    if (p.gate0) {
+        const bf16_t* g = (m < p.gate_split ? p.gate0 : p.gate1) + (long long)z * p.gate_bs + n4;
+        const u32x2 gv = *reinterpret_cast<const u32x2*>(g);
+        v[0] *= bflo(gv[0]); v[1] *= bfhi(gv[0]); v[2] *= bflo(gv[1]); v[3] *= bfhi(gv[1]);
+    }
+    long long col = n4;
+    if (p.n_split > 0) col = (long long)(n4 / p.n_split) * p.c_split_stride + (n4 % p.n_split);
+    if (p.res) {
+        const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + (long long)z * p.res_bs + (long long)m * p.ldres + n4);
+        v[0] += bflo(rv[0]); v[1] += bfhi(rv[0]); v[2] += bflo(rv[1]); v[3] += bfhi(rv[1]);
+    }
+    u32x2 o;
+    o[0] = pack2bf(v[0], v[1]);
+    o[1] = pack2bf(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(p.C + (long long)z * p.c_bs + (long long)m * p.ldc + col) = o;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int TILE_A = BM * BK * 2, TILE_W = BN * BK * 2, STAGE = TILE_A + TILE_W;
-    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MI = WM / 16, NI = WN / 16;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,8 +129,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
-        stage_tile<BM>(A, p.lda, m0, p.M - 1, kt * BK, base, wave, lane);
-        stage_tile<BN>(p.W, p.ldw, n0, p.N - 1, kt * BK, base + TILE_A, wave, lane);
+        stage_tile<BM, NWAVES>(A, p.lda, m0, p.M - 1, kt * BK, base, wave, lane);
+        stage_tile<BN, NWAVES>(p.W, p.ldw, n0, p.N - 1, kt * BK, base + TILE_A, wave, lane);
     };
 
     f32x4 acc[NI][MI];
@@ -99,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int fr = lane & 15, fq = lane >> 4;
 
     stage(0, 0);
@@ -125,55 +165,278 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     }
 
     // ---- epilogue: lane holds C[m][n4..n4+3], m = m0 + wm*WM + j*16 + fr, n4 = n0 + wn*WN + i*16 + fq*4
-    bf16_t* C = p.C + (long long)z * p.c_bs;
-    const bf16_t* R = p.res ? p.res + (long long)z * p.res_bs : nullptr;
+    // (one fully unrolled, switch-free copy per activation: a runtime-indexed accumulator array would go to scratch)
+    auto run = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int n4 = n0 + wn * WN + i * 16 + fq * 4;
-        if (n4 >= p.N) continue;
-        float b4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-            const u32x2 bv = *reinterpret_cast<const u32x2*>(p.bias + n4);
-            b4[0] = bflo(bv[0]); b4[1] = bfhi(bv[0]); b4[2] = bflo(bv[1]); b4[3] = bfhi(bv[1]);
-        }
-#pragma unroll
-        for (int j = 0; j < MI; ++j) {
-            const int m = m0 + wm * WM + j * 16 + fr;
-            if (m >= p.M) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][e] + b4[e], p.act, p.leaky);
-            if (p.gate0) {
-                const bf16_t* g = (m < p.gate_split ? p.gate0 : p.gate1) + (long long)z * p.gate_bs + n4;
-                const u32x2 gv = *reinterpret_cast<const u32x2*>(g);
-                v[0] *= bflo(gv[0]); v[1] *= bfhi(gv[0]); v[2] *= bflo(gv[1]); v[3] *= bfhi(gv[1]);
+        for (int i = 0; i < NI; ++i) {
+            const int n4 = n0 + wn * WN + i * 16 + fq * 4;
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n4 < p.N) {
+                const u32x2 bv = *reinterpret_cast<const u32x2*>(p.bias + n4);
+                b4[0] = bflo(bv[0]); b4[1] = bfhi(bv[0]); b4[2] = bflo(bv[1]); b4[3] = bfhi(bv[1]);
             }
-            if (R) {
-                const u32x2 rv = *reinterpret_cast<const u32x2*>(R + (long long)m * p.ldres + n4);
-                v[0] += bflo(rv[0]); v[1] += bfhi(rv[0]); v[2] += bflo(rv[1]); v[3] += bfhi(rv[1]);
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const int m = m0 + wm * WM + j * 16 + fr;
+                if (m < p.M && n4 < p.N) epilogue4<ACT>(p, z, m, n4, acc[i][j], b4);
             }
-            u32x2 o;
-            o[0] = pack2bf(v[0], v[1]);
-            o[1] = pack2bf(v[2], v[3]);
-            *reinterpret_cast<u32x2*>(C + (long long)m * p.ldc + n4) = o;
         }
-    }
+    };
+    dispatch_act(p.act, run);
 }
 
-template <int BM, int BN>
+// ================================================================================================================
+// Pipelined 256x256x64 kernel (8 waves = 2(M) x 4(N), wave tile 128x64, 2-stage 128 KiB LDS ring).
+//
+// Per K-tile a wave runs eight 8-MFMA phases: for each 32-wide k-step the four 64x32 quadrants of its 128x64 tile
+// in snake order (A0,B0) (A0,B1) (A1,B1) (A1,B0), so every fragment is read from LDS exactly once per tile and
+// each phase needs at most ONE new operand, whose ds_reads are issued BEFORE the MFMAs of the previous phase:
+// the matrix pipe never waits on LDS inside a tile and only 48 fragment registers are live.
+// There is ONE raw s_barrier per K-tile, between the last two phases: by then every fragment the wave still
+// needs from the current stage is in registers, so the barrier is both "tile t+1 has landed" (each wave drains
+// its own LDS-DMA with vmcnt(0) first) and "stage t is free".  Right after it the wave reads the first fragments
+// of tile t+1 and starts the LDS-DMA of tile t+2 into the stage it just stopped reading (2 of its 8
+// global_load_lds per phase over the next four phases): no MFMA bubble at the tile seam, and every DMA gets
+// most of a K-tile period to land.  No __syncthreads() in the loop: its implied vmcnt(0) would drain the DMA it is
+// supposed to overlap.
+struct FragA { bf16x8 v[4]; };   // 64 rows x 32 k
+struct FragB { bf16x8 v[2]; };   // 32 cols x 32 k
+
+// Fragment reads are inline asm so that (a) hipcc's conservative "LDS-DMA in flight -> s_waitcnt vmcnt(0) before the
+// next LDS read" never triggers and (b) the lgkmcnt waits can be COUNTED by hand: LDS ops complete in order, so
+// "wait until all but the N youngest reads are back" leaves the prefetch of the next phase in flight.
+// Every wait names the registers it makes valid as "+v" operands: the MFMAs that consume them then depend on the
+// wait statement and cannot be scheduled above it (a bare asm s_waitcnt does not order register-only MFMAs).
+template <int OFF>
+__device__ __forceinline__ void ds_read128(bf16x8& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int HALF>
+__device__ __forceinline__ void load_frag_a(FragA& f, uint32_t addr) {
+    ds_read128<(HALF * 64 + 0) * 128>(f.v[0], addr);
+    ds_read128<(HALF * 64 + 16) * 128>(f.v[1], addr);
+    ds_read128<(HALF * 64 + 32) * 128>(f.v[2], addr);
+    ds_read128<(HALF * 64 + 48) * 128>(f.v[3], addr);
+}
+template <int HALF>
+__device__ __forceinline__ void load_frag_b(FragB& f, uint32_t addr) {
+    ds_read128<(HALF * 32 + 0) * 128>(f.v[0], addr);
+    ds_read128<(HALF * 32 + 16) * 128>(f.v[1], addr);
+}
+template <int N>
+__device__ __forceinline__ void wait_frags(FragA& a, FragB& b) {
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b.v[0]), "+v"(b.v[1])
+                 : "i"(N));
+}
+
+template <int HA, int HB>
+__device__ __forceinline__ void mfma_quadrant(f32x4 (&acc)[4][8], const FragA& a, const FragB& b) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            acc[HB * 2 + ni][HA * 4 + mi] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.v[ni], a.v[mi], acc[HB * 2 + ni][HA * 4 + mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 256, STAGE = (BM + BN) * BK * 2, TILE_A = BM * BK * 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    constexpr int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int group = id / per_group, first_m = group * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = id - group * per_group;
+    const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+    const bf16_t* A = p.A + (long long)z * p.a_bs;
+    const int nk = p.K / BK;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // lane-constant parts of the fragment addresses (the XOR swizzle depends on (row >> 1) & 7 only, and every
+    // tile/half offset is a multiple of 16 rows)
+    const int a_row = wm * 128 + fr, w_row = wn * 64 + fr;
+    const int a_sw = (a_row >> 1) & 7, w_sw = (w_row >> 1) & 7;
+    const int a_off0 = ((fq ^ a_sw) << 4), a_off1 = (((4 + fq) ^ a_sw) << 4);
+    const int w_off0 = ((fq ^ w_sw) << 4), w_off1 = (((4 + fq) ^ w_sw) << 4);
+    const int a_lane = a_row * 128, w_lane = w_row * 128;
+
+    // global -> LDS staging: 8 one-KiB pieces per wave per K-tile (q = 0..3: A rows wave*32 + 8q, q = 4..7: W rows)
+    // through buffer_load ... lds: the per-lane byte offsets are loop-invariant (8 VGPRs), the K-tile advances in the
+    // scalar offset, and rows past M / N fall outside the descriptor's range -> the hardware writes zeros (no clamps).
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)A, 0, (int)(((long long)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.W, 0, (int)(((long long)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+    uint32_t voff[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int rl = wave * 32 + (q & 3) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((rl >> 1) & 7);
+        voff[q] = (q < 4) ? (uint32_t)(m0 + rl) * (uint32_t)(p.lda * 2) + chunk * 16
+                          : (uint32_t)(n0 + rl) * (uint32_t)(p.ldw * 2) + chunk * 16;
+    }
+    auto piece = [&](int t, int q) {
+        char* dst = smem + (t & 1) * STAGE + (q >= 4 ? TILE_A : 0) + (wave * 32 + (q & 3) * 8) * 128;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(q >= 4 ? rsW : rsA, LDS_PTR(dst), 16, voff[q], t * (BK * 2), 0, 0);
+    };
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: tile 0 completely, tile 1's first two pieces
+    piece(0, 0); piece(0, 1); piece(0, 2); piece(0, 3); piece(0, 4); piece(0, 5); piece(0, 6); piece(0, 7);
+    if (nk > 1) { piece(1, 0); piece(1, 1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // LDS byte addresses of this lane's fragment rows for the CURRENT stage, k-step 0 / 1 (tile and half offsets are
+    // instruction immediates); stage 1 lives STAGE = 64 KiB above stage 0, so the seam just flips one address bit.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+    uint32_t cA0 = lds0 + a_lane + a_off0, cA1 = lds0 + a_lane + a_off1;
+    uint32_t cW0 = lds0 + TILE_A + w_lane + w_off0, cW1 = lds0 + TILE_A + w_lane + w_off1;
+    static_assert(STAGE == 65536, "stage flip uses one address bit");
+    FragA a0, a1;
+    FragB bx, by;
+    load_frag_a<0>(a0, cA0);
+    load_frag_b<0>(bx, cW0);
+
+    for (int t = 0; t < nk; ++t) {
+        const bool more = t + 1 < nk;
+        // ---- k-step 0
+        load_frag_b<1>(by, cW0);                                // B1k0 (2 reads)
+        if (more) { piece(t + 1, 2); piece(t + 1, 3); }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags<2>(a0, bx);
+        mfma_quadrant<0, 0>(acc, a0, bx);                       // P0 (A0k0, B0k0)
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag_a<1>(a1, cA0);                                // A1k0 (4 reads)
+        if (more) { piece(t + 1, 4); piece(t + 1, 5); }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags<4>(a0, by);
+        mfma_quadrant<0, 1>(acc, a0, by);                       // P1 (A0k0, B1k0)
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag_a<0>(a0, cA1);                                // A0k1 (4 reads)
+        if (more) { piece(t + 1, 6); piece(t + 1, 7); }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags<4>(a1, by);
+        mfma_quadrant<1, 1>(acc, a1, by);                       // P2 (A1k0, B1k0)
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag_b<0>(by, cW1);                                // B0k1 (2 reads)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quadrant<1, 0>(acc, a1, bx);                       // P3 (A1k0, B0k0): operands already waited for
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- k-step 1
+        load_frag_b<1>(bx, cW1);                                // B1k1 (2 reads)
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags<2>(a0, by);
+        mfma_quadrant<0, 0>(acc, a0, by);                       // P4 (A0k1, B0k1)
+        __builtin_amdgcn_sched_barrier(0);
+        load_frag_a<1>(a1, cA1);                                // A1k1 (4 reads)
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags<4>(a0, bx);
+        mfma_quadrant<0, 1>(acc, a0, bx);                       // P5 (A0k1, B1k1)
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags<0>(a1, bx);
+        mfma_quadrant<1, 1>(acc, a1, bx);                       // P6 (A1k1, B1k1)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- seam: tile t+1 landed for everybody, stage t free for everybody (P7's operands are in registers)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cA0 ^= STAGE; cA1 ^= STAGE; cW0 ^= STAGE; cW1 ^= STAGE;
+        if (more) {
+            load_frag_a<0>(a0, cA0);                            // A0k0 of tile t+1 (4 reads)
+            load_frag_b<0>(bx, cW0);                            // B0k0 of tile t+1 (2 reads)
+            if (t + 2 < nk) { piece(t + 2, 0); piece(t + 2, 1); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quadrant<1, 0>(acc, a1, by);                       // P7 (A1k1, B0k1): operands already waited for
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---- epilogue (same lane map as the small-tile kernel): acc[i][j] -> C[m][n4..n4+3]
+    auto run = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n4 = n0 + wn * 64 + i * 16 + fq * 4;
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n4 < p.N) {
+                const u32x2 bv = *reinterpret_cast<const u32x2*>(p.bias + n4);
+                b4[0] = bflo(bv[0]); b4[1] = bfhi(bv[0]); b4[2] = bflo(bv[1]); b4[3] = bfhi(bv[1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = m0 + wm * 128 + j * 16 + fr;
+                if (m < p.M && n4 < p.N) epilogue4<ACT>(p, z, m, n4, acc[i][j], b4);
+            }
+        }
+    };
+    dispatch_act(p.act, run);
+}
+
+int launch256(const GemmArgs& a, int batch, hipStream_t s) {
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+    dim3 grid(tiles_m * tiles_n, 1, batch);
+    const size_t lds = 2 * 512 * BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return BYA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    BYA_LAUNCH(gemm256_kernel, grid, dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch(const GemmArgs& a, int batch, hipStream_t s) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, batch);
     const size_t lds = 2 * (BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return BYA_ERR_LAUNCH;
         attr_set = true;
     }
-    BYA_LAUNCH((gemm_bf16_kernel<BM, BN>), grid, dim3(256), lds, s, a);
+    BYA_LAUNCH((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(64 * WAVES_M * WAVES_N), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+// Tile choice: fewest "CU rounds" (wave quantisation on 256 CUs) weighted by the tile's relative efficiency.
+inline int pick_tile(int M, int N, int batch, int forced) {
+    if (forced >= 0) return forced;
+    if (N <= 64) return 0;
+    auto rounds = [&](int bm, int bn, int per_cu) {
+        const long long blocks = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
+        const long long slots = 256LL * per_cu;
+        return (double)((blocks + slots - 1) / slots) * (bm * bn) * (double)per_cu;   // rounds x work per CU per round
+    };
+    const double t128 = rounds(128, 128, 2) / 0.80;     // measured relative speeds of the three structures
+    const double t256x128 = rounds(256, 128, 1) / 0.95;
+    const double t256 = rounds(256, 256, 1) / 1.00;
+    (void)t256x128;
+    if (M < 1024 || N < 512) return 1;
+    // the pipelined 256x256 kernel is ~1.2x the 128x128 one per unit of tile area when its grid fills the CUs
+    return (t256 / 1.2 <= t128) ? 4 : 1;
 }
 
 }  // namespace
@@ -194,6 +457,14 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
     a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = d->ldres;
     a.a_bs = d->a_batch_stride; a.c_bs = d->c_batch_stride; a.res_bs = d->res_batch_stride;
     a.gate_bs = d->gate_batch_stride; a.gate_split = d->gate_split; a.act = d->act; a.leaky = 0.01f;
-    if (d->N <= 64) return launch<128, 64>(a, d->batch, stream);
-    return launch<128, 128>(a, d->batch, stream);
+    a.n_split = d->n_split; a.c_split_stride = d->c_split_stride;
+    if (d->n_split < 0 || (d->n_split > 0 && (d->n_split % 4 || d->c_split_stride % 4 || res))) return BYA_ERR_SHAPE;
+    static const int forced = [] { const char* e = getenv("BYA_GEMM_TILE"); return e ? atoi(e) : -1; }();
+    switch (pick_tile(d->M, d->N, d->batch, forced)) {
+        case 0: return launch<128, 64, 2, 2>(a, d->batch, stream);
+        case 1: return launch<128, 128, 2, 2>(a, d->batch, stream);
+        case 2: return launch<256, 128, 4, 2>(a, d->batch, stream);
+        case 3: return launch<256, 256, 2, 4>(a, d->batch, stream);
+        default: return launch256(a, d->batch, stream);
+    }
 }

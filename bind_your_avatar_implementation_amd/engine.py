@@ -66,6 +66,12 @@ class DenoiseEngine:
         self.mod_w = cat(mods_w).contiguous()          # [(2L*6 + 2) * D, temb]
         self.mod_b = cat(mods_b).contiguous()
         self.patch_w = m.patch_embed.proj.weight.reshape(D, -1)   # [D, C*4], k = c*4 + ph*2 + pw
+        # q|k|v projection weights packed per block: one GEMM launch with N = 3D fills the CUs evenly
+        # (N = D alone leaves the last of 3.3 "rounds" of 256x256 tiles three-quarters empty)
+        self.qkv_w = [cat([b.attn1.to_q.weight, b.attn1.to_k.weight, b.attn1.to_v.weight]).contiguous()
+                      for b in m.transformer_blocks]
+        self.qkv_b = [cat([b.attn1.to_q.bias, b.attn1.to_k.bias, b.attn1.to_v.bias]).contiguous()
+                      for b in m.transformer_blocks]
         pe = getattr(m.patch_embed, "pos_embedding", None)
         use_pe = (not self.cfg.use_rotary_positional_embeddings) or self.cfg.use_learned_positional_embeddings
         self.pos_embedding = pe[0] if (pe is not None and use_pe) else None
@@ -314,7 +320,8 @@ class DenoiseEngine:
             taps["emb"], taps["embed"] = emb.clone(), x.clone()
 
         xn = buf("xn", B, S, D)
-        q, k, v = buf("q", B, S, D), buf("k", B, S, D), buf("v", B, S, D)
+        qkv = buf("qkv", 3, B, S, D)
+        q, k, v = qkv[0], qkv[1], qkv[2]
         ff = buf("ff", B, S, 4 * D)
         r_logits = None
         for i, blk in enumerate(m.transformer_blocks):
@@ -326,9 +333,7 @@ class DenoiseEngine:
                               scale0=mo[:, 4 * D:], shift1=mo, scale1=mo[:, D:], split=Tt, mod_batch_stride=mbs)
                 if half == 0:
                     at = blk.attn1
-                    ops.gemm(xn, at.to_q.weight, q, bias=at.to_q.bias)
-                    ops.gemm(xn, at.to_k.weight, k, bias=at.to_k.bias)
-                    ops.gemm(xn, at.to_v.weight, v, bias=at.to_v.bias)
+                    ops.gemm(xn, self.qkv_w[i], q, bias=self.qkv_b[i], split=(D, B * S * D))
                     ops.qknorm_rope(q, k, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
                                     heads=H, text_rows=Tt if cos is not None else S, eps=at.norm_q.eps)
                     ops.self_attention(q, k, v, xn, heads=H, tag="joint")

@@ -77,11 +77,17 @@ def _mat(t, name):
     raise ValueError(f"{name}: expected 2-D or 3-D, got {t.dim()}-D")
 
 
-def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, gate_batch_stride=0, act=None):
-    """out = res + gate * act(a @ w.T + bias).  a: [(B,) M, K], w: [N, K], out/res: [(B,) M, N]."""
+def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, gate_batch_stride=0, act=None,
+         split=None):
+    """out = res + gate * act(a @ w.T + bias).  a: [(B,) M, K], w: [N, K], out/res: [(B,) M, N].
+
+    ``split=(n_split, stride)``: ``out`` is the FIRST of N/n_split equally shaped tensors ``stride`` elements apart;
+    column n of the product lands in tensor n // n_split (packed q|k|v projection -> three buffers, one launch)."""
     lib = _hip.load()
     ab, M, K, a_bs, lda = _mat(a, "a")
     ob, Mo, N, c_bs, ldc = _mat(out, "out")
+    if split is not None:
+        N = w.shape[0]
     if w.dim() != 2 or w.shape[1] != K or w.shape[0] != N or w.stride(1) != 1 or w.dtype != torch.bfloat16:
         raise ValueError(f"w: expected bf16 [{N}, {K}], got {tuple(w.shape)} {w.dtype}")
     if (ab, M) != (ob, Mo):
@@ -97,6 +103,7 @@ def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, g
             raise ValueError("res shape mismatch")
         d.ldres, d.res_batch_stride = ldres, (r_bs if rb == ab else 0)
     d.gate_batch_stride, d.gate_split, d.act = gate_batch_stride, gate_split, ACT[act]
+    d.n_split, d.c_split_stride = (0, 0) if split is None else split
     tok = _begin("bya_gemm_bf16", 2.0 * ab * M * N * K)
     check(lib.bya_gemm_bf16(_p(a), _p(w), _p(bias), _p(out), _p(res), _p(gate0), _p(gate1), ctypes.byref(d),
                             _stream()), "bya_gemm_bf16")

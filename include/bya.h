@@ -52,6 +52,9 @@ typedef struct bya_gemm_desc {
     int64_t a_batch_stride, c_batch_stride, res_batch_stride, gate_batch_stride;
     int32_t gate_split;
     int32_t act;              /* BYA_ACT_* applied to (acc + bias) */
+    int32_t n_split;          /* > 0: column n is written to C + (n / n_split) * c_split_stride, column n % n_split
+                                 (one launch for the packed q|k|v projection writing three separate tensors) */
+    int64_t c_split_stride;
 } bya_gemm_desc;
 
 int bya_gemm_bf16(const void* A, const void* W, const void* bias, void* C, const void* res,

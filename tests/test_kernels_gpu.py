@@ -102,6 +102,28 @@ def test_gemm_strided_views(ops, dev):
     assert big[:, :, :N].abs().max() == 0 and big[:, :, 2 * N:].abs().max() == 0
 
 
+def test_gemm_split_output(ops, dev):
+    """Packed q|k|v projection: one launch, three output tensors."""
+    B, S, D = 2, 300, 256
+    a = rnd((B, S, D), dev, 13)
+    w, b = rnd((3 * D, D), dev, 14, D ** -0.5), rnd((3 * D,), dev, 15, 0.2)
+    qkv = torch.zeros(3, B, S, D, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a, w, qkv[0], bias=b, split=(D, B * S * D))
+    ref = a.float() @ w.float().T + b.float()
+    for i in range(3):
+        check(qkv[i], ref[..., i * D:(i + 1) * D], what=f"gemm split {i}")
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 64), (2500, 3072, 192), (4100, 768, 3072), (17776, 512, 512)])
+def test_gemm_pipelined_256(ops, dev, M, N, K):
+    """Shapes that select the pipelined 256x256 kernel (ragged M and N tiles, K = 1 and 3 tiles, long K)."""
+    a, w, b = rnd((M, K), dev, 16), rnd((N, K), dev, 17, K ** -0.5), rnd((N,), dev, 18)
+    res = rnd((M, N), dev, 19)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a, w, out, bias=b, res=res, act="gelu_tanh")
+    check(out, res.float() + F.gelu(a.float() @ w.float().T + b.float(), approximate="tanh"), what=f"gemm256 {M}x{N}x{K}")
+
+
 def test_gemm_rejects_bad_shapes(ops, dev):
     from bind_your_avatar_implementation_amd._hip import ByaError
     a, w = rnd((64, 96), dev, 1), rnd((64, 96), dev, 2)       # K % 64 != 0

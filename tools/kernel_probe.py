@@ -29,7 +29,19 @@ def gemm_case(M, N, K, **kw):
     a, w, out = rnd(M, K), rnd(N, K, std=K ** -0.5), torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     b = rnd(N)
     t = timeit(lambda: ops.gemm(a, w, out, bias=b, **kw))
-    print(f"gemm M={M} N={N} K={K} {kw}: {t*1e3:.3f} ms  {2*M*N*K/t/1e12:.1f} TFLOP/s", flush=True)
+    # cold: rotate over enough distinct operands (> 1 GB) that nothing is served from L2 / Infinity Cache
+    nrot = max(2, int(1.2e9 // ((M * K + N * K + M * N) * 2)) + 1)
+    As = [rnd(M, K) for _ in range(nrot)]
+    Ws = [rnd(N, K, std=K ** -0.5) for _ in range(nrot)]
+    Os = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(nrot)]
+    it = [0]
+    def cold():
+        i = it[0] % nrot
+        it[0] += 1
+        ops.gemm(As[i], Ws[i], Os[i], bias=b, **kw)
+    tc = timeit(cold, iters=2 * nrot, warm=nrot)
+    print(f"gemm M={M} N={N} K={K} {kw}: hot {t*1e3:.3f} ms {2*M*N*K/t/1e12:.1f} TF/s | cold {tc*1e3:.3f} ms "
+          f"{2*M*N*K/tc/1e12:.1f} TF/s", flush=True)
 
 
 def attn_case(B, S, H, D=64):
