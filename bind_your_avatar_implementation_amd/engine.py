@@ -21,6 +21,7 @@ Nothing here falls back to torch math: torch is used for device memory, views an
 import torch
 
 from . import ops
+from .parallel import SeqShard
 
 
 def _key(tensors):
@@ -262,7 +263,11 @@ class DenoiseEngine:
         per_frame, N = ht * wt, T * ht * wt
         Tt = encoder_hidden_states.shape[1]
         S = Tt + N
-        key = (B, T, C, Hh, Ww, Tt)
+        sh = SeqShard(getattr(m, "_seq_rank", 0), getattr(m, "_seq_world", 1), S, Tt, getattr(m, "_seq_group", None))
+        if sh.world > 1 and B != 1:
+            raise NotImplementedError("sequence-parallel execution shards ONE sample; split a CFG batch over rank groups")
+        S_loc, Tt_loc, N_loc, v0, v1 = sh.S_loc, sh.Tt_loc, sh.N_loc, sh.v0, sh.v1
+        key = (B, T, C, Hh, Ww, Tt, sh.rank, sh.world)
         if self._ws_key != key:
             self._ws_key, self._ws = key, {}
         buf = self._buf
@@ -281,10 +286,10 @@ class DenoiseEngine:
                              f"but the latents give {T}x{wt}x{ht} tokens")
         cos = sin = None
         if image_rotary_emb is not None:
-            cos = image_rotary_emb[0].to(device=self.dev, dtype=torch.float32).contiguous()
-            sin = image_rotary_emb[1].to(device=self.dev, dtype=torch.float32).contiguous()
+            cos = image_rotary_emb[0].to(device=self.dev, dtype=torch.float32)[v0:v1].contiguous()
+            sin = image_rotary_emb[1].to(device=self.dev, dtype=torch.float32)[v0:v1].contiguous()
 
-        # ---- step-invariant conditioning
+        # ---- step-invariant conditioning (replicated on every rank: it is tiny)
         if use_face:
             flat_face = list(id_cond[:n_id]) + [t for i in range(n_id) for t in id_vit_hidden[i]]
             face_kv, router_k = self._cached("face", flat_face, lambda: self._face_invariants(id_cond, id_vit_hidden, B))
@@ -295,7 +300,7 @@ class DenoiseEngine:
         if routing_logits_forcing is not None and use_face:
             f_in = self._bf(routing_logits_forcing).reshape(T, per_frame, n_id)
             forced = ops.forcing_max_over_frames(f_in, buf("forced", 1, N, n_id).view(T, per_frame, n_id), T, per_frame,
-                                                 n_id).view(1, N, n_id)
+                                                 n_id).view(1, N, n_id)[:, v0:v1].contiguous()
 
         # ---- D0: timestep embedding and every AdaLN modulation vector of the step
         tfeat = ops.timestep_features(ts, buf("tfeat", B, D), cfg.flip_sin_to_cos, float(cfg.freq_shift))
@@ -306,23 +311,28 @@ class DenoiseEngine:
         mods = ops.linear_small_m(emb, self.mod_w, self.mod_b, buf("mods", B, self.mod_w.shape[0]), silu_in=True)
         mbs = mods.stride(0)
 
-        # ---- D1: patch embed into the joint stream x = [text | video]
-        x = buf("x", B, S, D)
-        xv = x[:, Tt:]
+        # ---- D1: patch embed into the joint stream x = [text | video] (this rank's rows only)
+        x = buf("x", B, S_loc, D)
+        xv = x[:, Tt_loc:]
         pe = self.pos_embedding
         if pe is not None and pe.shape[0] != S:
             raise ValueError("learned positional embeddings need the configured sample height/width/frames")
-        tp = m.patch_embed.text_proj
-        ops.gemm(enc_in, tp.weight, x[:, :Tt], bias=tp.bias, res=None if pe is None else pe[:Tt])
+        if Tt_loc:
+            tp = m.patch_embed.text_proj
+            ops.gemm(enc_in[:, sh.r0:sh.r0 + Tt_loc], tp.weight, x[:, :Tt_loc], bias=tp.bias,
+                     res=None if pe is None else pe[sh.r0:sh.r0 + Tt_loc])
         cols = ops.patchify(hs, buf("cols", B, N, C * 4))
-        ops.gemm(cols, self.patch_w, xv, bias=m.patch_embed.proj.bias, res=None if pe is None else pe[Tt:])
+        ops.gemm(cols[:, v0:v1], self.patch_w, xv, bias=m.patch_embed.proj.bias,
+                 res=None if pe is None else pe[Tt + v0:Tt + v1])
         if taps is not None:
             taps["emb"], taps["embed"] = emb.clone(), x.clone()
 
-        xn = buf("xn", B, S, D)
-        qkv = buf("qkv", 3, B, S, D)
+        xn = buf("xn", B, S_loc, D)
+        qkv = buf("qkv", 3, B, S_loc, D)
         q, k, v = qkv[0], qkv[1], qkv[2]
-        ff = buf("ff", B, S, 4 * D)
+        ff = buf("ff", B, S_loc, 4 * D)
+        if sh.world > 1:
+            k_full, v_full = buf("k_full", 1, S, D), buf("v_full", 1, S, D)
         r_logits = None
         for i, blk in enumerate(m.transformer_blocks):
             # ---- D2..D4: CogVideoXBlock (models/transformer.py:223-262)
@@ -330,19 +340,24 @@ class DenoiseEngine:
                 mo = mods[:, (2 * i + half) * 6 * D:]
                 # chunk order: shift, scale, gate, enc_shift, enc_scale, enc_gate
                 ops.layernorm(x, xn, nz.norm.weight, nz.norm.bias, eps=nz.norm.eps, shift0=mo[:, 3 * D:],
-                              scale0=mo[:, 4 * D:], shift1=mo, scale1=mo[:, D:], split=Tt, mod_batch_stride=mbs)
+                              scale0=mo[:, 4 * D:], shift1=mo, scale1=mo[:, D:], split=Tt_loc, mod_batch_stride=mbs)
                 if half == 0:
                     at = blk.attn1
-                    ops.gemm(xn, self.qkv_w[i], q, bias=self.qkv_b[i], split=(D, B * S * D))
+                    ops.gemm(xn, self.qkv_w[i], q, bias=self.qkv_b[i], split=(D, B * S_loc * D))
                     ops.qknorm_rope(q, k, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
-                                    heads=H, text_rows=Tt if cos is not None else S, eps=at.norm_q.eps)
-                    ops.self_attention(q, k, v, xn, heads=H, tag="joint")
+                                    heads=H, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps)
+                    if sh.world > 1:      # exchange A: every rank needs all keys / values (RCCL all-gather over xGMI)
+                        sh.gather_rows(k[0], k_full[0])
+                        sh.gather_rows(v[0], v_full[0])
+                        ops.self_attention(q, k_full, v_full, xn, heads=H, tag="joint")
+                    else:
+                        ops.self_attention(q, k, v, xn, heads=H, tag="joint")
                     ops.gemm(xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
-                             gate1=mo[:, 2 * D:], gate_split=Tt, gate_batch_stride=mbs)
+                             gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                 else:
                     ops.gemm(xn, blk.ff.net[0].proj.weight, ff, bias=blk.ff.net[0].proj.bias, act="gelu_tanh")
                     ops.gemm(ff, blk.ff.net[2].weight, x, bias=blk.ff.net[2].bias, res=x, gate0=mo[:, 5 * D:],
-                             gate1=mo[:, 2 * D:], gate_split=Tt, gate_batch_stride=mbs)
+                             gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
             if taps is not None:
                 taps[f"block{i}"] = x.clone()
 
@@ -352,21 +367,21 @@ class DenoiseEngine:
                 pc = m.perceiver_cross_attention[ca]
                 inner_p = pc.to_q.weight.shape[0]
                 hd_p = inner_p // 16
-                lat = buf("lat", B, N, D)
+                lat = buf("lat", B, N_loc, D)
                 ops.layernorm(xv, lat, pc.norm2.weight, pc.norm2.bias, eps=pc.norm2.eps)
-                qp = ops.gemm(lat, pc.to_q.weight, buf("qp", B, N, inner_p))
+                qp = ops.gemm(lat, pc.to_q.weight, buf("qp", B, N_loc, inner_p))
                 kv_l = face_kv[ca]
                 ntok = kv_l.shape[2]
-                pout = buf("pout", B, n_id, N, inner_p)
-                ops.attention(qp, kv_l, kv_l[..., inner_p:], pout, head_dim=hd_p, heads=16, nb1=B, nb2=n_id, Sq=N,
-                              Skv=ntok, q_strides=(N * inner_p, 0, inner_p),
+                pout = buf("pout", B, n_id, N_loc, inner_p)
+                ops.attention(qp, kv_l, kv_l[..., inner_p:], pout, head_dim=hd_p, heads=16, nb1=B, nb2=n_id, Sq=N_loc,
+                              Skv=ntok, q_strides=(N_loc * inner_p, 0, inner_p),
                               k_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
                               v_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
-                              o_strides=(n_id * N * inner_p, N * inner_p, inner_p), scale=hd_p ** -0.5)
-                feat = buf("feat", B, n_id, N, D)
-                ops.gemm(pout.view(B * n_id, N, inner_p), pc.to_out.weight, feat.view(B * n_id, N, D))
+                              o_strides=(n_id * N_loc * inner_p, N_loc * inner_p, inner_p), scale=hd_p ** -0.5)
+                feat = buf("feat", B, n_id, N_loc, D)
+                ops.gemm(pout.view(B * n_id, N_loc, inner_p), pc.to_out.weight, feat.view(B * n_id, N_loc, D))
                 if forced is None:
-                    r_logits = self._router(qp, router_k[ca], ca, B, T, per_frame, taps)
+                    r_logits = self._router(qp, router_k[ca], ca, B, T, per_frame, sh, taps)
                 else:
                     r_logits = forced
                 if taps is not None:
@@ -379,51 +394,63 @@ class DenoiseEngine:
             if use_audio and i % m.audio_attn_interval == 0:
                 al = m.audio_model.layers[i // m.audio_attn_interval]
                 at = al["attn"]
-                an = buf("lat", B, N, D)
+                an = buf("lat", B, N_loc, D)
                 ops.layernorm(xv, an, al["norm_q"].weight, al["norm_q"].bias, eps=al["norm_q"].eps)
-                qa = ops.gemm(an, at.to_q.weight, buf("qa", B, N, D), bias=at.to_q.bias)
+                qa = ops.gemm(an, at.to_q.weight, buf("qa", B, N_loc, D), bias=at.to_q.bias)
                 ka, va = audio_k[i // m.audio_attn_interval], audio_v[i // m.audio_attn_interval]
                 ntok = ka.shape[3]
-                ao = buf("ao", B, n_id, N, D)
+                ao = buf("ao", B, n_id, N_loc, D)
+                kvs = (T * ntok * D, ntok * D, D)
                 for b in range(B):      # (id, frame) batch of one sample; q rows shared by both ids
-                    ops.attention(qa[b], ka[b], va[b], ao[b], head_dim=64, heads=H, nb1=n_id, nb2=T, Sq=per_frame,
-                                  Skv=ntok, q_strides=(0, per_frame * D, D), k_strides=(T * ntok * D, ntok * D, D),
-                                  v_strides=(T * ntok * D, ntok * D, D), o_strides=(N * D, per_frame * D, D),
-                                  scale=64 ** -0.5)
-                feat = buf("feat", B, n_id, N, D)
-                ops.gemm(ao.view(B * n_id, N, D), at.to_out[0].weight, feat.view(B * n_id, N, D), bias=at.to_out[0].bias)
+                    if sh.world == 1:
+                        ops.attention(qa[b], ka[b], va[b], ao[b], head_dim=64, heads=H, nb1=n_id, nb2=T, Sq=per_frame,
+                                      Skv=ntok, q_strides=(0, per_frame * D, D), k_strides=kvs, v_strides=kvs,
+                                      o_strides=(N_loc * D, per_frame * D, D), scale=64 ** -0.5)
+                    else:               # shard boundaries cut frames: one launch per (partial) frame of this rank
+                        for f, start, length in sh.frame_segments(per_frame):
+                            ops.attention(qa[b, start:], ka[b, :, f], va[b, :, f], ao[b, :, start:], head_dim=64,
+                                          heads=H, nb1=n_id, nb2=1, Sq=length, Skv=ntok, q_strides=(0, 0, D),
+                                          k_strides=kvs, v_strides=kvs, o_strides=(N_loc * D, 0, D), scale=64 ** -0.5)
+                feat = buf("feat", B, n_id, N_loc, D)
+                ops.gemm(ao.view(B * n_id, N_loc, D), at.to_out[0].weight, feat.view(B * n_id, N_loc, D),
+                         bias=at.to_out[0].bias)
                 ops.masked_combine(xv, feat, r_logits, af, "audio")
                 if taps is not None:
                     taps[f"audio{i}"] = xv.clone()
 
         # ---- F1: final norm, AdaLN head, projection, unpatchify (models/transformer.py:938-957)
-        xf = buf("lat", B, N, D)
+        xf = buf("lat", B, N_loc, D)
         ops.layernorm(xv, xf, m.norm_final.weight, m.norm_final.bias, eps=m.norm_final.eps)
         mo = mods[:, 2 * self.L * 6 * D:]                      # AdaLayerNorm chunk_dim=1: (shift, scale)
-        xo = buf("qa", B, N, D)
+        xo = buf("qa", B, N_loc, D)
         ops.layernorm(xf, xo, m.norm_out.norm.weight, m.norm_out.norm.bias, eps=m.norm_out.norm.eps, shift0=mo,
                       scale0=mo[:, D:], shift1=mo, scale1=mo[:, D:], split=0, mod_batch_stride=mbs)
         co = m.proj_out.weight.shape[0]
-        y = ops.gemm(xo, m.proj_out.weight, buf("y", B, N, co), bias=m.proj_out.bias)
+        y = ops.gemm(xo, m.proj_out.weight, buf("y", B, N_loc, co), bias=m.proj_out.bias)
+        y = sh.gather_video_rows(y)                             # every rank returns the full latent prediction
         out = torch.empty(B, T, co // 4, Hh, Ww, dtype=torch.bfloat16, device=self.dev)
         ops.unpatchify(y, out)
         return out
 
-    def _router(self, qp, kr, ca, B, T, per_frame, taps):
+    def _router(self, qp, kr, ca, B, T, per_frame, sh, taps):
         """MultiIPRouter.forward (models/router.py:364-411) on the perceiver's q (shared by both ids) and the
-        pre-projected router keys.  Returns routing logits [B, N, n_id] (sigmoid)."""
+        pre-projected router keys.  Returns this rank's rows of the routing logits, [B, N_loc, n_id] (sigmoid)."""
         m, n_id, buf = self.m, self.N_ID, self._buf
         r = m.router
-        N = T * per_frame
+        N, N_loc = T * per_frame, sh.N_loc
         F = r.feat_dim
         qk = qp.shape[-1]
-        qn = buf("r_qn", B, N, qk)
+        qn = buf("r_qn", B, N_loc, qk)
         ops.layernorm(qp, qn, self.r_nq_w, self.r_nq_b, eps=r.norm_q.eps)
-        qr = ops.gemm(qn, self.r_to_q[ca], buf("r_qr", B, N, qk))
-        rs = buf("r_s", B, n_id, N, F)
+        qr = ops.gemm(qn, self.r_to_q[ca], buf("r_qr", B, N_loc, qk))
+        rs = buf("r_s_loc", B, n_id, N_loc, F)
+        pos = self.r_pos[sh.v0:sh.v1]
         for b in range(B):
-            ops.router_scores(qr[b], kr[b].contiguous(), r.norm.weight, r.norm.bias, self.r_pos, rs[b], n_id, N,
+            ops.router_scores(qr[b], kr[b].contiguous(), r.norm.weight, r.norm.bias, pos, rs[b], n_id, N_loc,
                               eps=r.norm.eps)
+        # exchange B: the spatial / temporal attentions mix tokens across the whole clip -> gather the 512-wide
+        # router rows (36 MB) and run the four small blocks replicated
+        rs = sh.gather_video_rows(rs)
         R = B * n_id * N
         rs2, rn = rs.view(R, F), buf("r_n", R, F)
         qkv, ra, rh = buf("r_qkv", R, 3 * F), buf("r_a", R, F), buf("r_h", R, F)
@@ -456,11 +483,12 @@ class DenoiseEngine:
             self._ln(rs2, rn, st.norm4)
             ops.gemm(rn, st.mlp[0].weight, rh, bias=st.mlp[0].bias, act="gelu_erf")
             ops.gemm(rh, st.mlp[2].weight, rs2, bias=st.mlp[2].bias, res=rs2)
-        logits = buf(f"r_logits", B, N, n_id)
+        logits = buf("r_logits", B, N, n_id)
         fp = r.final_proj[0]
+        rs4 = rs2.view(B, n_id, N, F)
         for b in range(B):
-            ops.router_head(rs[b], fp.weight, fp.bias, logits[b], n_id, N)
+            ops.router_head(rs4[b], fp.weight, fp.bias, logits[b], n_id, N)
         if taps is not None:
             for b in range(B):
                 taps[f"router{ca}_b{b}"] = logits[b:b + 1].clone()
-        return logits
+        return logits if sh.world == 1 else logits[:, sh.v0:sh.v1].contiguous()
