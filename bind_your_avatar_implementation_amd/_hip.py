@@ -16,7 +16,7 @@ class GemmDesc(_c.Structure):
                 ("lda", _i32), ("ldw", _i32), ("ldc", _i32), ("ldres", _i32),
                 ("a_batch_stride", _i64), ("c_batch_stride", _i64), ("res_batch_stride", _i64),
                 ("gate_batch_stride", _i64), ("gate_split", _i32), ("act", _i32),
-                ("n_split", _i32), ("c_split_stride", _i64)]
+                ("n_split", _i32), ("c_split_stride", _i64), ("bias_rowscale", _vp), ("alpha", _f32)]
 
 
 class AttnDesc(_c.Structure):
@@ -43,6 +43,7 @@ SIGNATURES = {
     "bya_router_head": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp],
     "bya_forcing_max_over_frames": [_vp, _vp, _i32, _i64, _i32, _vp],
     "bya_masked_combine": [_vp, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _i64, _i32, _i64, _i64, _i64, _vp],
+    "bya_routed_mix": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _i64, _vp],
     "bya_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "bya_unpatchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "bya_act_add": [_vp, _vp, _vp, _i64, _i32, _vp],

@@ -29,6 +29,8 @@ struct GemmArgs {
     float leaky;
     int n_split;            // > 0: output column n goes to C + (n / n_split) * c_split_stride, column n % n_split
     long long c_split_stride;
+    const float* bias_rowscale;   // optional fp32 [batch*M]: bias is multiplied by bias_rowscale[z*M + m]
+    float alpha;                  // scales (acc + bias) after the activation (local_face_scale)
 };
 
 constexpr int BK = 64;  // bf16 elements per K tile = 128-byte LDS rows
@@ -83,8 +85,9 @@ __device__ __forceinline__ void dispatch_act(int act, F&& f) {
 template <int ACT>
 __device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n4, const f32x4 acc, const float (&b4)[4]) {
     float v[4];
+    const float bs = p.bias_rowscale ? p.bias_rowscale[(long long)z * p.M + m] : 1.0f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(acc[e] + b4[e], p.leaky);
+    for (int e = 0; e < 4; ++e) v[e] = p.alpha * apply_act<ACT>(fmaf(bs, b4[e], acc[e]), p.leaky);
     if (p.gate0) {
         const bf16_t* g = (m < p.gate_split ? p.gate0 : p.gate1) + (long long)z * p.gate_bs + n4;
         const u32x2 gv = *reinterpret_cast<const u32x2*>(g);
@@ -458,6 +461,7 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
     a.a_bs = d->a_batch_stride; a.c_bs = d->c_batch_stride; a.res_bs = d->res_batch_stride;
     a.gate_bs = d->gate_batch_stride; a.gate_split = d->gate_split; a.act = d->act; a.leaky = 0.01f;
     a.n_split = d->n_split; a.c_split_stride = d->c_split_stride;
+    a.bias_rowscale = d->bias_rowscale; a.alpha = d->alpha == 0.0f ? 1.0f : d->alpha;
     if (d->n_split < 0 || (d->n_split > 0 && (d->n_split % 4 || d->c_split_stride % 4 || res))) return BYA_ERR_SHAPE;
     static const int forced = [] { const char* e = getenv("BYA_GEMM_TILE"); return e ? atoi(e) : -1; }();
     switch (pick_tile(d->M, d->N, d->batch, forced)) {

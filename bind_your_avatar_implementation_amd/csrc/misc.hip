@@ -115,6 +115,48 @@ __global__ __launch_bounds__(256) void masked_combine_kernel(CombArgs p) {
     *reinterpret_cast<u32x4*>(xp) = pack8(xv);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Routed sum BEFORE the output projection (linearity of to_out):
+//   sum_id w[n,id] * (o[id,n,:] @ W^T + b)  ==  (sum_id w[n,id] * o[id,n,:]) @ W^T + (sum_id w[n,id]) * b
+// so the engine mixes the two per-identity attention outputs first and runs ONE half-size GEMM whose epilogue adds
+// rowscale[n] * bias and the residual.  Weights are derived exactly as in masked_combine (mode 0 face / 1 audio).
+__global__ __launch_bounds__(256) void routed_mix_kernel(CombArgs p, bf16_t* __restrict__ z, float* __restrict__ wsum) {
+    const int vec_per_row = p.D / 8;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.batch * p.N * vec_per_row;
+    if (gid >= total) return;
+    const int c8 = (int)(gid % vec_per_row);
+    const long long bn = gid / vec_per_row;
+    const long long n = bn % p.N;
+    const int b = (int)(bn / p.N);
+    const bf16_t* r = p.r + b * p.r_bs + n * p.n_id;
+    float w[4];
+    if (p.mode == 0) {
+        for (int i = 0; i < p.n_id; ++i) w[i] = bf2f(r[i]);
+    } else {
+        const bf16_t* af = p.af + b * 4;
+        const float r0 = bf2f(r[0]), r1 = bf2f(r[1]);
+        const float av0 = bf2f(f2bf(bf2f(af[0]) * r0 + bf2f(af[1]) * r1));
+        const float av1 = bf2f(f2bf(bf2f(af[2]) * r0 + bf2f(af[3]) * r1));
+        w[0] = bf2f(f2bf(1.0f - av1));
+        w[1] = bf2f(f2bf(1.0f - av0));
+    }
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    float ws = 0.f;
+    for (int i = 0; i < p.n_id; ++i) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(p.feat + (((long long)b * p.n_id + i) * p.N + n) * p.D + c8 * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(w[i], f[e], acc[e]);
+        ws += w[i];
+    }
+    *reinterpret_cast<u32x4*>(z + ((long long)b * p.N + n) * p.D + c8 * 8) = pack8(acc);
+    if (c8 == 0 && wsum) wsum[(long long)b * p.N + n] = ws;
+}
+
 __global__ void forcing_max_kernel(const bf16_t* __restrict__ f, bf16_t* __restrict__ out, int frames,
                                    long long per_frame, int n_id) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (r, id)
@@ -241,6 +283,23 @@ extern "C" int bya_masked_combine(void* x, const void* feat, const void* r, cons
     a.r_bs = r_batch_stride; a.alpha = alpha;
     const long long total = (long long)batch * N * (D / 8);
     BYA_LAUNCH(masked_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    return ok();
+}
+
+extern "C" int bya_routed_mix(const void* feat, const void* r, const void* af, void* z, float* wsum, int32_t mode,
+                              int32_t batch, int32_t n_id, int64_t N, int32_t D, int64_t r_batch_stride,
+                              hipStream_t stream) {
+    if (!feat || !r || !z || batch <= 0 || N <= 0 || D <= 0) return BYA_ERR_SHAPE;
+    if (mode != 0 && mode != 1) return BYA_ERR_UNSUPPORTED;
+    if (n_id < 1 || n_id > 4 || (mode == 1 && (n_id != 2 || !af))) return BYA_ERR_UNSUPPORTED;
+    if (D % 8) return BYA_ERR_ALIGN;
+    if (((uintptr_t)z | (uintptr_t)feat) & 15) return BYA_ERR_ALIGN;
+    CombArgs a;
+    a.x = nullptr; a.feat = (const bf16_t*)feat; a.r = (const bf16_t*)r; a.af = (const bf16_t*)af;
+    a.mode = mode; a.batch = batch; a.n_id = n_id; a.D = D; a.N = N; a.x_row = 0; a.x_bs = 0;
+    a.r_bs = r_batch_stride; a.alpha = 1.0f;
+    const long long total = (long long)batch * N * (D / 8);
+    BYA_LAUNCH(routed_mix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, (bf16_t*)z, wsum);
     return ok();
 }
 

@@ -18,6 +18,8 @@ One ``DenoiseEngine.step`` == one reference ``BindyouravatarTransformer3DModel.f
 
 Nothing here falls back to torch math: torch is used for device memory, views and copies only.
 """
+import os
+
 import torch
 
 from . import ops
@@ -47,6 +49,9 @@ class DenoiseEngine:
         self.L = len(model.transformer_blocks)
         self.Tt_max = self.cfg.max_text_seq_length
         self.cache_invariants = False
+        # route-then-project (exact by linearity of to_out; halves those GEMMs and drops the [2,N,D] round trip).
+        # False = the reference's order of operations (project each identity, then combine).
+        self.mix_before_projection = os.environ.get("BYA_MIX_BEFORE_PROJECTION", "1") != "0"
         self._inv_cache = {}
         self._ws_key, self._ws = None, None
         if model.is_train_audio and not model.is_train_face:
@@ -378,15 +383,20 @@ class DenoiseEngine:
                               k_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
                               v_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
                               o_strides=(n_id * N_loc * inner_p, N_loc * inner_p, inner_p), scale=hd_p ** -0.5)
-                feat = buf("feat", B, n_id, N_loc, D)
-                ops.gemm(pout.view(B * n_id, N_loc, inner_p), pc.to_out.weight, feat.view(B * n_id, N_loc, D))
                 if forced is None:
                     r_logits = self._router(qp, router_k[ca], ca, B, T, per_frame, sh, taps)
                 else:
                     r_logits = forced
-                if taps is not None:
-                    taps[f"id_feat{ca}"] = feat[0].clone()
-                ops.masked_combine(xv, feat, r_logits, None, "face", alpha=m.local_face_scale)
+                if self.mix_before_projection:
+                    # to_out is linear and bias-free: route first, project once (half the GEMM, no feat round trip)
+                    z = ops.routed_mix(pout, r_logits, None, "face", buf("zmix_p", B, N_loc, inner_p))
+                    ops.gemm(z, pc.to_out.weight, xv, res=xv, alpha=m.local_face_scale)
+                else:
+                    feat = buf("feat", B, n_id, N_loc, D)
+                    ops.gemm(pout.view(B * n_id, N_loc, inner_p), pc.to_out.weight, feat.view(B * n_id, N_loc, D))
+                    if taps is not None:
+                        taps[f"id_feat{ca}"] = feat[0].clone()
+                    ops.masked_combine(xv, feat, r_logits, None, "face", alpha=m.local_face_scale)
                 if taps is not None:
                     taps[f"face{i}"] = xv.clone()
 
@@ -411,10 +421,17 @@ class DenoiseEngine:
                             ops.attention(qa[b, start:], ka[b, :, f], va[b, :, f], ao[b, :, start:], head_dim=64,
                                           heads=H, nb1=n_id, nb2=1, Sq=length, Skv=ntok, q_strides=(0, 0, D),
                                           k_strides=kvs, v_strides=kvs, o_strides=(N_loc * D, 0, D), scale=64 ** -0.5)
-                feat = buf("feat", B, n_id, N_loc, D)
-                ops.gemm(ao.view(B * n_id, N_loc, D), at.to_out[0].weight, feat.view(B * n_id, N_loc, D),
-                         bias=at.to_out[0].bias)
-                ops.masked_combine(xv, feat, r_logits, af, "audio")
+                if self.mix_before_projection:
+                    wsum = self._ws.get("wsum")
+                    if wsum is None or wsum.numel() != B * N_loc:
+                        wsum = self._ws["wsum"] = torch.empty(B, N_loc, dtype=torch.float32, device=self.dev)
+                    z = ops.routed_mix(ao, r_logits, af, "audio", buf("zmix_a", B, N_loc, D), wsum)
+                    ops.gemm(z, at.to_out[0].weight, xv, bias=at.to_out[0].bias, res=xv, bias_rowscale=wsum)
+                else:
+                    feat = buf("feat", B, n_id, N_loc, D)
+                    ops.gemm(ao.view(B * n_id, N_loc, D), at.to_out[0].weight, feat.view(B * n_id, N_loc, D),
+                             bias=at.to_out[0].bias)
+                    ops.masked_combine(xv, feat, r_logits, af, "audio")
                 if taps is not None:
                     taps[f"audio{i}"] = xv.clone()
 

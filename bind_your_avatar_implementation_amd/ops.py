@@ -78,7 +78,7 @@ def _mat(t, name):
 
 
 def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, gate_batch_stride=0, act=None,
-         split=None):
+         split=None, bias_rowscale=None, alpha=1.0):
     """out = res + gate * act(a @ w.T + bias).  a: [(B,) M, K], w: [N, K], out/res: [(B,) M, N].
 
     ``split=(n_split, stride)``: ``out`` is the FIRST of N/n_split equally shaped tensors ``stride`` elements apart;
@@ -104,6 +104,9 @@ def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, g
         d.ldres, d.res_batch_stride = ldres, (r_bs if rb == ab else 0)
     d.gate_batch_stride, d.gate_split, d.act = gate_batch_stride, gate_split, ACT[act]
     d.n_split, d.c_split_stride = (0, 0) if split is None else split
+    d.bias_rowscale, d.alpha = _p(bias_rowscale), float(alpha)
+    if bias_rowscale is not None:
+        assert bias_rowscale.dtype == torch.float32 and bias_rowscale.is_contiguous() and bias_rowscale.numel() == ab * M
     tok = _begin("bya_gemm_bf16", 2.0 * ab * M * N * K)
     check(lib.bya_gemm_bf16(_p(a), _p(w), _p(bias), _p(out), _p(res), _p(gate0), _p(gate1), ctypes.byref(d),
                             _stream()), "bya_gemm_bf16")
@@ -250,6 +253,22 @@ def masked_combine(x, feat, r, af, mode, alpha=1.0):
                                  n_id, N, D, x_row, x_bs, r_bs, _stream()), "bya_masked_combine")
     _end(tok)
     return x
+
+
+def routed_mix(feat, r, af, mode, z, wsum=None):
+    """z [B, N, D] = sum_id w[b,n,id] * feat [B, n_id, N, D]; wsum [B, N] fp32 = sum_id w (optional)."""
+    lib = _hip.load()
+    b, n_id, N, D = feat.shape
+    assert feat.is_contiguous() and z.is_contiguous() and z.shape == (b, N, D)
+    assert r.is_contiguous() and r.shape[-2:] == (N, n_id) and r.dtype == torch.bfloat16
+    r_bs = 0 if r.shape[0] == 1 else N * n_id
+    if wsum is not None:
+        assert wsum.dtype == torch.float32 and wsum.is_contiguous() and wsum.numel() == b * N
+    tok = _begin("bya_routed_mix")
+    check(lib.bya_routed_mix(_p(feat), _p(r), _p(af), _p(z), _p(wsum), {"face": 0, "audio": 1}[mode], b, n_id, N, D,
+                             r_bs, _stream()), "bya_routed_mix")
+    _end(tok)
+    return z
 
 
 def patchify(x, cols):

@@ -35,7 +35,7 @@ enum { BYA_ACT_NONE = 0, BYA_ACT_GELU_TANH = 1, BYA_ACT_GELU_ERF = 2, BYA_ACT_RE
 int bya_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
- * GEMM:  C[z][m,n] = res[z][m,n] + gate[z][row-type(m)][n] * act( sum_k A[z][m,k] * W[n,k] + bias[n] )
+ * GEMM:  C[z][m,n] = res[z][m,n] + gate[z][row-type(m)][n] * alpha * act( sum_k A[z][m,k] * W[n,k] + rowscale[m]*bias[n] )
  * Replaces every nn.Linear / 2x2-stride Conv2d-as-GEMM on the path: attn1.to_q/k/v/to_out,
  * ff.net.0.proj/ff.net.2 (models/transformer.py:241-260), perceiver to_q/to_out (models/router.py:253,275),
  * router to_q/to_k and the SpatialTemporalAttentionBlock projections + mlp (models/router.py:381-383,
@@ -55,6 +55,8 @@ typedef struct bya_gemm_desc {
     int32_t n_split;          /* > 0: column n is written to C + (n / n_split) * c_split_stride, column n % n_split
                                  (one launch for the packed q|k|v projection writing three separate tensors) */
     int64_t c_split_stride;
+    const float* bias_rowscale; /* optional fp32 [batch*M]: bias[n] is multiplied by bias_rowscale[z*M + m] */
+    float alpha;              /* scales act(acc + bias); 0 is read as 1 */
 } bya_gemm_desc;
 
 int bya_gemm_bf16(const void* A, const void* W, const void* bias, void* C, const void* res,
@@ -152,6 +154,13 @@ int bya_forcing_max_over_frames(const void* forcing, void* out, int32_t frames, 
 int bya_masked_combine(void* x, const void* feat, const void* r, const void* af, int32_t mode, float alpha,
                        int32_t batch, int32_t n_id, int64_t N, int32_t D, int64_t x_row, int64_t x_batch_stride,
                        int64_t r_batch_stride, hipStream_t stream);
+
+/* Routed mix BEFORE the output projection (to_out is linear, so sum_id w*(o_id W^T + b) = (sum_id w*o_id) W^T +
+ * (sum_id w) b): z[b,n,:] = sum_id w[b,n,id] * feat[b,id,n,:], wsum[b,n] = sum_id w (fp32, may be NULL); w derived from
+ * the routing logits exactly as in bya_masked_combine (mode 0 face, mode 1 audio).  The half-size GEMM that follows
+ * takes wsum as bias_rowscale and the hidden stream as residual. */
+int bya_routed_mix(const void* feat, const void* r, const void* af, void* z, float* wsum, int32_t mode, int32_t batch,
+                   int32_t n_id, int64_t N, int32_t D, int64_t r_batch_stride, hipStream_t stream);
 
 /* Patchify (im2col of the 2x2/stride-2 Conv2d of CogVideoXPatchEmbed, models/transformer.py:690):
  *   cols[b, (t*Ht+h)*Wt+w, c*4+ph*2+pw] = x[b,t,c,2h+ph,2w+pw]

@@ -355,6 +355,33 @@ def test_masked_combine(ops, dev, hard):
         assert torch.equal(x[:, :T], xbuf[:, :T])
 
 
+@pytest.mark.parametrize("mode", ["face", "audio"])
+def test_routed_mix_then_projection_equals_project_then_combine(ops, dev, mode):
+    """Route-then-project (engine default) against the reference order of operations
+    (models/transformer.py:821-832 / 925-936): equal up to bf16 rounding; exact row selection on hard masks."""
+    B, NID, N, Dp, D = 2, 2, 260, 256, 512
+    o = rnd((B, NID, N, Dp), dev, 130)
+    w_out, b_out = rnd((D, Dp), dev, 131, Dp ** -0.5), rnd((D,), dev, 132, 0.3)
+    x = rnd((B, N, D), dev, 133)
+    r = bf(torch.rand(B, N, NID, generator=torch.Generator().manual_seed(9))).to(dev)
+    r[:, :40] = (r[:, :40] > 0.5).to(torch.bfloat16)                      # some hard-routed tokens
+    af = bf(torch.stack([torch.eye(2), 1 - torch.eye(2)])).to(dev)
+    z = torch.empty(B, N, Dp, dtype=torch.bfloat16, device=dev)
+    wsum = torch.empty(B, N, dtype=torch.float32, device=dev)
+    ops.routed_mix(o, r, af if mode == "audio" else None, mode, z, wsum)
+    out = x.clone()
+    ops.gemm(z, w_out, out, bias=b_out, res=out, bias_rowscale=wsum, alpha=1.0)
+    if mode == "audio":
+        av = bf(af.float() @ r.float().transpose(-2, -1)).transpose(-2, -1)
+        wgt = bf(1 - av[:, :, [1, 0]].float()).float()
+    else:
+        wgt = r.float()
+    assert torch.allclose(wsum, wgt.sum(-1), atol=1e-6)
+    feat = o.float() @ w_out.float().T + b_out.float()                     # [B, NID, N, D]
+    ref = x.float() + torch.einsum("bni,bind->bnd", wgt, feat)
+    check(out, ref, tol=2e-3, what=f"routed mix {mode}")
+
+
 def test_patchify_unpatchify_exact(ops, dev):
     B, T, C, H, W = 2, 3, 48, 12, 20
     x = rnd((B, T, C, H, W), dev, 110)
