@@ -192,10 +192,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const int r = lane & 31, hf = lane >> 5;
 
     // block -> (bh, q-tile): blocks with equal (blockIdx % 8) share an XCD; give each XCD whole (batch, head)s.
+    // (when the (batch, head) count is not a multiple of 8 -- e.g. 6 heads per rank under head-parallel sharding --
+    // plain order: the q-tiles of one head spread over all XCDs, every CU stays busy)
     const int nbh = p.nb1 * p.nb2 * p.heads;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int bh = (j / p.nqt) * 8 + xcd;
-    const int qt = j % p.nqt;
+    int bh, qt;
+    if (nbh % 8 == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bh = (j / p.nqt) * 8 + xcd;
+        qt = j % p.nqt;
+    } else {
+        bh = blockIdx.x / p.nqt;
+        qt = blockIdx.x % p.nqt;
+    }
     if (bh >= nbh) return;
     const int head = bh % p.heads;
     const int b12 = bh / p.heads;
@@ -284,8 +292,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     const int nbh = a.nb1 * a.nb2 * a.heads;
-    const int groups = (nbh + 7) / 8;
-    dim3 grid(groups * 8 * a.nqt);
+    dim3 grid(nbh * a.nqt);
     const size_t lds = 4 * KV_TILE * D * 2;
     BYA_LAUNCH((attn_fwd_kernel<D>), grid, dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;

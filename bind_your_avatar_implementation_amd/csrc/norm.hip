@@ -113,17 +113,16 @@ struct QkArgs {
 };
 
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
+    // one 8-lane group per (row, head) pair, pairs enumerated row-major over all batches: any head count works
     const int lane = threadIdx.x & 63;
-    const int hgroups = p.heads / 8;                 // waves per (row, tensor)
-    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long total = (long long)p.batch * p.S * hgroups * 2;
-    if (wid >= total) return;
-    const int which = (int)(wid % 2);                // 0 = q, 1 = k
-    long long rest = wid / 2;
-    const int hg = (int)(rest % hgroups); rest /= hgroups;
+    const long long pairs_per_tensor = (long long)p.batch * p.S * p.heads;
+    const long long pair = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+    if (pair >= 2 * pairs_per_tensor) return;
+    const int which = pair >= pairs_per_tensor;      // 0 = q, 1 = k
+    long long rest = pair - which * pairs_per_tensor;
+    const int head = (int)(rest % p.heads); rest /= p.heads;
     const int s = (int)(rest % p.S);
     const int z = (int)(rest / p.S);
-    const int head = hg * 8 + (lane >> 3);
     const int d0 = (lane & 7) * 8;
     bf16_t* base = (which ? p.k : p.q) + z * p.bs + (long long)s * p.ld + head * 64 + d0;
     const bf16_t* w = (which ? p.kw : p.qw) + d0;
@@ -196,7 +195,6 @@ extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb,
                                const float* cos, const float* sin, int32_t batch, int32_t S, int32_t heads,
                                int64_t ld, int64_t batch_stride, int32_t text_rows, float eps, hipStream_t stream) {
     if (!q || !k || !qw || !qb || !kw || !kb || batch <= 0 || S <= 0 || heads <= 0) return BYA_ERR_SHAPE;
-    if (heads % 8) return BYA_ERR_UNSUPPORTED;
     if (text_rows < S && (!cos || !sin)) return BYA_ERR_SHAPE;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)qw | (uintptr_t)kw |
          (uintptr_t)qb | (uintptr_t)kb) & 15) return BYA_ERR_ALIGN;
@@ -205,7 +203,7 @@ extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb,
     a.q = (bf16_t*)q; a.k = (bf16_t*)k; a.qw = (const bf16_t*)qw; a.qb = (const bf16_t*)qb;
     a.kw = (const bf16_t*)kw; a.kb = (const bf16_t*)kb; a.cos = cos; a.sin = sin;
     a.batch = batch; a.S = S; a.heads = heads; a.text_rows = text_rows; a.ld = ld; a.bs = batch_stride; a.eps = eps;
-    const long long total = (long long)batch * S * (heads / 8) * 2;
+    const long long total = ((long long)batch * S * heads * 2 + 7) / 8;      // waves: 8 (row, head) pairs each
     dim3 grid((unsigned)((total + 3) / 4));
     BYA_LAUNCH(qknorm_rope_kernel, grid, dim3(256), 0, stream, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;

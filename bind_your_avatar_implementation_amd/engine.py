@@ -23,7 +23,7 @@ import os
 import torch
 
 from . import ops
-from .parallel import SeqShard
+from .parallel import RouterPartition, SeqShard
 
 
 def _key(tensors):
@@ -336,7 +336,14 @@ class DenoiseEngine:
         qkv = buf("qkv", 3, B, S_loc, D)
         q, k, v = qkv[0], qkv[1], qkv[2]
         ff = buf("ff", B, S_loc, 4 * D)
-        if sh.world > 1:
+        head_parallel = sh.world > 1 and H % sh.world == 0 and os.environ.get("BYA_SP_ALLGATHER", "0") != "1"
+        if head_parallel:
+            W = sh.world
+            Dl = D // W
+            qkvb = buf("qkv_blocks", 3 * W, S_loc, Dl)         # column block t*W + j: tensor t (q,k,v), heads of rank j
+            qh, kh, vh = buf("q_heads", S, Dl), buf("k_heads", S, Dl), buf("v_heads", S, Dl)
+            oh = buf("o_heads", S, Dl)
+        elif sh.world > 1:
             k_full, v_full = buf("k_full", 1, S, D), buf("v_full", 1, S, D)
         r_logits = None
         for i, blk in enumerate(m.transformer_blocks):
@@ -348,10 +355,25 @@ class DenoiseEngine:
                               scale0=mo[:, 4 * D:], shift1=mo, scale1=mo[:, D:], split=Tt_loc, mod_batch_stride=mbs)
                 if half == 0:
                     at = blk.attn1
+                    if head_parallel:
+                        # exchange A, head-parallel: the projection writes per-destination column blocks, q/k-norm +
+                        # RoPE run on the local rows, then rows are traded for heads (every element moves once)
+                        ops.gemm(xn[0], self.qkv_w[i], qkvb[0], bias=self.qkv_b[i], split=(Dl, S_loc * Dl))
+                        ops.qknorm_rope(qkvb[:W], qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
+                                        at.norm_k.bias, cos, sin, heads=H // W,
+                                        text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps)
+                        sh.rows_to_heads(qkvb[:W], qh)
+                        sh.rows_to_heads(qkvb[W:2 * W], kh)
+                        sh.rows_to_heads(qkvb[2 * W:], vh)
+                        ops.self_attention(qh[None], kh[None], vh[None], oh[None], heads=H // W, tag="joint")
+                        sh.heads_to_rows(oh, xn[0])
+                        ops.gemm(xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
+                                 gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
+                        continue
                     ops.gemm(xn, self.qkv_w[i], q, bias=self.qkv_b[i], split=(D, B * S_loc * D))
                     ops.qknorm_rope(q, k, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
                                     heads=H, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps)
-                    if sh.world > 1:      # exchange A: every rank needs all keys / values (RCCL all-gather over xGMI)
+                    if sh.world > 1:      # exchange A (fallback when heads % world != 0): all-gather K and V
                         sh.gather_rows(k[0], k_full[0])
                         sh.gather_rows(v[0], v_full[0])
                         ops.self_attention(q, k_full, v_full, xn, heads=H, tag="joint")
@@ -457,6 +479,9 @@ class DenoiseEngine:
         N, N_loc = T * per_frame, sh.N_loc
         F = r.feat_dim
         qk = qp.shape[-1]
+        if sh.world > 1 and n_id * T >= sh.world and per_frame >= sh.world and \
+                os.environ.get("BYA_ROUTER_REPLICATED", "0") != "1":
+            return self._router_sharded(qp, kr, ca, T, per_frame, sh, taps)
         qn = buf("r_qn", B, N_loc, qk)
         ops.layernorm(qp, qn, self.r_nq_w, self.r_nq_b, eps=r.norm_q.eps)
         qr = ops.gemm(qn, self.r_to_q[ca], buf("r_qr", B, N_loc, qk))
@@ -509,3 +534,69 @@ class DenoiseEngine:
             for b in range(B):
                 taps[f"router{ca}_b{b}"] = logits[b:b + 1].clone()
         return logits if sh.world == 1 else logits[:, sh.v0:sh.v1].contiguous()
+
+    def _router_sharded(self, qp, kr, ca, T, per_frame, sh, taps):
+        """Multi-GPU form of ``_router`` (B = 1): the four SpatialTemporalAttentionBlocks run SHARDED.  Spatial attention in
+        the frame-major partition (whole (id, frame) pairs per rank), everything else in the location-major partition
+        (a range of within-frame locations for all frames and ids per rank), one all-to-all between them
+        (parallel.RouterPartition); the sigmoid logits (70 KB) are all-gathered at the end."""
+        m, n_id, buf = self.m, self.N_ID, self._buf
+        r = m.router
+        N, N_loc, F = T * per_frame, sh.N_loc, r.feat_dim
+        pairs = n_id * T
+        rp = RouterPartition(sh.rank, sh.world, pairs, per_frame, sh.group)
+        qk = qp.shape[-1]
+        qn = buf("r_qn", 1, N_loc, qk)
+        ops.layernorm(qp, qn, self.r_nq_w, self.r_nq_b, eps=r.norm_q.eps)
+        qr = ops.gemm(qn, self.r_to_q[ca], buf("r_qr", 1, N_loc, qk))
+        rs_loc = buf("r_s_loc", 1, n_id, N_loc, F)
+        ops.router_scores(qr[0], kr[0].contiguous(), r.norm.weight, r.norm.bias, self.r_pos[sh.v0:sh.v1], rs_loc[0],
+                          n_id, N_loc, eps=r.norm.eps)
+        rs_full = sh.gather_video_rows(rs_loc)                                # token ranges -> everyone (36 MB, once)
+        xa = buf("rp_xa", rp.nPA, per_frame, F)
+        xa.copy_(rs_full.view(pairs, per_frame, F)[rp.pa0:rp.pa1])
+        RA, RB = rp.nPA * per_frame, pairs * rp.nLB
+        rn_a, qkv_a, ra_a = buf("rp_rn_a", RA, F), buf("rp_qkv_a", RA, 3 * F), buf("rp_ra_a", RA, F)
+        xb = buf("rp_xb", pairs, rp.nLB, F)
+        rn_b, qkv_b, ra_b, rh_b = buf("rp_rn_b", RB, F), buf("rp_qkv_b", RB, 3 * F), buf("rp_ra_b", RB, F), buf("rp_rh_b", RB, F)
+        hd = 64
+        heads = F // hd
+        nblk = len(r.spatial_temporal_layers)
+        for bi, (st, pk) in enumerate(zip(r.spatial_temporal_layers, self.r_qkv)):
+            # ---- frame-major: spatial attention over the per_frame tokens of each local (id, frame) pair
+            xa2 = xa.view(RA, F)
+            self._ln(xa2, rn_a, st.norm1)
+            ops.gemm(rn_a, pk["spatial_attn"][0], qkv_a, bias=pk["spatial_attn"][1])
+            ops.attention(qkv_a, qkv_a[:, F:], qkv_a[:, 2 * F:], ra_a, head_dim=hd, heads=heads, nb1=rp.nPA, nb2=1,
+                          Sq=per_frame, Skv=per_frame, q_strides=(per_frame * 3 * F, 0, 3 * F),
+                          k_strides=(per_frame * 3 * F, 0, 3 * F), v_strides=(per_frame * 3 * F, 0, 3 * F),
+                          o_strides=(per_frame * F, 0, F), scale=hd ** -0.5)
+            o = st.spatial_attn.to_out[0]
+            ops.gemm(ra_a, o.weight, xa2, bias=o.bias, res=xa2)
+            # ---- location-major: temporal, multi-ID, MLP
+            rp.a_to_b(xa, xb)
+            xb2 = xb.view(RB, F)
+            self._ln(xb2, rn_b, st.norm2)
+            ops.gemm(rn_b, pk["temporal_attn"][0], qkv_b, bias=pk["temporal_attn"][1])
+            ops.attn_tiny(qkv_b, qkv_b[:, F:], qkv_b[:, 2 * F:], ra_b, T, heads, n_id, rp.nLB, T * rp.nLB, rp.nLB,
+                          3 * F, F, hd ** -0.5)
+            o = st.temporal_attn.to_out[0]
+            ops.gemm(ra_b, o.weight, xb2, bias=o.bias, res=xb2)
+            self._ln(xb2, rn_b, st.norm3)
+            ops.gemm(rn_b, pk["multi_id_attn"][0], qkv_b, bias=pk["multi_id_attn"][1])
+            ops.attn_tiny(qkv_b, qkv_b[:, F:], qkv_b[:, 2 * F:], ra_b, n_id, heads, 1, T * rp.nLB, 0, T * rp.nLB, 3 * F, F,
+                          hd ** -0.5)
+            o = st.multi_id_attn.to_out[0]
+            ops.gemm(ra_b, o.weight, xb2, bias=o.bias, res=xb2)
+            self._ln(xb2, rn_b, st.norm4)
+            ops.gemm(rn_b, st.mlp[0].weight, rh_b, bias=st.mlp[0].bias, act="gelu_erf")
+            ops.gemm(rh_b, st.mlp[2].weight, xb2, bias=st.mlp[2].bias, res=xb2)
+            if bi + 1 < nblk:
+                rp.b_to_a(xb, xa)
+        fp = r.final_proj[0]
+        lb = buf("rp_logits_b", T * rp.nLB, n_id)
+        ops.router_head(xb.view(n_id, T * rp.nLB, F), fp.weight, fp.bias, lb, n_id, T * rp.nLB)
+        logits = rp.gather_b_rows(lb.view(T, rp.nLB, n_id)).view(1, N, n_id)
+        if taps is not None:
+            taps[f"router{ca}_b0"] = logits.clone()
+        return logits[:, sh.v0:sh.v1].contiguous()

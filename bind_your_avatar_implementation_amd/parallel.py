@@ -80,6 +80,37 @@ class SeqShard:
         full = full.view(self.world, C, self.S_loc, F).permute(1, 0, 2, 3).reshape(C, self.S, F)[:, self.Tt:]
         return full.reshape(*lead, self.N, F).contiguous()
 
+    # ---- head-parallel ("Ulysses") exchange for the joint self-attention ---------------------------------------
+    # All-gathering K and V replicates 2*S*D elements onto every rank (191 MB received per rank and layer at 8 GPUs);
+    # trading rows for heads moves every element of q, k, v (and of the output) exactly once: 48 MB per rank and layer.
+    def _a2a_equal(self, out, inp):
+        if inp.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(host, inp.cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_to_all_single(out, inp, group=self.group)
+
+    def rows_to_heads(self, blocks, out=None):
+        """blocks [world, S_loc, Dl]: this rank's rows, column block j = the heads owned by rank j
+        -> [S, Dl]: ALL rows (global order) of this rank's heads."""
+        W, S_loc, Dl = blocks.shape
+        if out is None:
+            out = torch.empty(W * S_loc, Dl, dtype=blocks.dtype, device=blocks.device)
+        self._a2a_equal(out.view(-1), blocks.reshape(-1))
+        return out
+
+    def heads_to_rows(self, o_heads, out=None):
+        """o_heads [S, Dl] (all rows, this rank's heads) -> [S_loc, world*Dl] (this rank's rows, all heads)."""
+        S, Dl = o_heads.shape
+        recv = torch.empty(self.world, self.S_loc, Dl, dtype=o_heads.dtype, device=o_heads.device)
+        self._a2a_equal(recv.view(-1), o_heads.reshape(-1))
+        res = recv.permute(1, 0, 2).reshape(self.S_loc, self.world * Dl)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res.contiguous()
+
     def frame_segments(self, per_frame):
         """Local video rows split at frame boundaries: [(frame, local_start, length)]."""
         out, v = [], self.v0
@@ -89,6 +120,90 @@ class SeqShard:
             out.append((f, v - self.v0, end - v))
             v = end
         return out
+
+
+def _splits(n, parts):
+    """Contiguous split of range(n) into ``parts`` pieces whose sizes differ by at most one: [(start, stop)]."""
+    base, extra = divmod(n, parts)
+    out, a = [], 0
+    for i in range(parts):
+        b = a + base + (1 if i < extra else 0)
+        out.append((a, b))
+        a = b
+    return out
+
+
+class RouterPartition:
+    """Two partitions of the router feature tensor ``[n_id*T pairs, per_frame locations, F]`` and the all-to-all
+    between them (exchange B of DESIGN.md section 5, sharded form).
+
+    * partition A ("frame-major"): a rank owns whole (id, frame) pairs -> the spatial attention is local;
+      local layout ``xa [nPA, per_frame, F]``.
+    * partition B ("location-major"): a rank owns a range of within-frame locations for every pair -> the temporal
+      and multi-ID attentions, every LayerNorm / GEMM / MLP and the sigmoid head are local; layout ``xb [pairs, nLB, F]``.
+
+    An element moves once per exchange (all-to-all), 36 MB in total across the node instead of 36 MB *per rank* for an
+    all-gather.  A -> B packs on the send side (W slice copies) and receives in place; B -> A sends in place and
+    unpacks on the receive side."""
+
+    def __init__(self, rank, world, pairs, per_frame, group=None):
+        self.rank, self.world, self.pairs, self.per_frame, self.group = rank, world, pairs, per_frame, group
+        self.PA = _splits(pairs, world)
+        self.LB = _splits(per_frame, world)
+        self.pa0, self.pa1 = self.PA[rank]
+        self.lb0, self.lb1 = self.LB[rank]
+        self.nPA, self.nLB = self.pa1 - self.pa0, self.lb1 - self.lb0
+
+    def _a2a(self, out, inp, out_splits, in_splits):
+        if inp.is_cuda and dist.get_backend(self.group) == "gloo":      # single-GPU functional test path
+            host_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(host_out, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(host_out)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def a_to_b(self, xa, xb=None):
+        """xa [nPA, per_frame, F] -> xb [pairs, nLB, F]."""
+        F = xa.shape[-1]
+        send = torch.cat([xa[:, a:b].reshape(-1) for a, b in self.LB])
+        if xb is None:
+            xb = torch.empty(self.pairs, self.nLB, F, dtype=xa.dtype, device=xa.device)
+        in_splits = [self.nPA * (b - a) * F for a, b in self.LB]
+        out_splits = [(b - a) * self.nLB * F for a, b in self.PA]
+        self._a2a(xb.view(-1), send, out_splits, in_splits)
+        return xb
+
+    def b_to_a(self, xb, xa=None):
+        """xb [pairs, nLB, F] -> xa [nPA, per_frame, F]."""
+        F = xb.shape[-1]
+        if xa is None:
+            xa = torch.empty(self.nPA, self.per_frame, F, dtype=xb.dtype, device=xb.device)
+        in_splits = [(b - a) * self.nLB * F for a, b in self.PA]
+        out_splits = [self.nPA * (b - a) * F for a, b in self.LB]
+        recv = torch.empty(sum(out_splits), dtype=xb.dtype, device=xb.device)
+        self._a2a(recv, xb.reshape(-1), out_splits, in_splits)
+        off = 0
+        for a, b in self.LB:
+            n = self.nPA * (b - a) * F
+            xa[:, a:b] = recv[off:off + n].view(self.nPA, b - a, F)
+            off += n
+        return xa
+
+    def gather_b_rows(self, yb):
+        """yb [T_or_pairs, nLB, C] per rank (location-major) -> [T_or_pairs, per_frame, C] on every rank."""
+        lead, C = yb.shape[0], yb.shape[-1]
+        nmax = max(b - a for a, b in self.LB)
+        pad = torch.zeros(lead, nmax, C, dtype=yb.dtype, device=yb.device)
+        pad[:, :self.nLB] = yb
+        full = torch.empty(self.world * lead, nmax, C, dtype=yb.dtype, device=yb.device)
+        if pad.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(host, pad.cpu(), group=self.group)
+            full.copy_(host)
+        else:
+            dist.all_gather_into_tensor(full, pad, group=self.group)
+        full = full.view(self.world, lead, nmax, C)
+        return torch.cat([full[j, :, :b - a] for j, (a, b) in enumerate(self.LB)], dim=1).contiguous()
 
 
 def shard_sequence(model, group=None):

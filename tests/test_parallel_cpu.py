@@ -31,6 +31,18 @@ def _worker(rank, world, port, S, Tt, per_frame, ret):
         loc = F.scaled_dot_product_attention(hd(q[sh.r0:sh.r1])[None], hd(kf)[None], hd(vf)[None])[0]
         loc = loc.transpose(0, 1).reshape(sh.S_loc, -1)
         assert torch.allclose(loc, full[sh.r0:sh.r1], atol=1e-5)
+        # exchange A, head-parallel form: rows -> heads all-to-all, attention on whole sequences of the local heads,
+        # heads -> rows all-to-all; must equal the full attention restricted to this rank's rows
+        Hl = H // world
+        Dl = Hl * D
+        def blocks(t):      # [world, S_loc, Dl]: local rows, column block j = heads of rank j
+            return t[sh.r0:sh.r1].view(sh.S_loc, world, Dl).transpose(0, 1).contiguous()
+        qh, kh, vh = (sh.rows_to_heads(blocks(t)) for t in (q, k, v))
+        assert torch.equal(qh, q[:, rank * Dl:(rank + 1) * Dl])
+        hl = lambda t: t.view(S, Hl, D).transpose(0, 1)
+        oh = F.scaled_dot_product_attention(hl(qh)[None], hl(kh)[None], hl(vh)[None])[0].transpose(0, 1).reshape(S, Dl)
+        mine = sh.heads_to_rows(oh)
+        assert torch.allclose(mine, full[sh.r0:sh.r1], atol=1e-5)
         # exchange B: video-row gather (rank 0 owns the text rows, hence fewer video rows)
         feats = torch.randn(2, 3, N, 8)           # e.g. [B, n_id, N, F]
         got = sh.gather_video_rows(feats[:, :, sh.v0:sh.v1].contiguous())
@@ -46,6 +58,16 @@ def _worker(rank, world, port, S, Tt, per_frame, ret):
         # output gather: every rank ends with the whole prediction
         y = torch.randn(1, N, 6)
         assert torch.equal(sh.gather_video_rows(y[:, sh.v0:sh.v1].contiguous()), y)
+        # router repartition: frame-major <-> location-major all-to-all is a permutation (round trip = identity)
+        from bind_your_avatar_implementation_amd.parallel import RouterPartition
+        pairs, Fd = 6, 4
+        rp = RouterPartition(rank, world, pairs, per_frame, dist.group.WORLD)
+        glob = torch.arange(pairs * per_frame * Fd, dtype=torch.float32).view(pairs, per_frame, Fd)
+        xa = glob[rp.pa0:rp.pa1].clone()
+        xb = rp.a_to_b(xa)
+        assert torch.equal(xb, glob[:, rp.lb0:rp.lb1])
+        assert torch.equal(rp.b_to_a(xb), xa)
+        assert torch.equal(rp.gather_b_rows(glob[:, rp.lb0:rp.lb1, :2].contiguous()), glob[:, :, :2])
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
