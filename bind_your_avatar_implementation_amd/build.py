@@ -56,6 +56,9 @@ def build_hip_library(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    # every symbol must resolve (a kernel whose host launch stub was not emitted only fails at dlopen time); checked
+    # in a child process so this one keeps a single HIP runtime
+    subprocess.check_call([sys.executable, "-c", f"import ctypes; ctypes.CDLL({LIB_PATH!r})"])
     return LIB_PATH
 
 
