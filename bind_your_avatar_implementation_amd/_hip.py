@@ -25,7 +25,7 @@ class AttnDesc(_c.Structure):
                 ("k_s1", _i64), ("k_s2", _i64), ("k_row", _i64),
                 ("v_s1", _i64), ("v_s2", _i64), ("v_row", _i64),
                 ("o_s1", _i64), ("o_s2", _i64), ("o_row", _i64),
-                ("scale", _f32)]
+                ("scale", _f32), ("scores_prescaled", _i32)]
 
 
 # name -> argtypes (all return int32 status); mirrors include/bya.h one-to-one
@@ -36,7 +36,7 @@ SIGNATURES = {
     "bya_timestep_features": [_vp, _vp, _i32, _i32, _i32, _f32, _vp],
     "bya_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,
                       _f32, _vp],
-    "bya_qknorm_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _vp],
+    "bya_qknorm_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _f32, _vp],
     "bya_attn_fwd": [_vp, _vp, _vp, _vp, _c.POINTER(AttnDesc), _vp],
     "bya_attn_tiny": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
     "bya_router_scores": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp],

@@ -24,6 +24,7 @@ struct AttnArgs {
     int heads, nb1, nb2, Sq, Skv, nqt;
     long long q_s1, q_s2, q_row, k_s1, k_s2, k_row, v_s1, v_s2, v_row, o_s1, o_s2, o_row;
     float scale_log2;  // scale * log2(e)
+    int prescaled;     // scores already in exp2 units (scale folded into k by the producer)
 };
 
 constexpr int KV_TILE = 64;
@@ -110,9 +111,12 @@ constexpr float RESCALE_THR = 6.0f;   // skip the O rescale while the running ma
 // common path is ONE v_exp_f32 per score (no per-element fma/sub; +2 MFMAs per tile, which the matrix pipe has room
 // for).  m_run moves only when some row's maximum grows by more than 2^RESCALE_THR (wave-uniform branch); the first
 // tile always sets it.  m_run is kept equal to the two-term bf16 value actually subtracted, so the algebra is exact.
-// PRESCALED = true: q was multiplied by c = scale*log2(e) and rounded to bf16 at load (one v_exp per score, but the
-// rounding of q*c costs ~1e-3 of accuracy); false: q untouched, scores and m_run stay in raw units and c is applied in
-// fp32 right before the exp (one extra v_mul per score, bit-level accuracy of the scores).
+// PRESCALED = true: the caller already folded scale*log2(e) into k (bya_qknorm_rope's k_scale applies it in fp32
+// BEFORE k is rounded to bf16, so there is no extra rounding): scores are in exp2 units, one v_exp per score.
+// false: scores and m_run stay in raw units and c = scale*log2(e) is applied in fp32 right before the exp
+// (one extra v_mul per score).  Things tried and measured slower on MI355X (kept out of the tree): a 3-stage ring with
+// S(t+1) issued before softmax(t) at 2 waves/SIMD (884 vs 910 TFLOP/s), two 32-row query blocks per wave sharing the
+// K/V fragments (884 vs 933), pre-scaling q in the kernel (faster, but the second rounding of q costs 1e-3 accuracy).
 template <int D, bool TAIL, bool PRESCALED>
 __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase)[D / 32], const bf16x8 (&qf)[D / 16],
                                           f32x16 (&oacc)[D / 32], const bf16x8& ones, bf16x8& mfrag, float& m_run,
@@ -242,8 +246,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
     const bf16_t* V = p.v + b1 * p.v_s1 + b2 * p.v_s2 + (long long)head * D;
     bf16_t* O = p.o + b1 * p.o_s1 + b2 * p.o_s2 + (long long)head * D;
 
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane (r,hf) holds Q[q0+r][16s + 8hf .. +7], pre-scaled by
-    // scale * log2(e) (rounded to bf16 once) so that the scores come out of the MFMA in exp2 units
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane (r,hf) holds Q[q0+r][16s + 8hf .. +7]
     const int q0 = qt * Q_PER_BLOCK + wave * Q_PER_WAVE;
     int qrow = q0 + r;
     const bool q_valid = qrow < p.Sq;
@@ -252,14 +255,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
 #pragma unroll
     for (int s = 0; s < DSTEPS; ++s) {
         const u32x4 raw = *reinterpret_cast<const u32x4*>(Q + (long long)qrow * p.q_row + s * 16 + hf * 8);
-        float f[8];
-        unpack8(raw, f);
-        if (PRESCALED) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] *= p.scale_log2;
-        }
-        const u32x4 sc = PRESCALED ? pack8(f) : raw;
-        qf[s] = __builtin_bit_cast(bf16x8, sc);
+        qf[s] = __builtin_bit_cast(bf16x8, raw);
     }
 
     f32x16 oacc[DT];
@@ -371,248 +367,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel_d128(AttnArgs p) {
     attn_fwd_body<128, false>(p, smem);
 }
 
-// ================================================================================================================
-// v3: software-pipelined structure for D = 64 and long key sequences (the joint 17776-token attention).
-//   * 3-stage LDS ring, ONE raw s_barrier per key tile (no __syncthreads(): its implied vmcnt(0)/lgkmcnt(0) would
-//     drain the LDS-DMA prefetch); the DMA of tile t+2 is issued right after the barrier of iteration t and waited
-//     for at the top of iteration t+1;
-//   * S(t+1) = K(t+1).Q^T is issued BEFORE the softmax of tile t: the matrix pipe works on the next tile's scores
-//     while the VALU does exp/max/sum/convert of the current one (two S accumulators, statically named);
-//   * K fragments by inline-asm ds_read_b128 with counted lgkmcnt, V fragments by asm ds_read_b64_tr_b16 one k-step
-//     ahead of their MFMAs.
-template <int OFF>
-__device__ __forceinline__ void lds_read128(bf16x8& dst, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
-}
-
-template <bool TAIL>
-__device__ __forceinline__ void softmax_tile64(f32x16 (&sacc)[2], bf16x8 (&pf)[4], f32x16 (&oacc)[2], float& m_run,
-                                               float& l_run, float c, int kv_valid, int hf) {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (TAIL) {
-                const int kv = u * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
-                if (kv >= kv_valid) sacc[u][i] = -INFINITY;
-            }
-            mx = fmaxf(mx, sacc[u][i]);
-        }
-    {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * c;
-    }
-    if (__builtin_amdgcn_ballot_w64(mx > m_run + RESCALE_THR) != 0) {
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
-    }
-    float psum = 0.f;
-    const float neg_m = -m_run;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[u][tt * 8 + e], c, neg_m));
-                psum += pv;
-                pf[u * 2 + tt][e] = (__bf16)pv;
-            }
-    l_run += psum;
-}
-
-__global__ __launch_bounds__(256, 2) void attn_fwd3_kernel(AttnArgs p) {
-    constexpr int D = 64, ROW_BYTES = 128, TILE_BYTES = KV_TILE * ROW_BYTES, STAGE_BYTES = 2 * TILE_BYTES, DT = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hf = lane >> 5;
-    const int nbh = p.nb1 * p.nb2 * p.heads;
-    int bh, qt;
-    if (nbh % 8 == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        bh = (j / p.nqt) * 8 + xcd;
-        qt = j % p.nqt;
-    } else {
-        bh = blockIdx.x / p.nqt;
-        qt = blockIdx.x % p.nqt;
-    }
-    if (bh >= nbh) return;
-    const int head = bh % p.heads;
-    const int b12 = bh / p.heads;
-    const int b1 = b12 / p.nb2, b2 = b12 % p.nb2;
-    const bf16_t* Q = p.q + b1 * p.q_s1 + b2 * p.q_s2 + (long long)head * D;
-    const bf16_t* K = p.k + b1 * p.k_s1 + b2 * p.k_s2 + (long long)head * D;
-    const bf16_t* V = p.v + b1 * p.v_s1 + b2 * p.v_s2 + (long long)head * D;
-    bf16_t* O = p.o + b1 * p.o_s1 + b2 * p.o_s2 + (long long)head * D;
-
-    const int q0 = qt * Q_PER_BLOCK + wave * Q_PER_WAVE;
-    int qrow = q0 + r;
-    const bool q_valid = qrow < p.Sq;
-    qrow = q_valid ? qrow : p.Sq - 1;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        qf[s] = *reinterpret_cast<const bf16x8*>(Q + (long long)qrow * p.q_row + s * 16 + hf * 8);
-
-    f32x16 oacc[DT];
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-
-    // lane-constant LDS offsets.  K (A operand of S^T): row 32u + r, chunk (2s + hf) ^ ((row >> 1) & 7); 32u keeps the
-    // XOR term, so one address per d-step s and the u half goes into the immediate (32 rows * 128 B = 4096).
-    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
-    uint32_t koff[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) koff[s] = r * ROW_BYTES + (((2 * s + hf) ^ kswz<D>(r)) << 4);
-    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-    uint32_t voff[DT];
-#pragma unroll
-    for (int d = 0; d < DT; ++d) {
-        const int row = 4 * hf + tq;
-        const int chunk = 4 * d + 2 * (g & 1) + (tp >> 1);
-        voff[d] = TILE_BYTES + row * ROW_BYTES + ((chunk ^ vswz<D>(row)) << 4) + (tp & 1) * 8;
-    }
-
-    const int ntiles = (p.Skv + KV_TILE - 1) / KV_TILE;
-    // LDS-DMA staging through buffer_load ... lds: loop-invariant per-lane offsets (2 VGPRs), the tile advances in the
-    // scalar offset, keys past Skv are outside the descriptor -> zeros land in LDS (their scores are masked anyway).
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)K, 0, (int)(((long long)(p.Skv - 1) * p.k_row + D) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)V, 0, (int)(((long long)(p.Skv - 1) * p.v_row + D) * 2), 0x00020000);
-    // per wave: K rows wave*16 + {0..7, 8..15}, same for V; lane -> (row = lane >> 3, 16-byte slot = lane & 7)
-    const int st_row = wave * 16 + (lane >> 3);
-    const uint32_t kvo0 = (uint32_t)st_row * (uint32_t)(p.k_row * 2) + (((lane & 7) ^ kswz<D>(st_row)) << 4);
-    const uint32_t kvo1 = (uint32_t)(st_row + 8) * (uint32_t)(p.k_row * 2) + (((lane & 7) ^ kswz<D>(st_row + 8)) << 4);
-    const uint32_t vvo0 = (uint32_t)st_row * (uint32_t)(p.v_row * 2) + (((lane & 7) ^ vswz<D>(st_row)) << 4);
-    const uint32_t vvo1 = (uint32_t)(st_row + 8) * (uint32_t)(p.v_row * 2) + (((lane & 7) ^ vswz<D>(st_row + 8)) << 4);
-    const int k_tile_stride = KV_TILE * (int)p.k_row * 2, v_tile_stride = KV_TILE * (int)p.v_row * 2;
-    auto stage = [&](int t) {
-        char* st = smem + (t % 3) * STAGE_BYTES + wave * 16 * ROW_BYTES;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_PTR(st), 16, kvo0, t * k_tile_stride, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_PTR(st + 8 * ROW_BYTES), 16, kvo1, t * k_tile_stride, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_PTR(st + TILE_BYTES), 16, vvo0, t * v_tile_stride, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_PTR(st + TILE_BYTES + 8 * ROW_BYTES), 16, vvo1,
-                                                 t * v_tile_stride, 0, 0);
-    };
-    auto qk = [&](f32x16 (&sacc)[2], uint32_t sbase) {      // S^T = K.Q^T of the tile staged at sbase
-        bf16x8 kf[4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (u == 0) lds_read128<0>(kf[s], sbase + koff[s]);
-                else lds_read128<4096>(kf[s], sbase + koff[s]);
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[u][i] = 0.f;
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]));
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sacc[u], 0, 0, 0);
-        }
-    };
-    auto pv = [&](const bf16x8 (&pf)[4], uint32_t sbase) {   // O^T += V^T.P^T, V reads one k-step ahead
-        const uint32_t vb[DT] = {sbase + voff[0], sbase + voff[1]};
-        VFrag<D> fa, fb;
-        v_issue<D, 0>(fa, vb);
-        v_issue<D, 1>(fb, vb);
-        lgkm_wait<2 * DT>();
-        pv_mfma<D>(fa, pf[0], oacc);
-        v_issue<D, 2>(fa, vb);
-        lgkm_wait<2 * DT>();
-        pv_mfma<D>(fb, pf[1], oacc);
-        v_issue<D, 3>(fb, vb);
-        lgkm_wait<2 * DT>();
-        pv_mfma<D>(fa, pf[2], oacc);
-        lgkm_wait<0>();
-        pv_mfma<D>(fb, pf[3], oacc);
-    };
-
-    // prologue: tiles 0 and 1 in flight, S(0)
-    stage(0);
-    if (ntiles > 1) stage(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    f32x16 sA[2], sB[2];
-    qk(sA, lds0);
-
-    // iteration t < ntiles-1: tile t+1 landed (waited at the barrier), DMA tile t+2, S(t+1) || softmax(t), PV(t)
-    auto iter = [&](int t, f32x16 (&scur)[2], f32x16 (&snext)[2]) {
-        if (t > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        if (t + 2 < ntiles) stage(t + 2);
-        qk(snext, lds0 + ((t + 1) % 3) * STAGE_BYTES);
-        bf16x8 pf[4];
-        softmax_tile64<false>(scur, pf, oacc, m_run, l_run, p.scale_log2, KV_TILE, hf);
-        pv(pf, lds0 + (t % 3) * STAGE_BYTES);
-    };
-    // last tile (possibly ragged): no next S
-    auto last = [&](int t, f32x16 (&scur)[2]) {
-        bf16x8 pf[4];
-        if ((p.Skv % KV_TILE) != 0)
-            softmax_tile64<true>(scur, pf, oacc, m_run, l_run, p.scale_log2, p.Skv - t * KV_TILE, hf);
-        else
-            softmax_tile64<false>(scur, pf, oacc, m_run, l_run, p.scale_log2, KV_TILE, hf);
-        pv(pf, lds0 + (t % 3) * STAGE_BYTES);
-    };
-    int t = 0;
-    for (; t + 2 < ntiles; t += 2) {
-        iter(t, sA, sB);
-        iter(t + 1, sB, sA);
-    }
-    if (t + 1 < ntiles) {          // two tiles left: S(t) in sA
-        iter(t, sA, sB);
-        last(t + 1, sB);
-    } else {
-        last(t, sA);
-    }
-
-    const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-    const float l_tot = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
-    const float inv = 1.0f / l_tot;
-    if (q_valid) {
-        bf16_t* orow = O + (long long)(q0 + r) * p.o_row;
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                u32x2 w;
-                w[0] = pack2bf(oacc[d][gq * 4 + 0] * inv, oacc[d][gq * 4 + 1] * inv);
-                w[1] = pack2bf(oacc[d][gq * 4 + 2] * inv, oacc[d][gq * 4 + 3] * inv);
-                *reinterpret_cast<u32x2*>(orow + d * 32 + gq * 8 + hf * 4) = w;
-            }
-    }
-}
-
-int launch_attn3(const AttnArgs& a, hipStream_t s) {
-    const int nbh = a.nb1 * a.nb2 * a.heads;
-    dim3 grid(nbh * a.nqt);
-    const size_t lds = 3 * 2 * KV_TILE * 64 * 2;
-    BYA_LAUNCH(attn_fwd3_kernel, grid, dim3(256), lds, s, a);
-    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
-}
-
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     const int nbh = a.nb1 * a.nb2 * a.heads;
     dim3 grid(nbh * a.nqt);
     const size_t lds = 4 * KV_TILE * D * 2;
-    static const int prescaled = [] { const char* e = getenv("BYA_ATTN_PRESCALED_Q"); return e ? atoi(e) : 0; }();
-    if (D == 64 && prescaled) BYA_LAUNCH(attn_fwd_kernel_d64_prescaled, grid, dim3(256), lds, s, a);
+    if (D == 64 && a.prescaled) BYA_LAUNCH(attn_fwd_kernel_d64_prescaled, grid, dim3(256), lds, s, a);
     else if (D == 64) BYA_LAUNCH(attn_fwd_kernel_d64, grid, dim3(256), lds, s, a);
     else BYA_LAUNCH(attn_fwd_kernel_d128, grid, dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
@@ -638,7 +398,7 @@ extern "C" int bya_attn_fwd(const void* q, const void* k, const void* v, void* o
     a.v_s1 = d->v_s1; a.v_s2 = d->v_s2; a.v_row = d->v_row;
     a.o_s1 = d->o_s1; a.o_s2 = d->o_s2; a.o_row = d->o_row;
     a.scale_log2 = d->scale * 1.4426950408889634f;
-    static const int use_v3 = [] { const char* e = getenv("BYA_ATTN_V3"); return e ? atoi(e) : 0; }();
-    if (d->head_dim == 64 && use_v3 && d->Skv >= 4 * KV_TILE) return launch_attn3(a, stream);
+    a.prescaled = d->scores_prescaled;
+    if (a.prescaled && d->head_dim != 64) return BYA_ERR_UNSUPPORTED;
     return d->head_dim == 64 ? launch_attn<64>(a, stream) : launch_attn<128>(a, stream);
 }

@@ -425,7 +425,7 @@ int launch(const GemmArgs& a, int batch, hipStream_t s) {
 }
 
 // Tile choice: fewest "CU rounds" (wave quantisation on 256 CUs) weighted by the tile's relative efficiency.
-inline int pick_tile(int M, int N, int batch, int forced) {
+inline int pick_tile(int M, int N, int K, int batch, int forced) {
     if (forced >= 0) return forced;
     if (N <= 64) return 0;
     auto rounds = [&](int bm, int bn, int per_cu) {
@@ -437,7 +437,7 @@ inline int pick_tile(int M, int N, int batch, int forced) {
     const double t256x128 = rounds(256, 128, 1) / 0.95;
     const double t256 = rounds(256, 256, 1) / 1.00;
     (void)t256x128;
-    if (M < 1024 || N < 512) return 1;
+    if (M < 1024 || N < 512 || K < 1024) return 1;     // short K loops: the pipelined kernel's prologue/epilogue dominate
     // the pipelined 256x256 kernel is ~1.2x the 128x128 one per unit of tile area when its grid fills the CUs
     return (t256 / 1.2 <= t128) ? 4 : 1;
 }
@@ -464,7 +464,7 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
     a.bias_rowscale = d->bias_rowscale; a.alpha = d->alpha == 0.0f ? 1.0f : d->alpha;
     if (d->n_split < 0 || (d->n_split > 0 && (d->n_split % 4 || d->c_split_stride % 4 || res))) return BYA_ERR_SHAPE;
     static const int forced = [] { const char* e = getenv("BYA_GEMM_TILE"); return e ? atoi(e) : -1; }();
-    switch (pick_tile(d->M, d->N, d->batch, forced)) {
+    switch (pick_tile(d->M, d->N, d->K, d->batch, forced)) {
         case 0: return launch<128, 64, 2, 2>(a, d->batch, stream);
         case 1: return launch<128, 128, 2, 2>(a, d->batch, stream);
         case 2: return launch<256, 128, 4, 2>(a, d->batch, stream);

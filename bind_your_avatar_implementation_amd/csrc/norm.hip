@@ -110,6 +110,7 @@ struct QkArgs {
     int batch, S, heads, text_rows;
     long long ld, bs;
     float eps;
+    float k_scale;     // multiplies the finished k (fp32, before the single rounding to bf16); 1 = off
 };
 
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
@@ -161,6 +162,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = o[e];
     }
+    if (which && p.k_scale != 1.0f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.k_scale;
+    }
     *reinterpret_cast<u32x4*>(base) = pack8(v);
 }
 
@@ -193,7 +198,8 @@ extern "C" int bya_layernorm(const void* x, void* y, const void* w, const void* 
 
 extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb, const void* kw, const void* kb,
                                const float* cos, const float* sin, int32_t batch, int32_t S, int32_t heads,
-                               int64_t ld, int64_t batch_stride, int32_t text_rows, float eps, hipStream_t stream) {
+                               int64_t ld, int64_t batch_stride, int32_t text_rows, float eps, float k_scale,
+                               hipStream_t stream) {
     if (!q || !k || !qw || !qb || !kw || !kb || batch <= 0 || S <= 0 || heads <= 0) return BYA_ERR_SHAPE;
     if (text_rows < S && (!cos || !sin)) return BYA_ERR_SHAPE;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)qw | (uintptr_t)kw |
@@ -202,7 +208,7 @@ extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb,
     QkArgs a;
     a.q = (bf16_t*)q; a.k = (bf16_t*)k; a.qw = (const bf16_t*)qw; a.qb = (const bf16_t*)qb;
     a.kw = (const bf16_t*)kw; a.kb = (const bf16_t*)kb; a.cos = cos; a.sin = sin;
-    a.batch = batch; a.S = S; a.heads = heads; a.text_rows = text_rows; a.ld = ld; a.bs = batch_stride; a.eps = eps;
+    a.batch = batch; a.S = S; a.heads = heads; a.text_rows = text_rows; a.ld = ld; a.bs = batch_stride; a.eps = eps; a.k_scale = k_scale == 0.0f ? 1.0f : k_scale;
     const long long total = ((long long)batch * S * heads * 2 + 7) / 8;      // waves: 8 (row, head) pairs each
     dim3 grid((unsigned)((total + 3) / 4));
     BYA_LAUNCH(qknorm_rope_kernel, grid, dim3(256), 0, stream, a);

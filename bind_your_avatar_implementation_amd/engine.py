@@ -49,6 +49,9 @@ class DenoiseEngine:
         self.L = len(model.transformer_blocks)
         self.Tt_max = self.cfg.max_text_seq_length
         self.cache_invariants = False
+        # softmax scale * log2(e) of the joint attention is folded into k where k is finished in fp32 (q/k-norm + RoPE
+        # kernel), so the attention kernel's scores are born in exp2 units (no per-score multiply)
+        self.k_scale = (self.cfg.attention_head_dim ** -0.5) * 1.4426950408889634
         # route-then-project (exact by linearity of to_out; halves those GEMMs and drops the [2,N,D] round trip).
         # False = the reference's order of operations (project each identity, then combine).
         self.mix_before_projection = os.environ.get("BYA_MIX_BEFORE_PROJECTION", "1") != "0"
@@ -361,24 +364,26 @@ class DenoiseEngine:
                         ops.gemm(xn[0], self.qkv_w[i], qkvb[0], bias=self.qkv_b[i], split=(Dl, S_loc * Dl))
                         ops.qknorm_rope(qkvb[:W], qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
                                         at.norm_k.bias, cos, sin, heads=H // W,
-                                        text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps)
+                                        text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
+                                        k_scale=self.k_scale)
                         sh.rows_to_heads(qkvb[:W], qh)
                         sh.rows_to_heads(qkvb[W:2 * W], kh)
                         sh.rows_to_heads(qkvb[2 * W:], vh)
-                        ops.self_attention(qh[None], kh[None], vh[None], oh[None], heads=H // W, tag="joint")
+                        ops.self_attention(qh[None], kh[None], vh[None], oh[None], heads=H // W, tag="joint", prescaled=True)
                         sh.heads_to_rows(oh, xn[0])
                         ops.gemm(xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
                                  gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                         continue
                     ops.gemm(xn, self.qkv_w[i], q, bias=self.qkv_b[i], split=(D, B * S_loc * D))
                     ops.qknorm_rope(q, k, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
-                                    heads=H, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps)
+                                    heads=H, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
+                                        k_scale=self.k_scale)
                     if sh.world > 1:      # exchange A (fallback when heads % world != 0): all-gather K and V
                         sh.gather_rows(k[0], k_full[0])
                         sh.gather_rows(v[0], v_full[0])
-                        ops.self_attention(q, k_full, v_full, xn, heads=H, tag="joint")
+                        ops.self_attention(q, k_full, v_full, xn, heads=H, tag="joint", prescaled=True)
                     else:
-                        ops.self_attention(q, k, v, xn, heads=H, tag="joint")
+                        ops.self_attention(q, k, v, xn, heads=H, tag="joint", prescaled=True)
                     ops.gemm(xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
                              gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                 else:

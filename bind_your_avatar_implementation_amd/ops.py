@@ -154,7 +154,7 @@ def layernorm(x, out, weight=None, bias=None, eps=1e-5, shift0=None, scale0=None
     return out
 
 
-def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6):
+def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6, k_scale=1.0):
     """In place on q, k [B, S, heads*64]."""
     lib = _hip.load()
     b, S, _, bs, ld = _mat(q, "q")
@@ -164,12 +164,13 @@ def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6):
         assert cos.shape == (S - text_rows, 64)
     tok = _begin("bya_qknorm_rope")
     check(lib.bya_qknorm_rope(_p(q), _p(k), _p(qw), _p(qb), _p(kw), _p(kb), _p(cos), _p(sin), b, S, heads, ld,
-                              bs if b > 1 else 0, text_rows, float(eps), _stream()), "bya_qknorm_rope")
+                              bs if b > 1 else 0, text_rows, float(eps), float(k_scale), _stream()),
+          "bya_qknorm_rope")
     _end(tok)
 
 
 def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_strides, v_strides, o_strides,
-              scale, tag="other"):
+              scale, tag="other", prescaled=False):
     """Flash attention with explicit (level-1, level-2, row) element strides for q, k, v, out."""
     lib = _hip.load()
     d = AttnDesc()
@@ -179,6 +180,7 @@ def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_
     d.v_s1, d.v_s2, d.v_row = v_strides
     d.o_s1, d.o_s2, d.o_row = o_strides
     d.scale = float(scale)
+    d.scores_prescaled = int(prescaled)
     for t in (q, k, v, out):
         assert t.dtype == torch.bfloat16 and t.is_cuda
     tok = _begin("bya_attn_fwd:" + tag, 4.0 * nb1 * nb2 * heads * Sq * Skv * head_dim)
@@ -187,7 +189,7 @@ def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_
     return out
 
 
-def self_attention(q, k, v, out, heads, head_dim=64, scale=None, tag="other"):
+def self_attention(q, k, v, out, heads, head_dim=64, scale=None, tag="other", prescaled=False):
     """q,k,v,out: [B, S, heads*head_dim] views (row-strided ok)."""
     b, S, _, q_bs, q_ld = _mat(q, "q")
     _, Skv, _, k_bs, k_ld = _mat(k, "k")
@@ -196,7 +198,7 @@ def self_attention(q, k, v, out, heads, head_dim=64, scale=None, tag="other"):
     scale = head_dim ** -0.5 if scale is None else scale
     return attention(q, k, v, out, head_dim=head_dim, heads=heads, nb1=b, nb2=1, Sq=S, Skv=Skv,
                      q_strides=(q_bs, 0, q_ld), k_strides=(k_bs, 0, k_ld), v_strides=(v_bs, 0, v_ld),
-                     o_strides=(o_bs, 0, o_ld), scale=scale, tag=tag)
+                     o_strides=(o_bs, 0, o_ld), scale=scale, tag=tag, prescaled=prescaled)
 
 
 def attn_tiny(q, k, v, out, L, heads, n_outer, n_inner, outer_stride, seq_stride, ld_qkv, ld_o, scale):

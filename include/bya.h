@@ -91,10 +91,12 @@ int bya_layernorm(const void* x, void* y, const void* w, const void* b, const vo
 
 /* Per-head LayerNorm(64, eps, affine) on q and k followed by interleaved-pair RoPE on rows >= text_rows
  * (diffusers CogVideoXAttnProcessor2_0 + apply_rotary_emb; models/transformer.py:204-208).  In place.
- * q,k: [batch, S, heads*64] with row stride ld; cos,sin: fp32 [S - text_rows, 64]. */
+ * q,k: [batch, S, heads*64] with row stride ld; cos,sin: fp32 [S - text_rows, 64].
+ * k_scale (0 or 1 = off): the finished k is multiplied by it in fp32 before its single rounding to bf16 -- the engine
+ * folds softmax_scale*log2(e) into k here so that bya_attn_fwd can run with scores_prescaled = 1. */
 int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb, const void* kw, const void* kb,
                     const float* cos, const float* sin, int32_t batch, int32_t S, int32_t heads, int64_t ld,
-                    int64_t batch_stride, int32_t text_rows, float eps, hipStream_t stream);
+                    int64_t batch_stride, int32_t text_rows, float eps, float k_scale, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Flash attention forward, head_dim 64 or 128, no mask, fp32 online softmax, bf16 P.V on MFMA.
@@ -115,6 +117,8 @@ typedef struct bya_attn_desc {
     int64_t v_s1, v_s2, v_row;
     int64_t o_s1, o_s2, o_row;
     float scale;
+    int32_t scores_prescaled;   /* 1: q.k is already scale*log2(e)*(q.k) (folded into k upstream); scale is ignored;
+                                   head_dim 64 only.  Saves one multiply per score in the VALU-bound softmax. */
 } bya_attn_desc;
 
 int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya_attn_desc* desc,

@@ -148,6 +148,20 @@ def test_attn_self_d64(ops, dev, S, H):
     check(out, ref, tol=ATTN_TOL, what=f"attn S={S} H={H}")
 
 
+def test_attn_prescaled_scores(ops, dev):
+    """Engine path of the joint attention: scale*log2(e) is folded into k by the q/k-norm kernel (k_scale), the
+    attention kernel then takes the scores as exp2 exponents.  Reference: softmax(ln2 * q.k') with the same k'."""
+    B, S, H, D = 1, 1000, 8, 64
+    q, k, v = (rnd((B, S, H * D), dev, 25 + i) for i in range(3))
+    c = D ** -0.5 * 1.4426950408889634
+    k2 = bf(k.float() * c)
+    out = torch.empty_like(q)
+    ops.self_attention(q, k2, v, out, heads=H, prescaled=True)
+    sp = lambda t: t.view(B, S, H, D).transpose(1, 2)
+    ref = sdpa_ref(sp(q), sp(k2), sp(v), math.log(2.0)).transpose(1, 2).reshape(B, S, H * D)
+    check(out, ref, tol=ATTN_TOL, what="attn prescaled")
+
+
 def test_attn_layout_exact(ops, dev):
     """One-hot softmax (a huge matching key) makes the output an exact row gather of V: pins every
     MFMA / transposed-LDS-read lane map with integer data."""
@@ -271,6 +285,10 @@ def test_qknorm_rope(ops, dev):
 
     check(q, ref(q0, qw, qb), what="qknorm_rope q")
     check(k, ref(k0, kw, kb), what="qknorm_rope k")
+    q, k = q0.clone(), k0.clone()
+    ops.qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads=H, text_rows=T, eps=1e-6, k_scale=0.18)
+    check(q, ref(q0, qw, qb), what="qknorm_rope q (k_scale leaves q alone)")
+    check(k, 0.18 * ref(k0, kw, kb), what="qknorm_rope k * k_scale (single rounding)")
 
 
 # ----------------------------------------------------------------------------------------------- small linears
