@@ -59,6 +59,17 @@ def cpu_baseline(threads):
                       f"{dt:.1f} s; extrapolated linearly by FLOPs to a full step"}
 
 
+def attn_traffic(world):
+    """HBM bytes per launch of the joint-attention kernel from the committed rocprofv3 PMC passes
+    (profiles/r1_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md section HBM); single-GPU only."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f).get("attn_fwd_kernel_d64_prescaled")
+    return rec["hbm_bytes_per_launch"] if rec else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +78,7 @@ def main():
     ap.add_argument("--layers", type=int, default=42, help="debug only: anything but 42 is not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N = 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,6 +109,10 @@ def main():
     inp["id_cond"] = [t.to(dev, torch.bfloat16) for t in inp["id_cond"]]
     inp["id_vit_hidden"] = [[t.to(dev, torch.bfloat16) for t in l] for l in inp["id_vit_hidden"]]
 
+    if args.graph and world == 1:
+        model.use_hip_graph = True
+        args.no_kernel_timers = True          # events cannot be recorded per kernel inside a replayed graph
+
     def step():
         return model(return_dict=False, denoise_step=0, **inp)[0]
 
@@ -105,7 +121,6 @@ def main():
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all(), "non-finite output"
 
-    timers = None if args.no_kernel_timers else ops.enable_kernel_timers()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -120,7 +135,15 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    ktimes = ops.collect_kernel_timers() if timers is not None else {}
+    # Per-kernel HIP-event timing runs in a SECOND pass of the same K steps: an event pair around every one of the
+    # ~3000 launches of a step costs ~5 % of wall time, which must not leak into `value`.
+    ktimes = {}
+    if not args.no_kernel_timers:
+        ops.enable_kernel_timers()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        ktimes = ops.collect_kernel_timers()
 
     if rank == 0:
         sec_per_step = dt / args.steps
@@ -134,6 +157,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: full transformer.forward, 49x480x720 (13x30x45 latent "
                                    "tokens + 226 text), 2 characters (2 ID + 2 audio), batch 1, random-init 8.6B-param "
                                    "architecture", "layers": args.layers, "tokens": 17776,
+                       "launch": "hipGraph replay" if (args.graph and world == 1) else "eager",
                        "parallelism": "single GPU" if world == 1 else f"sequence-parallel x{world} (K/V all-gather)"},
         }
         if ktimes:
@@ -146,12 +170,12 @@ def main():
                 ach = ATTN_TFLOP_PER_LAUNCH / world / avg
                 res["roofline"] = {"kernel": "attn_fwd_kernel<64> (joint 17776-token self-attention)",
                                    "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                                   "frac": ach / PEAK_BF16_TFLOPS, "traffic": attn_traffic(world),
                                    "avg_launch_ms": avg * 1e3, "launches": len(attn)}
             gemm = ktimes.get("bya_gemm_bf16", [])
             if gemm:
                 gflop = ops.kernel_timer_flops().get("bya_gemm_bf16", 0.0)
-                res["gemm_roofline"] = {"kernel": "gemm_bf16_kernel<128,128>", "bound": "mfma",
+                res["gemm_roofline"] = {"kernel": "gemm256_kernel + gemm_bf16_kernel<128,128> (all Linear launches)", "bound": "mfma",
                                         "achieved": gflop / 1e12 / sum(gemm), "peak": PEAK_BF16_TFLOPS,
                                         "unit": "TFLOP/s", "frac": gflop / 1e12 / sum(gemm) / PEAK_BF16_TFLOPS,
                                         "launches": len(gemm)}

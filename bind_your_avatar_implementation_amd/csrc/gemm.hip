@@ -469,6 +469,36 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
         case 1: return launch<128, 128, 2, 2>(a, d->batch, stream);
         case 2: return launch<256, 128, 4, 2>(a, d->batch, stream);
         case 3: return launch<256, 256, 2, 4>(a, d->batch, stream);
-        default: return launch256(a, d->batch, stream);
+        default: break;
     }
+    // Pipelined 256x256 tiles, one workgroup per CU.  When the last round of tiles would leave most CUs idle
+    // (N = 3072 at 17776 rows: 840 tiles = 3.28 rounds), the rows of the complete rounds go to the pipelined kernel
+    // and the remaining rows to the 128x128 kernel, whose many small tiles fill all CUs at once.
+    static const bool no_tail = getenv("BYA_GEMM_NO_TAIL") != nullptr;
+    const int tn = (a.N + 255) / 256, tm = (a.M + 255) / 256;
+    const long long tiles = (long long)tm * tn;
+    const long long full = tiles / 256;
+    if (!no_tail && d->batch == 1 && full >= 1 && tiles % 256 != 0) {
+        const int main_tm = (int)(full * 256 / tn);
+        const int m0 = main_tm * 256;
+        if (m0 > 0 && m0 < a.M) {
+            const long long tail_blocks = (long long)((a.M - m0 + 127) / 128) * ((a.N + 127) / 128);
+            const double tail_cost = 0.6 * (double)((tail_blocks + 511) / 512);      // in pipelined-kernel rounds
+            const double main_cost = (double)(((long long)main_tm * tn + 255) / 256);
+            if (main_cost + tail_cost < (double)((tiles + 255) / 256) - 0.15) {
+                GemmArgs lo = a, hi = a;
+                lo.M = m0;
+                hi.M = a.M - m0;
+                hi.A += (long long)m0 * a.lda;
+                hi.C += (long long)m0 * a.ldc;
+                if (hi.res) hi.res += (long long)m0 * a.ldres;
+                if (hi.bias_rowscale) hi.bias_rowscale += m0;
+                hi.gate_split = a.gate_split > m0 ? a.gate_split - m0 : 0;
+                const int rc = launch256(lo, 1, stream);
+                if (rc != BYA_OK) return rc;
+                return launch<128, 128, 2, 2>(hi, 1, stream);
+            }
+        }
+    }
+    return launch256(a, d->batch, stream);
 }

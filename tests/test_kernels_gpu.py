@@ -124,6 +124,25 @@ def test_gemm_pipelined_256(ops, dev, M, N, K):
     check(out, res.float() + F.gelu(a.float() @ w.float().T + b.float(), approximate="tanh"), what=f"gemm256 {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("gate_split", [226, 16500])
+def test_gemm_quantisation_tail_split(ops, dev, gate_split):
+    """17776 x 3072 is 3.28 rounds of 256x256 tiles: rows [0, 16384) run on the pipelined kernel and the last 1392
+    rows on the 128x128 kernel.  Every row-indexed operand (residual, gate switch row, per-row bias scale) must land
+    on the right rows in both parts."""
+    M, N, K = 17776, 3072, 1024
+    a, w, b = rnd((M, K), dev, 30), rnd((N, K), dev, 31, K ** -0.5), rnd((N,), dev, 32, 0.3)
+    x = rnd((M, N), dev, 33)
+    g = rnd((2, N), dev, 34, 0.5)
+    rs = torch.rand(M, generator=torch.Generator().manual_seed(35)).to(dev)
+    out = torch.empty_like(x)
+    ops.gemm(a, w, out, bias=b, res=x, gate0=g[0], gate1=g[1], gate_split=gate_split, bias_rowscale=rs)
+    y = a.float() @ w.float().T + b.float() * rs[:, None]
+    gate = torch.where(torch.arange(M, device=dev)[:, None] < gate_split, g[0].float(), g[1].float())
+    ref = x.float() + gate * y
+    for lo, hi in ((0, 16384), (16384, M)):
+        check(out[lo:hi], ref[lo:hi], what=f"gemm tail split rows {lo}:{hi} gate_split={gate_split}")
+
+
 def test_gemm_rejects_bad_shapes(ops, dev):
     from bind_your_avatar_implementation_amd._hip import ByaError
     a, w = rnd((64, 96), dev, 1), rnd((64, 96), dev, 2)       # K % 64 != 0
