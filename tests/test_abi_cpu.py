@@ -60,10 +60,11 @@ def test_struct_layout_matches_header():
             decl = decl.strip()
             if not decl:
                 continue
-            typ, names = decl.split(None, 1)
-            fields += [(n.strip(), typ) for n in names.split(",")]
+            first, *more = decl.split(",")
+            typ, name = re.match(r"(.*?)(\w+)$", first.strip(), flags=re.S).groups()
+            fields += [(name, typ.strip())] + [(n.strip(), typ.strip()) for n in more]
         assert [f[0] for f in fields] == [f[0] for f in cls._fields_], cname
-        size = {"int32_t": 4, "int64_t": 8, "float": 4}
+        size = {"int32_t": 4, "int64_t": 8, "float": 4, "const float*": 8}
         for (n, typ), (_, ct) in zip(fields, cls._fields_):
             assert ctypes.sizeof(ct) == size[typ], (cname, n)
 
