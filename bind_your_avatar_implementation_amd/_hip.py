@@ -28,6 +28,11 @@ class AttnDesc(_c.Structure):
                 ("scale", _f32), ("scores_prescaled", _i32)]
 
 
+class SchedCoef(_c.Structure):
+    _fields_ = [("guidance", _f32), ("sqrt_alpha", _f32), ("sqrt_beta", _f32), ("k_sample", _f32),
+                ("k_denoised", _f32), ("k_noise", _f32), ("k_cur", _f32), ("k_old", _f32)]
+
+
 # name -> argtypes (all return int32 status); mirrors include/bya.h one-to-one
 SIGNATURES = {
     "bya_abi_version": [],
@@ -47,6 +52,7 @@ SIGNATURES = {
     "bya_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "bya_unpatchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "bya_act_add": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "bya_cfg_scheduler_step": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _c.POINTER(SchedCoef), _vp],
 }
 
 ERRORS = {-1: "BYA_ERR_SHAPE", -2: "BYA_ERR_ALIGN", -3: "BYA_ERR_LAUNCH", -4: "BYA_ERR_UNSUPPORTED"}

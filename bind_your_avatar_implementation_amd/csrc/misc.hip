@@ -240,6 +240,47 @@ __global__ __launch_bounds__(256) void act_add_kernel(const bf16_t* __restrict__
 
 inline int ok() { const hipError_t e = hipGetLastError(); return e == hipSuccess ? BYA_OK : -(1000 + (int)e); }
 
+
+// ---- classifier-free-guidance combine + scheduler step, fused -------------------------
+// One pass over the latents instead of ~10 elementwise launches.  The fp32 / bf16 rounding points are the ones torch's
+// type promotion produces for the expressions of the reference loop (models/pipeline_bindyouravatar.py:924-948) and of
+// diffusers' CogVideoX DDIM / DPM schedulers: a 0-dim coefficient times the bf16 sample (or noise) is a bf16 product,
+// everything touching the fp32 prediction stays fp32.  FP contraction is off so no product is fused into an FMA.
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(256)
+cfg_sched_kernel(const bf16_t* __restrict__ pred, long long pred_stride, int n_pred, const bf16_t* __restrict__ x,
+                 const float* __restrict__ old_x0, const bf16_t* __restrict__ noise, bf16_t* __restrict__ prev,
+                 float* __restrict__ x0_out, long long n, bya_sched_coef c) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = bf2f(pred[i]);
+        if (n_pred == 2) {
+            const float cond = bf2f(pred[pred_stride + i]);
+            const float diff = cond - v;
+            const float scaled = c.guidance * diff;
+            v = v + scaled;
+        }
+        const float xs = bf2f(x[i]);
+        const float t1 = bf2f(f2bf(c.sqrt_alpha * xs));
+        const float t2 = c.sqrt_beta * v;
+        const float x0 = t1 - t2;
+        float d = x0;
+        if (old_x0) {
+            const float cur = c.k_cur * x0;
+            const float old = c.k_old * old_x0[i];
+            d = cur - old;
+        }
+        const float t3 = bf2f(f2bf(c.k_sample * xs));
+        const float t4 = c.k_denoised * d;
+        float r = t3 - t4;
+        if (noise) {
+            const float tn = bf2f(f2bf(c.k_noise * bf2f(noise[i])));
+            r = r + tn;
+        }
+        prev[i] = f2bf(r);
+        if (x0_out) x0_out[i] = x0;
+    }
+}
+
 }  // namespace
 
 extern "C" int bya_abi_version(void) { return 1; }
@@ -343,5 +384,19 @@ extern "C" int bya_act_add(const void* x, const void* r, void* y, int64_t n, int
     if (blocks > 4096) blocks = 4096;
     BYA_LAUNCH(act_add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x,
                        (const bf16_t*)r, (bf16_t*)y, nvec, act);
+    return ok();
+}
+
+extern "C" int bya_cfg_scheduler_step(const void* pred, int32_t n_pred, int64_t pred_stride, const void* sample,
+                                      const float* old_x0, const void* noise, void* prev_sample, float* x0_out,
+                                      int64_t n, const bya_sched_coef* coef, hipStream_t stream) {
+    if (!pred || !sample || !prev_sample || !coef || n <= 0) return BYA_ERR_SHAPE;
+    if (n_pred != 1 && n_pred != 2) return BYA_ERR_SHAPE;
+    if (n_pred == 2 && pred_stride < n) return BYA_ERR_SHAPE;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    BYA_LAUNCH(cfg_sched_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)pred,
+               (long long)pred_stride, n_pred, (const bf16_t*)sample, old_x0, (const bf16_t*)noise,
+               (bf16_t*)prev_sample, x0_out, (long long)n, *coef);
     return ok();
 }

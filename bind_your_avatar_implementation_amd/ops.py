@@ -300,3 +300,26 @@ def act_add(x, out, act=None, res=None):
     check(lib.bya_act_add(_p(x), _p(res), _p(out), x.numel(), ACT[act], _stream()), "bya_act_add")
     _end(tok)
     return out
+
+
+def cfg_scheduler_step(pred, sample, coef, old_x0=None, noise=None, x0_out=None, out=None):
+    """Fused CFG combine + scheduler step (reference models/pipeline_bindyouravatar.py:924-948).
+    pred: bf16 [1 or 2, ...] model output ([uncond, cond] when 2); sample: bf16 latents [1, ...] (or any shape with the
+    element count of one prediction); coef: dict with the fields of ``bya_sched_coef``; old_x0 / x0_out: fp32;
+    noise: bf16.  Returns the new bf16 latents."""
+    import ctypes
+    lib = _hip.load()
+    n = sample.numel()
+    n_pred = pred.shape[0] if pred.numel() != n else 1
+    assert pred.dtype == sample.dtype == torch.bfloat16 and pred.is_contiguous() and sample.is_contiguous()
+    assert n_pred in (1, 2) and pred.numel() == n_pred * n
+    for t, dt in ((old_x0, torch.float32), (noise, torch.bfloat16), (x0_out, torch.float32)):
+        assert t is None or (t.dtype == dt and t.is_contiguous() and t.numel() == n)
+    if out is None:
+        out = torch.empty_like(sample)
+    c = _hip.SchedCoef(**{k: float(v) for k, v in coef.items()})
+    tok = _begin("bya_cfg_scheduler_step")
+    check(lib.bya_cfg_scheduler_step(_p(pred), n_pred, n, _p(sample), _p(old_x0), _p(noise), _p(out), _p(x0_out), n,
+                                     ctypes.byref(c), _stream()), "bya_cfg_scheduler_step")
+    _end(tok)
+    return out

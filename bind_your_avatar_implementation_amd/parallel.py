@@ -213,3 +213,55 @@ def shard_sequence(model, group=None):
     model._seq_rank = dist.get_rank(model._seq_group)
     model.invalidate_engine()
     return model
+
+
+# ---- classifier-free-guidance batch split (first row) ---------------------------------------
+class CfgSplit:
+    """The two halves of a CFG batch ([uncond, cond], reference models/pipeline_bindyouravatar.py:897-923) never interact
+    inside ``forward``, so ranks [0, W/2) run sample 0 and ranks [W/2, W) run sample 1, each half optionally
+    sequence-sharded over its own W/2 ranks.  One exchange per step: rank r and rank r + W/2 trade their
+    ``[1,13,16,60,90]`` predictions (2 MB) so every rank returns the full ``[2, ...]`` batch."""
+
+    def __init__(self, group=None):
+        group = group if group is not None else dist.group.WORLD
+        ranks = dist.get_process_group_ranks(group)
+        W = len(ranks)
+        if W % 2:
+            raise ValueError("the CFG split needs an even number of ranks")
+        me = dist.get_rank(group)
+        self.world, self.half_size, self.half = W, W // 2, me // (W // 2)
+        # every rank creates every subgroup, in the same order (torch.distributed requirement)
+        halves = [dist.new_group(ranks[h * self.half_size:(h + 1) * self.half_size]) for h in range(2)]
+        pairs = [dist.new_group([ranks[r], ranks[r + self.half_size]]) for r in range(self.half_size)]
+        self.seq_group = halves[self.half]
+        self.pair_group = pairs[me % self.half_size]
+
+    def take(self, obj):
+        """This rank's sample of every batch-2 tensor in a (nested) argument; batch-1 tensors are shared."""
+        if torch.is_tensor(obj):
+            return obj[self.half:self.half + 1] if obj.dim() > 0 and obj.shape[0] == 2 else obj
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self.take(o) for o in obj)
+        return obj
+
+    def join(self, local):
+        """[1, ...] per rank -> [2, ...] on every rank (sample order = half order)."""
+        out = torch.empty(2, *local.shape[1:], dtype=local.dtype, device=local.device)
+        if local.is_cuda and dist.get_backend(self.pair_group) == "gloo":
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=self.pair_group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.pair_group)
+        return out
+
+
+def shard_cfg(model, group=None):
+    """Run the two samples of a CFG batch on two halves of ``group``; inside a half the step is sequence-parallel
+    when the half has more than one rank (2 x 2, 2 x 4).  Batch-1 calls fall through to plain execution on the half."""
+    model._cfg = CfgSplit(group)
+    if model._cfg.half_size > 1:
+        shard_sequence(model, model._cfg.seq_group)
+    else:
+        model.invalidate_engine()
+    return model

@@ -7,9 +7,11 @@ Out of scope (third-party models that run once outside the 
 encode/decode, key-point drawing.  Consequently ``prompt_embeds`` / ``negative_prompt_embeds`` and the condition
 latents are passed as tensors and ``output_type`` must be ``"latent"``; passing ``prompt`` / ``image`` raises.
 
-The scheduler is a restatement of diffusers' ``CogVideoXDDIMScheduler`` (v-prediction, scaled-linear betas with SNR
-shift 3.0, zero-terminal-SNR rescale, trailing spacing).  Its configuration ships with the HF checkpoint, not with
-the reference repo, so it is "parity unpinned" like the other diffusers-owned pieces.
+Schedulers: ``DDIMScheduler`` / ``DPMScheduler`` hold the host side (float64 coefficient tables, per-step scalars) of
+diffusers' ``CogVideoXDDIMScheduler`` / ``CogVideoXDPMScheduler`` (v-prediction, scaled-linear betas with SNR shift 3.0,
+zero-terminal-SNR rescale, trailing spacing); the CFG combine and the step itself are one fused HIP launch
+(``bya_cfg_scheduler_step``).  Their configuration ships with the HF checkpoint, not with
+the reference repo, so they are "parity unpinned" like the other diffusers-owned pieces.
 """
 import math
 from types import SimpleNamespace
@@ -49,24 +51,33 @@ def get_af_matrix_infer(speaker_pos):
     raise ValueError("speaker is not left or right")
 
 
-class DDIMScheduler:
-    """CogVideoXDDIMScheduler restated (eta = 0 path).  fp32 math on the latents' device."""
+def _alphas_cumprod(num_train_timesteps, beta_start, beta_end, snr_shift_scale):
+    """float64: scaled-linear betas -> cumprod -> SNR shift -> zero-terminal-SNR rescale (CogVideoX schedulers)."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float64) ** 2
+    ac = torch.cumprod(1.0 - betas, dim=0)
+    ac = ac / (snr_shift_scale + (1 - snr_shift_scale) * ac)
+    s = ac.sqrt()
+    s0, sT = s[0].clone(), s[-1].clone()
+    s = (s - sT) * (s0 / (s0 - sT))
+    return s ** 2
+
+
+class _SchedulerBase:
+    """Host side of a scheduler: float64 coefficient tables and per-step scalars.  The element-wise work (CFG combine
+    + the step itself) runs in ONE HIP launch, ``ops.cfg_scheduler_step`` -- there is no torch implementation here."""
 
     order = 1
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, snr_shift_scale=3.0,
                  prediction_type="v_prediction"):
-        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float64) ** 2
-        ac = torch.cumprod(1.0 - betas, dim=0)
-        ac = ac / (snr_shift_scale + (1 - snr_shift_scale) * ac)             # SNR shift
-        s = ac.sqrt()                                                        # zero terminal SNR rescale
-        s0, sT = s[0].clone(), s[-1].clone()
-        s = (s - sT) * s0 / (s0 - sT)
-        self.alphas_cumprod = (s ** 2).float()
-        self.final_alpha_cumprod = torch.tensor(1.0)
+        if prediction_type != "v_prediction":
+            raise NotImplementedError(prediction_type)
+        self.alphas_cumprod = _alphas_cumprod(num_train_timesteps, beta_start, beta_end, snr_shift_scale)
+        self.final_alpha_cumprod = torch.tensor(1.0, dtype=torch.float64)
         self.num_train_timesteps = num_train_timesteps
         self.prediction_type = prediction_type
         self.timesteps = None
+        self.init_noise_sigma = 1.0
 
     def set_timesteps(self, num_inference_steps, device=None):
         self.num_inference_steps = num_inference_steps
@@ -77,19 +88,68 @@ class DDIMScheduler:
     def scale_model_input(self, sample, t):
         return sample
 
-    def step(self, model_output, timestep, sample):
+    def _alphas(self, timestep):
         t = int(timestep)
         prev_t = t - self.num_train_timesteps // self.num_inference_steps
-        a_t = self.alphas_cumprod[t].to(sample.device)
-        a_prev = (self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod).to(sample.device)
-        x, v = sample.float(), model_output.float()
-        if self.prediction_type != "v_prediction":
-            raise NotImplementedError(self.prediction_type)
-        x0 = a_t.sqrt() * x - (1 - a_t).sqrt() * v
-        # diffusers' CogVideoX form: prev = a * x_t + b * x0
-        a = ((1 - a_prev) / (1 - a_t)).sqrt()
-        b = a_prev.sqrt() - a_t.sqrt() * a
-        return a * x + b * x0
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        return a_t, a_prev, prev_t
+
+
+class DDIMScheduler(_SchedulerBase):
+    """CogVideoXDDIMScheduler, eta = 0."""
+
+    def coefficients(self, timestep, guidance=1.0):
+        a_t, a_prev, _ = self._alphas(timestep)
+        a = ((1 - a_prev) / (1 - a_t)) ** 0.5
+        b = a_prev ** 0.5 - a_t ** 0.5 * a
+        return dict(guidance=guidance, sqrt_alpha=a_t ** 0.5, sqrt_beta=(1 - a_t) ** 0.5, k_sample=a, k_denoised=-b,
+                    k_noise=0.0, k_cur=1.0, k_old=0.0)
+
+    def step(self, model_output, timestep, sample, guidance=1.0):
+        """``model_output``: the bf16 prediction, [1, ...] or the CFG pair [2, ...]; returns the new bf16 latents."""
+        from . import ops
+        return ops.cfg_scheduler_step(model_output.to(torch.bfloat16).contiguous(), sample.contiguous(),
+                                      self.coefficients(timestep, guidance))
+
+
+class DPMScheduler(_SchedulerBase):
+    """CogVideoXDPMScheduler (SDE DPM-Solver++ 2M; what the reference's infer.py:202 configures).  Stochastic: every
+    step consumes Gaussian draws from the caller's generator exactly like diffusers does (one draw on the first and on
+    the last step, two on the others, of which the second reaches the sample)."""
+
+    def coefficients(self, timestep, timestep_back=None, guidance=1.0, have_old=True):
+        a_t, a_prev, prev_t = self._alphas(timestep)
+        lamb = ((a_t / (1 - a_t)) ** 0.5).log()
+        lamb_next = ((a_prev / (1 - a_prev)) ** 0.5).log()
+        h = lamb_next - lamb
+        m0 = ((1 - a_prev) / (1 - a_t)) ** 0.5 * (-h).exp()
+        m1 = (-2 * h).expm1() * a_prev ** 0.5
+        m_noise = (1 - a_prev) ** 0.5 * (1 - (-2 * h).exp()) ** 0.5
+        second = have_old and timestep_back is not None and prev_t >= 0
+        k_cur, k_old = 1.0, 0.0
+        if second:
+            a_back = self.alphas_cumprod[int(timestep_back)]
+            lamb_prev = ((a_back / (1 - a_back)) ** 0.5).log()
+            r = (lamb - lamb_prev) / h
+            k_cur, k_old = 1 + 1 / (2 * r), 1 / (2 * r)
+        return dict(guidance=guidance, sqrt_alpha=a_t ** 0.5, sqrt_beta=(1 - a_t) ** 0.5, k_sample=m0, k_denoised=m1,
+                    k_noise=m_noise, k_cur=k_cur, k_old=k_old), second
+
+    def step(self, model_output, old_pred_original_sample, timestep, timestep_back, sample, guidance=1.0,
+             generator=None):
+        """-> (new bf16 latents, fp32 x0 for the next call)."""
+        from . import ops
+        coef, second = self.coefficients(timestep, timestep_back, guidance, old_pred_original_sample is not None)
+        gdev = sample.device if generator is None else generator.device
+        draw = lambda: torch.randn(sample.shape, generator=generator, device=gdev, dtype=sample.dtype).to(sample.device)
+        noise = draw()
+        if second:
+            noise = draw()                    # diffusers draws again for the corrected sample; the first is unused
+        x0 = torch.empty(sample.shape, dtype=torch.float32, device=sample.device)
+        prev = ops.cfg_scheduler_step(model_output.to(torch.bfloat16).contiguous(), sample.contiguous(), coef,
+                                      old_x0=old_pred_original_sample if second else None, noise=noise, x0_out=x0)
+        return prev, x0
 
 
 class BindyouravatarPipeline:
@@ -165,6 +225,7 @@ class BindyouravatarPipeline:
             id_cond = cfg_id_cond(id_cond, zero2cond_cfg_flag) if id_cond is not None else None
             af_matrix = cfg_af_matrix(af_matrix, zero2cond_cfg_flag) if af_matrix is not None else None
             audio_embs = cfg_audio(audio_embs) if audio_embs is not None else None
+        old_x0 = None
         for i, t in enumerate(ts):
             if self._interrupt:
                 continue
@@ -180,16 +241,25 @@ class BindyouravatarPipeline:
                        image_rotary_emb=rope, return_dict=False, id_vit_hidden=id_vit_hidden, id_cond=id_cond,
                        audio_embeds=audio_embs, af_matrix=af_matrix, denoise_step=i,
                        routing_logits_zeros_flag=routing_logits_zeros_flag,
-                       routing_logits_forcing=routing_logits_forcing)[0].float()
+                       routing_logits_forcing=routing_logits_forcing)[0]
             if tr._engine is not None:
                 tr._engine.cache_invariants = True           # conditioning does not change between steps
             if use_dynamic_cfg:
                 self._guidance_scale = 1 + guidance_scale * (
                     (1 - math.cos(math.pi * ((num_inference_steps - t.item()) / num_inference_steps) ** 5.0)) / 2)
-            if cfg:
-                u, c = noise.chunk(2)
-                noise = u + self.guidance_scale * (c - u)
-            latents = self.scheduler.step(noise, t, latents).to(dtype)
+            # CFG combine (fp32, [uncond, cond]) + scheduler step: one fused launch (ops.cfg_scheduler_step)
+            g = self.guidance_scale if cfg else 1.0
+            if isinstance(self.scheduler, DPMScheduler):
+                latents, old_x0 = self.scheduler.step(noise, old_x0, t, ts[i - 1] if i > 0 else None, latents,
+                                                      guidance=g, generator=generator)
+            elif isinstance(self.scheduler, DDIMScheduler):
+                latents = self.scheduler.step(noise, t, latents, guidance=g)
+            else:                                  # a scheduler object brought by the caller (diffusers API)
+                n32 = noise.float()
+                if cfg:
+                    u, c = n32.chunk(2)
+                    n32 = u + self.guidance_scale * (c - u)
+                latents = self.scheduler.step(n32, t, latents, return_dict=False)[0].to(dtype)
             if callback_on_step_end is not None:
                 kw = {k: locals()[k] for k in callback_on_step_end_tensor_inputs}
                 out = callback_on_step_end(self, i, t, kw)

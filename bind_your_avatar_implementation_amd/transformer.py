@@ -405,6 +405,13 @@ class BindyouravatarTransformer3DModel(nn.Module):
             self._engine = DenoiseEngine(self)
         args = (hidden_states, encoder_hidden_states, timestep, image_rotary_emb, id_cond, id_vit_hidden,
                 audio_embeds, af_matrix, routing_logits_forcing)
+        cfg = getattr(self, "_cfg", None)
+        if cfg is not None and hidden_states.shape[0] == 2:
+            # CFG batch split: this rank computes one sample, the pair exchange restores the [uncond, cond] batch
+            rope, forcing = args[3], args[8]                        # shared by both samples, never sliced
+            loc = list(cfg.take(args))
+            loc[3], loc[8] = rope, forcing
+            return (cfg.join(self._engine.step(*loc)), None, None, None, None)
         if self.use_hip_graph and getattr(self, "_seq_world", 1) == 1 and torch.is_tensor(timestep):
             out = self._graphed_step(args)
         else:

@@ -178,6 +178,25 @@ int bya_unpatchify(const void* y, void* out, int32_t batch, int32_t frames, int3
 /* Elementwise helpers: y = act(x) (+ r) over n bf16 elements (n % 8 == 0). */
 int bya_act_add(const void* x, const void* r, void* y, int64_t n, int32_t act, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Classifier-free-guidance combine + scheduler step in one pass over the latents.
+ * Replaces models/pipeline_bindyouravatar.py:924-948: noise = u + g*(c - u) in fp32 on the bf16 prediction
+ * (n_pred = 2: [uncond, cond], second sample at pred + pred_stride; n_pred = 1: no guidance), then the
+ * v-prediction step of diffusers' CogVideoXDDIMScheduler / CogVideoXDPMScheduler:
+ *   x0   = bf16(sqrt_alpha * x) - sqrt_beta * noise_pred
+ *   d    = old_x0 ? k_cur * x0 - k_old * old_x0 : x0                (DPM second-order correction)
+ *   prev = bf16( (bf16(k_sample * x) - k_denoised * d) [+ bf16(k_noise * noise)] )
+ * DDIM: k_sample = a_t, k_denoised = -b_t, old_x0 = noise = NULL.  x0_out (fp32, optional) feeds the next DPM step.
+ * The bf16() roundings are where torch's type promotion rounds (0-dim coefficient x bf16 tensor).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct bya_sched_coef {
+    float guidance, sqrt_alpha, sqrt_beta, k_sample, k_denoised, k_noise, k_cur, k_old;
+} bya_sched_coef;
+
+int bya_cfg_scheduler_step(const void* pred, int32_t n_pred, int64_t pred_stride, const void* sample,
+                           const float* old_x0, const void* noise, void* prev_sample, float* x0_out,
+                           int64_t n, const bya_sched_coef* coef, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

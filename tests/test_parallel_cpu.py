@@ -95,3 +95,42 @@ def test_shard_geometry_single_process():
         assert covered == 17550
     with pytest.raises(ValueError):
         SeqShard(0, 3, 17776, 226)
+
+
+def _cfg_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bind_your_avatar_implementation_amd.parallel import CfgSplit, SeqShard
+        cs = CfgSplit(dist.group.WORLD)
+        assert cs.half == rank // (world // 2) and cs.half_size == world // 2
+        assert dist.get_world_size(cs.seq_group) == world // 2 and dist.get_world_size(cs.pair_group) == 2
+        torch.manual_seed(0)
+        batch = torch.randn(2, 3, 5)
+        nested = [batch, [batch + 1, (batch + 2, torch.arange(7.0))], None, 3]
+        mine = cs.take(nested)
+        assert torch.equal(mine[0], batch[cs.half:cs.half + 1]) and torch.equal(mine[1][1][0], batch[cs.half:cs.half + 1] + 2)
+        assert torch.equal(mine[1][1][1], torch.arange(7.0)) and mine[2] is None and mine[3] == 3
+        # each half computes f(sample) on its own (sequence-sharded inside the half when it has 2 ranks) ...
+        f = lambda x: x * 2 + 1
+        local = mine[0]
+        if cs.half_size > 1:
+            sh = SeqShard(dist.get_rank(cs.seq_group), cs.half_size, 4, 0, cs.seq_group)
+            rows = torch.randn(2, 4, 6)[cs.half]                  # same on every rank (seeded)
+            assert torch.equal(sh.gather_rows(rows[sh.r0:sh.r1].clone()), rows)
+        # ... and the pair exchange restores the [uncond, cond] batch on every rank
+        assert torch.equal(cs.join(f(local)), f(batch))
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cfg_split(world):
+    """CFG-batch split: 2 ranks = one sample each; 4 ranks = 2 x 2 with sequence sharding inside."""
+    port = 31500 + (os.getpid() % 2000) + world
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cfg_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}

@@ -29,23 +29,51 @@ def test_cfg_helpers_order_and_zeroing():
         cfg_id_cond(None)
 
 
-def test_ddim_scheduler_algebra():
+def test_scheduler_tables_and_oracle_algebra():
+    """Host side of the schedulers (tables, spacing, per-step scalars) + the oracle restatement's algebra; the
+    element-wise step itself is a HIP kernel and is checked against this oracle in the GPU suite."""
+    from oracle import scheduler as osch
+    from bind_your_avatar_implementation_amd.pipeline import DPMScheduler
     s = DDIMScheduler()
     ac = s.alphas_cumprod
-    assert ac.shape == (1000,) and torch.all(ac[1:] <= ac[:-1]) and ac[-1].abs() < 1e-6     # zero terminal SNR
+    assert ac.dtype == torch.float64 and torch.equal(ac, osch.alphas_cumprod())
+    assert ac.shape == (1000,) and torch.all(ac[1:] <= ac[:-1]) and ac[-1].abs() < 1e-12    # zero terminal SNR
     ts = s.set_timesteps(50)
     assert ts[0] == 999 and ts[-1] == 19 and len(ts) == 50                                  # trailing spacing
-    # v-prediction consistency: if v is the true velocity of (x0, eps), one step lands on the exact DDIM point
-    x0, eps = torch.randn(2, 3, 4), torch.randn(2, 3, 4)
+    assert torch.equal(ts, osch.trailing_timesteps(1000, 50))
+    # v-prediction consistency of the oracle: the true velocity of (x0, eps) lands on the exact DDIM point
+    o = osch.DDIM()
+    o.set_timesteps(50)
+    x0, eps = torch.randn(2, 3, 4, dtype=torch.float64), torch.randn(2, 3, 4, dtype=torch.float64)
     t = int(ts[10])
-    a_t = ac[t]
+    a_t, a_p = ac[t], ac[t - 20]
     x_t = a_t.sqrt() * x0 + (1 - a_t).sqrt() * eps
     v = a_t.sqrt() * eps - (1 - a_t).sqrt() * x0
-    prev = s.step(v, t, x_t)
-    a_p = ac[t - 20]
-    assert torch.allclose(prev, a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps, atol=1e-5)
-    last = s.step(v, 19, x_t)            # previous timestep < 0 -> alpha = 1 -> returns x0 of that prediction
-    assert torch.isfinite(last).all()
+    assert torch.allclose(o.step(v, t, x_t), a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps, atol=1e-12)
+    # the product's coefficients are the oracle's scalars
+    c = s.coefficients(t, guidance=6.0)
+    a = ((1 - a_p) / (1 - a_t)) ** 0.5
+    assert float(c["k_sample"]) == float(a) and float(c["k_denoised"]) == -float(a_p ** 0.5 - a_t ** 0.5 * a)
+    assert float(c["sqrt_alpha"]) == float(a_t ** 0.5) and c["guidance"] == 6.0
+    last = s.coefficients(19)                                   # previous timestep < 0 -> alpha_prev = 1 -> prev = x0
+    assert float(last["k_sample"]) == 0.0 and abs(float(last["k_denoised"]) + 1.0) < 1e-12
+    # DPM: first-order on the first and last step, second-order (k_cur - k_old = 1) in between; with zero injected
+    # noise weight the first-order update is the DDIM point
+    d = DPMScheduler()
+    d.set_timesteps(50)
+    c1, second = d.coefficients(999, None, have_old=False)
+    assert not second and c1["k_cur"] == 1.0 and c1["k_old"] == 0.0
+    c2, second = d.coefficients(int(ts[10]), int(ts[9]))
+    assert second and abs(float(c2["k_cur"]) - float(c2["k_old"]) - 1.0) < 1e-12 and float(c2["k_noise"]) > 0
+    cl, second = d.coefficients(19, 39)
+    assert not second
+    od = osch.DPM()
+    od.set_timesteps(50)
+    prev, x0_hat = od.step(v, None, t, None, x_t, torch.zeros_like(x_t))
+    assert torch.allclose(x0_hat, x0, atol=1e-12)
+    h = ((a_p / (1 - a_p)) ** 0.5).log() - ((a_t / (1 - a_t)) ** 0.5).log()
+    expect = ((1 - a_p) / (1 - a_t)) ** 0.5 * (-h).exp() * x_t - (-2 * h).expm1() * a_p ** 0.5 * x0
+    assert torch.allclose(prev, expect, atol=1e-12)
 
 
 def test_pipeline_rejects_out_of_scope_inputs():
