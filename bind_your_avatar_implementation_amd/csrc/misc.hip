@@ -281,6 +281,57 @@ cfg_sched_kernel(const bf16_t* __restrict__ pred, long long pred_stride, int n_p
     }
 }
 
+
+// ---- tracking masks -> routing_logits_forcing (reference util/utils.py:481-514, 871-936) ---------------------------
+// One thread per latent token.  For every identity: trilinear sample (align_corners = false) of the binary mask
+// video at the token's centre, in fp32 with torch's index / weight construction and evaluation order
+// (outer T, then H, innermost W; out = a * w0 + b * w1 per level), threshold 0.5; later identities overwrite earlier
+// ones; the token's row is one-hot (or all zero for background).
+struct Lin1 { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lin1 lin_index(int dst, int in_size, int out_size) {
+    Lin1 r;
+    if (in_size == out_size) { r.i0 = r.i1 = dst; r.w0 = 1.0f; r.w1 = 0.0f; return r; }
+    const float scale = (float)in_size / (float)out_size;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    r.i0 = (int)src;
+    r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+    float l1 = src - (float)r.i0;
+    l1 = fminf(fmaxf(l1, 0.0f), 1.0f);
+    r.w1 = l1;
+    r.w0 = 1.0f - l1;
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+masks_to_logits_kernel(const uint8_t* __restrict__ masks, bf16_t* __restrict__ out, int n_id, int Ti, int Hi, int Wi,
+                       int To, int Ho, int Wo) {
+    const long long n = (long long)To * Ho * Wo;
+    const long long tok = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tok >= n) return;
+    const int w = (int)(tok % Wo), h = (int)((tok / Wo) % Ho), t = (int)(tok / ((long long)Wo * Ho));
+    const Lin1 lt = lin_index(t, Ti, To), lh = lin_index(h, Hi, Ho), lw = lin_index(w, Wi, Wo);
+    int label = -1;
+    for (int id = 0; id < n_id; ++id) {
+        const uint8_t* m = masks + (long long)id * Ti * Hi * Wi;
+        auto px = [&](int tt, int hh, int ww) -> float { return m[((long long)tt * Hi + hh) * Wi + ww] > 0 ? 1.0f : 0.0f; };
+        auto row = [&](int tt, int hh) -> float {
+            float o = px(tt, hh, lw.i0) * lw.w0;
+            o += px(tt, hh, lw.i1) * lw.w1;
+            return o;
+        };
+        auto plane = [&](int tt) -> float {
+            float o = row(tt, lh.i0) * lh.w0;
+            o += row(tt, lh.i1) * lh.w1;
+            return o;
+        };
+        float v = plane(lt.i0) * lt.w0;
+        v += plane(lt.i1) * lt.w1;
+        if (v > 0.5f) label = id;
+    }
+    for (int id = 0; id < n_id; ++id) out[tok * n_id + id] = (id == label) ? (bf16_t)0x3F80 : (bf16_t)0;
+}
+
 }  // namespace
 
 extern "C" int bya_abi_version(void) { return 1; }
@@ -398,5 +449,16 @@ extern "C" int bya_cfg_scheduler_step(const void* pred, int32_t n_pred, int64_t 
     BYA_LAUNCH(cfg_sched_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)pred,
                (long long)pred_stride, n_pred, (const bf16_t*)sample, old_x0, (const bf16_t*)noise,
                (bf16_t*)prev_sample, x0_out, (long long)n, *coef);
+    return ok();
+}
+
+extern "C" int bya_masks_to_routing_logits(const void* masks, void* logits, int32_t n_id, int32_t in_frames,
+                                           int32_t in_h, int32_t in_w, int32_t frames, int32_t h, int32_t w,
+                                           hipStream_t stream) {
+    if (!masks || !logits || n_id <= 0 || in_frames <= 0 || in_h <= 0 || in_w <= 0 || frames <= 0 || h <= 0 || w <= 0)
+        return BYA_ERR_SHAPE;
+    const long long n = (long long)frames * h * w;
+    BYA_LAUNCH(masks_to_logits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint8_t*)masks,
+               (bf16_t*)logits, n_id, in_frames, in_h, in_w, frames, h, w);
     return ok();
 }

@@ -261,6 +261,28 @@ class DenoiseEngine:
         self._inv_cache[name] = (key, list(tensors), val)    # keep the inputs alive so pointers cannot be recycled
         return val
 
+    @torch.no_grad()
+    def precompute(self, id_cond=None, id_vit_hidden=None, audio_embeds=None, latent_frames=13):
+        """Explicit step-invariant cache: run the LocalFacialExtractor, every perceiver
+        ``to_kv`` / router ``to_k`` and the AudioProjModel + per-layer audio K/V ONCE for the given conditioning and
+        keep the results for every following ``step`` that is passed the same tensors (2.4 GB of ``conv1`` weight
+        traffic and ~0.3 TFLOP per step disappear; results are bit-identical to recomputation because the same
+        launches produce them).  ``release()`` drops the cache and returns to the reference's recompute-every-step."""
+        self.cache_invariants = True
+        self._inv_cache = {}
+        if self.m.is_train_face and id_cond is not None:
+            B = id_cond[0].shape[0]
+            flat = list(id_cond[:self.N_ID]) + [t for i in range(self.N_ID) for t in id_vit_hidden[i]]
+            self._cached("face", flat, lambda: self._face_invariants(id_cond, id_vit_hidden, B))
+        if self.m.is_train_audio and audio_embeds is not None:
+            self._cached("audio", [audio_embeds],
+                         lambda: self._audio_invariants(audio_embeds, latent_frames, audio_embeds.shape[0]))
+        return self
+
+    def release(self):
+        self.cache_invariants = False
+        self._inv_cache = {}
+
     # ------------------------------------------------------------------------------------------ the step
     @torch.no_grad()
     def step(self, hidden_states, encoder_hidden_states, timestep, image_rotary_emb, id_cond, id_vit_hidden,

@@ -323,3 +323,18 @@ def cfg_scheduler_step(pred, sample, coef, old_x0=None, noise=None, x0_out=None,
                                      ctypes.byref(c), _stream()), "bya_cfg_scheduler_step")
     _end(tok)
     return out
+
+
+def masks_to_routing_logits(masks, frames=13, h=30, w=45, out=None):
+    """Tracking masks uint8 [n_id, T, H, W] (> 0 = foreground) -> ``routing_logits_forcing`` bf16 [1, frames*h*w, n_id]
+    (reference util/utils.py:871-936; feed it to ``forward(routing_logits_forcing=...)``)."""
+    lib = _hip.load()
+    assert masks.dtype == torch.uint8 and masks.is_contiguous() and masks.dim() == 4
+    n_id, Ti, Hi, Wi = masks.shape
+    if out is None:
+        out = torch.empty(1, frames * h * w, n_id, dtype=torch.bfloat16, device=masks.device)
+    tok = _begin("bya_masks_to_routing_logits")
+    check(lib.bya_masks_to_routing_logits(_p(masks), _p(out), n_id, Ti, Hi, Wi, frames, h, w, _stream()),
+          "bya_masks_to_routing_logits")
+    _end(tok)
+    return out

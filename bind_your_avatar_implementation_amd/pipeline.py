@@ -62,6 +62,14 @@ def _alphas_cumprod(num_train_timesteps, beta_start, beta_end, snr_shift_scale):
     return s ** 2
 
 
+def get_routing_logits_from_masks(masks, latent_frames=13, height=60, width=90, patch=2):
+    """Stage-2 inference of the reference (infer.py:368-413 -> util/utils.py:871-936): per-identity tracking masks
+    ``uint8 [n_id, T, H, W]`` on the GPU -> ``routing_logits_forcing [1, N, n_id]`` for ``__call__`` / ``forward``.
+    Reading the PNG frames (``annotated_frame_%05d.png`` under ``<dir>/1``, ``<dir>/2``) stays with the caller."""
+    from . import ops
+    return ops.masks_to_routing_logits(masks.contiguous(), latent_frames, height // patch, width // patch)
+
+
 class _SchedulerBase:
     """Host side of a scheduler: float64 coefficient tables and per-step scalars.  The element-wise work (CFG combine
     + the step itself) runs in ONE HIP launch, ``ops.cfg_scheduler_step`` -- there is no torch implementation here."""
@@ -162,6 +170,10 @@ class BindyouravatarPipeline:
         self.vae_scale_factor_temporal = vae_scale_factor_temporal
         self._guidance_scale, self._interrupt, self._num_timesteps = 1.0, False, 0
 
+    def fuse_lora(self, lora_scale=1.0, **kw):
+        """diffusers pipeline API the reference calls (infer.py:279): fold the transformer's staged LoRA adapters."""
+        return self.transformer.fuse_lora(lora_scale)
+
     guidance_scale = property(lambda self: self._guidance_scale)
     num_timesteps = property(lambda self: self._num_timesteps)
     interrupt = property(lambda self: self._interrupt)
@@ -226,6 +238,8 @@ class BindyouravatarPipeline:
             af_matrix = cfg_af_matrix(af_matrix, zero2cond_cfg_flag) if af_matrix is not None else None
             audio_embs = cfg_audio(audio_embs) if audio_embs is not None else None
         old_x0 = None
+        # the identities and the audio do not change between steps: face tokens, audio context and their K/V once
+        tr.precompute_conditioning(id_cond, id_vit_hidden, audio_embs, lat_frames)
         for i, t in enumerate(ts):
             if self._interrupt:
                 continue
@@ -242,8 +256,6 @@ class BindyouravatarPipeline:
                        audio_embeds=audio_embs, af_matrix=af_matrix, denoise_step=i,
                        routing_logits_zeros_flag=routing_logits_zeros_flag,
                        routing_logits_forcing=routing_logits_forcing)[0]
-            if tr._engine is not None:
-                tr._engine.cache_invariants = True           # conditioning does not change between steps
             if use_dynamic_cfg:
                 self._guidance_scale = 1 + guidance_scale * (
                     (1 - math.cos(math.pi * ((num_inference_steps - t.item()) / num_inference_steps) ** 5.0)) / 2)
@@ -264,6 +276,7 @@ class BindyouravatarPipeline:
                 kw = {k: locals()[k] for k in callback_on_step_end_tensor_inputs}
                 out = callback_on_step_end(self, i, t, kw)
                 latents = out.pop("latents", latents)
+        tr.release_conditioning()
         if not return_dict:
             return (latents,)
         return SimpleNamespace(frames=latents)

@@ -341,6 +341,28 @@ class BindyouravatarTransformer3DModel(nn.Module):
         self.router.load_state_dict(torch.load(path, map_location=self.device), strict=strict)
         self.invalidate_engine()
 
+    @classmethod
+    def from_pretrained_cus(cls, pretrained_model_path, subfolder=None, config_path=None,
+                            transformer_additional_kwargs={}, device=None, dtype=torch.bfloat16):
+        """Reference models/transformer.py:1024-1093 (see ``weights.py``)."""
+        from .weights import from_pretrained_cus
+        return from_pretrained_cus(cls, pretrained_model_path, subfolder, config_path, transformer_additional_kwargs,
+                                   device=device, dtype=dtype)
+
+    def load_lora_weights(self, path_or_state):
+        """Stage rank-r adapters for ``attn1.to_q`` / ``attn1.to_k`` (reference util/utils.py:1027-1048); they take
+        effect when ``fuse_lora`` folds them into the base weights."""
+        from .weights import read_lora
+        self._pending_lora = getattr(self, "_pending_lora", []) + [read_lora(path_or_state)]
+        return self
+
+    def fuse_lora(self, lora_scale=1.0, lora_alpha=128):
+        """Reference infer.py:279 (``pipe.fuse_lora(lora_scale=1/lora_rank)``): fold every staged adapter."""
+        from .weights import fold_lora
+        n = sum(fold_lora(self, l, lora_scale, lora_alpha) for l in getattr(self, "_pending_lora", []))
+        self._pending_lora = []
+        return n
+
     def invalidate_engine(self):
         """Drop packed weights / workspaces / captured graphs (call after changing parameters in place)."""
         self._engine = None
@@ -417,6 +439,21 @@ class BindyouravatarTransformer3DModel(nn.Module):
         else:
             out = self._engine.step(*args)
         return (out, None, None, None, None)
+
+    # ---- explicit step-invariant conditioning cache ---------------------------------
+    def precompute_conditioning(self, id_cond=None, id_vit_hidden=None, audio_embeds=None, latent_frames=13):
+        """Compute everything that depends only on the identities / audio (not on the timestep or the latents) once;
+        later ``forward`` calls given the SAME tensors reuse it.  Call ``release_conditioning()`` to go back to the
+        reference behaviour (recompute every step)."""
+        if self._engine is None:
+            from .engine import DenoiseEngine
+            self._engine = DenoiseEngine(self)
+        self._engine.precompute(id_cond, id_vit_hidden, audio_embeds, latent_frames)
+        return self
+
+    def release_conditioning(self):
+        if self._engine is not None:
+            self._engine.release()
 
     # ---- hipGraph replay of the step ---------------------------------------------------------------------------
     @staticmethod

@@ -197,6 +197,13 @@ int bya_cfg_scheduler_step(const void* pred, int32_t n_pred, int64_t pred_stride
                            const float* old_x0, const void* noise, void* prev_sample, float* x0_out,
                            int64_t n, const bya_sched_coef* coef, hipStream_t stream);
 
+/* Tracking masks -> routing_logits_forcing (stage 2 of the reference inference; util/utils.py:481-514 resize_mask,
+ * :871-936 process_masks_to_routing_logits parts 2-3).  masks: uint8 [n_id, in_frames, in_h, in_w], > 0 = foreground;
+ * logits: bf16 [frames*h*w, n_id], one-hot per token (zero row = background), the LAST identity whose trilinearly
+ * resized (align_corners = false) mask exceeds 0.5 wins.  Index / threshold work: bit-exact against the reference. */
+int bya_masks_to_routing_logits(const void* masks, void* logits, int32_t n_id, int32_t in_frames, int32_t in_h,
+                                int32_t in_w, int32_t frames, int32_t h, int32_t w, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -325,14 +325,47 @@ def run_modules(seed):
     np.savez_compressed(os.path.join(HERE, f"ref_modules_seed{seed}.npz"), **fx)
 
 
+def run_masks(seed):
+    """Tracking masks -> routing_logits_forcing through the reference's own util/utils.py functions (PNG frames on
+    disk exactly as its stage-2 inference reads them).  Imports need stand-ins for three I/O-only packages."""
+    import tempfile
+    from PIL import Image
+    from mask_cases import synthetic_masks
+    for name in ("imageio", "spandrel"):
+        m = types.ModuleType(name)
+        m.ModelLoader = object
+        sys.modules[name] = m
+    sys.modules["diffusers.utils"].export_to_video = lambda *a, **k: None
+    import importlib
+    U = importlib.import_module("util.utils")
+    from oracle.masks import masks_to_routing_logits
+    fx = {}
+    for sd in (seed, seed + 1):
+        masks = synthetic_masks(sd)
+        with tempfile.TemporaryDirectory() as d:
+            for i in range(2):
+                os.makedirs(os.path.join(d, str(i + 1)))
+                for t in range(masks.shape[1]):
+                    Image.fromarray(masks[i, t]).save(os.path.join(d, str(i + 1), f"annotated_frame_{t:05d}.png"))
+            ref = U.process_masks_to_routing_logits(d)
+        orc = masks_to_routing_logits(torch.from_numpy(masks))
+        assert ref.shape == (1, 17550, 2) and torch.equal(ref, orc), "oracle differs from the reference"
+        print(f"masks seed {sd}: id1 {int(ref[0, :, 0].sum())} tokens, id2 {int(ref[0, :, 1].sum())} tokens", flush=True)
+        fx[f"logits.seed{sd}"] = np.packbits(ref[0].numpy().astype(np.uint8), axis=0)
+    np.savez_compressed(os.path.join(HERE, f"ref_masks_seed{seed}.npz"), **fx)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--case", default="base", choices=["base", "cfg_forcing", "modules"])
+    ap.add_argument("--case", default="base", choices=["base", "cfg_forcing", "modules", "masks"])
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
-    if a.case == "modules":
+    if a.case == "masks":
+        install_standins()
+        run_masks(a.seed)
+    elif a.case == "modules":
         run_modules(a.seed)
     else:
         run_case(a.case, a.layers, a.seed)

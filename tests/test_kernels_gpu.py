@@ -493,3 +493,27 @@ def test_cfg_dpm_steps_bit_exact(ops, dev):
         xr = pr.to(torch.bfloat16)
         assert torch.equal(x, xr), (i, float((x.float() - xr.float()).abs().max()))
         assert torch.equal(old, old_r), i
+
+
+# ----------------------------------------------------------------------------------------------- mask path
+def test_masks_to_routing_logits_bit_exact(ops, dev):
+    """Tracking masks -> forcing logits: bit-exact against the reference's own output (golden) at 49x480x720 and against
+    the oracle on ragged sizes (non-integer scales in every axis, identical sizes, single frame, 3 identities)."""
+    import os
+    import numpy as np
+    from golden.mask_cases import synthetic_masks
+    from oracle.masks import masks_to_routing_logits
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_masks_seed0.npz"))
+    for sd in (0, 1):
+        want = np.unpackbits(fx[f"logits.seed{sd}"], axis=0)[:17550]
+        got = ops.masks_to_routing_logits(torch.from_numpy(synthetic_masks(sd)).to(dev))
+        assert got.shape == (1, 17550, 2) and got.dtype == torch.bfloat16
+        assert np.array_equal(got[0].float().cpu().numpy().astype(np.uint8), want), sd
+    g = torch.Generator().manual_seed(3)
+    for (n_id, Ti, Hi, Wi, To, Ho, Wo) in [(2, 25, 100, 147, 7, 13, 21), (3, 13, 30, 45, 13, 30, 45), (2, 1, 64, 64, 1, 8, 8),
+                                           (2, 9, 31, 17, 13, 40, 23)]:
+        blobs = F.interpolate(torch.rand(n_id, 1, 3, 5, 6, generator=g), size=(Ti, Hi, Wi), mode="trilinear")[:, 0]
+        masks = ((blobs > 0.5) * 255).to(torch.uint8)
+        ref = masks_to_routing_logits(masks, To, Ho * 2, Wo * 2)
+        got = ops.masks_to_routing_logits(masks.to(dev), To, Ho, Wo)
+        assert torch.equal(got.float().cpu(), ref), (n_id, Ti, Hi, Wi)

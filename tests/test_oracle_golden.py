@@ -110,3 +110,17 @@ def test_full_forward_fixtures_are_present_and_sane():
         else:
             m = f["forcing_u8"]
             assert set(np.unique(m)) <= {0, 1} and m.shape == (1, 17550, 2)
+
+
+def test_mask_path_oracle_matches_reference_golden():
+    """oracle.masks vs the output of the reference's own util/utils.py functions on the seeded synthetic masks."""
+    import numpy as np
+    from golden.mask_cases import synthetic_masks
+    from oracle.masks import masks_to_routing_logits
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_masks_seed0.npz"))
+    for sd in (0, 1):
+        want = np.unpackbits(fx[f"logits.seed{sd}"], axis=0)[:17550]
+        got = masks_to_routing_logits(torch.from_numpy(synthetic_masks(sd)))
+        assert got.shape == (1, 17550, 2)
+        assert np.array_equal(got[0].numpy().astype(np.uint8), want)
+        assert want.sum(1).max() == 1 and 1000 < want.sum() < 6000          # one-hot rows, both people present
