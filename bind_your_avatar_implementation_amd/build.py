@@ -11,7 +11,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libbya_hip.so")
-SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "misc.hip", "router.hip"]
+SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "misc.hip", "router.hip", "rowgemm.hip"]
 
 
 def _hipcc():

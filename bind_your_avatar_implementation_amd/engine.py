@@ -102,6 +102,14 @@ class DenoiseEngine:
                     a = getattr(st, name)
                     packed[name] = (cat([a.to_q.weight, a.to_k.weight, a.to_v.weight]).contiguous(),
                                     cat([a.to_q.bias, a.to_k.bias, a.to_v.bias]).contiguous())
+                if r.feat_dim == 512 and os.environ.get("BYA_ROUTER_ROWGEMM", "1") != "0":
+                    # row-stationary K = 512 GEMMs: LayerNorm folded into the q|k|v / MLP weights (ops.pack_rowgemm512)
+                    for name, ln in (("spatial_attn", st.norm1), ("temporal_attn", st.norm2), ("multi_id_attn", st.norm3)):
+                        a = getattr(st, name)
+                        packed["rg_" + name] = (ops.pack_rowgemm512(*packed[name], ln.weight, ln.bias), ln.eps,
+                                                ops.pack_rowgemm512(a.to_out[0].weight, a.to_out[0].bias))
+                    packed["rg_mlp"] = (ops.pack_rowgemm512(st.mlp[0].weight, st.mlp[0].bias, st.norm4.weight, st.norm4.bias),
+                                        st.norm4.eps, ops.pack_rowgemm512(st.mlp[2].weight, st.mlp[2].bias))
                 self.r_qkv.append(packed)
             self.lfe_proj_t = m.local_facial_extractor.proj_out.t().contiguous()
         if m.is_train_audio:
@@ -498,6 +506,21 @@ class DenoiseEngine:
         ops.unpatchify(y, out)
         return out
 
+    def _r_lnlin(self, x, tmp, ln, pk, key, w, b, out, act=None):
+        """out = act(Linear(LayerNorm(x))) on router rows: one fused row GEMM when packed, else LN + GEMM."""
+        rg = pk.get(key)
+        if rg is not None:
+            return ops.rowgemm512(x, rg[0], out, act=act, eps=rg[1])
+        self._ln(x, tmp, ln)
+        return ops.gemm(tmp, w, out, bias=b, act=act)
+
+    def _r_linres(self, a, pk, key, lin, x):
+        """x += Linear(a) on router rows."""
+        rg = pk.get(key)
+        if rg is not None:
+            return ops.rowgemm512(a, rg[2], x, res=x)
+        return ops.gemm(a, lin.weight, x, bias=lin.bias, res=x)
+
     def _router(self, qp, kr, ca, B, T, per_frame, sh, taps):
         """MultiIPRouter.forward (models/router.py:364-411) on the perceiver's q (shared by both ids) and the
         pre-projected router keys.  Returns this rank's rows of the routing logits, [B, N_loc, n_id] (sigmoid)."""
@@ -527,31 +550,24 @@ class DenoiseEngine:
         heads = F // hd
         for st, pk in zip(r.spatial_temporal_layers, self.r_qkv):
             # 1. spatial: every (sample, id, frame) attends over its per_frame tokens
-            self._ln(rs2, rn, st.norm1)
-            ops.gemm(rn, pk["spatial_attn"][0], qkv, bias=pk["spatial_attn"][1])
+            self._r_lnlin(rs2, rn, st.norm1, pk, "rg_spatial_attn", *pk["spatial_attn"], qkv)
             ops.attention(qkv, qkv[:, F:], qkv[:, 2 * F:], ra, head_dim=hd, heads=heads, nb1=B * n_id * T, nb2=1,
                           Sq=per_frame, Skv=per_frame, q_strides=(per_frame * 3 * F, 0, 3 * F),
                           k_strides=(per_frame * 3 * F, 0, 3 * F), v_strides=(per_frame * 3 * F, 0, 3 * F),
                           o_strides=(per_frame * F, 0, F), scale=hd ** -0.5)
-            o = st.spatial_attn.to_out[0]
-            ops.gemm(ra, o.weight, rs2, bias=o.bias, res=rs2)
+            self._r_linres(ra, pk, "rg_spatial_attn", st.spatial_attn.to_out[0], rs2)
             # 2. temporal: every (sample, id, location) attends over its T frames
-            self._ln(rs2, rn, st.norm2)
-            ops.gemm(rn, pk["temporal_attn"][0], qkv, bias=pk["temporal_attn"][1])
+            self._r_lnlin(rs2, rn, st.norm2, pk, "rg_temporal_attn", *pk["temporal_attn"], qkv)
             ops.attn_tiny(qkv, qkv[:, F:], qkv[:, 2 * F:], ra, T, heads, B * n_id, per_frame, N, per_frame, 3 * F, F,
                           hd ** -0.5)
-            o = st.temporal_attn.to_out[0]
-            ops.gemm(ra, o.weight, rs2, bias=o.bias, res=rs2)
+            self._r_linres(ra, pk, "rg_temporal_attn", st.temporal_attn.to_out[0], rs2)
             # 3. multi-ID: every (sample, token) attends over the ids
-            self._ln(rs2, rn, st.norm3)
-            ops.gemm(rn, pk["multi_id_attn"][0], qkv, bias=pk["multi_id_attn"][1])
+            self._r_lnlin(rs2, rn, st.norm3, pk, "rg_multi_id_attn", *pk["multi_id_attn"], qkv)
             ops.attn_tiny(qkv, qkv[:, F:], qkv[:, 2 * F:], ra, n_id, heads, B, N, n_id * N, N, 3 * F, F, hd ** -0.5)
-            o = st.multi_id_attn.to_out[0]
-            ops.gemm(ra, o.weight, rs2, bias=o.bias, res=rs2)
+            self._r_linres(ra, pk, "rg_multi_id_attn", st.multi_id_attn.to_out[0], rs2)
             # 4. MLP (GELU erf)
-            self._ln(rs2, rn, st.norm4)
-            ops.gemm(rn, st.mlp[0].weight, rh, bias=st.mlp[0].bias, act="gelu_erf")
-            ops.gemm(rh, st.mlp[2].weight, rs2, bias=st.mlp[2].bias, res=rs2)
+            self._r_lnlin(rs2, rn, st.norm4, pk, "rg_mlp", st.mlp[0].weight, st.mlp[0].bias, rh, act="gelu_erf")
+            self._r_linres(rh, pk, "rg_mlp", st.mlp[2], rs2)
         logits = buf("r_logits", B, N, n_id)
         fp = r.final_proj[0]
         rs4 = rs2.view(B, n_id, N, F)
@@ -592,32 +608,25 @@ class DenoiseEngine:
         for bi, (st, pk) in enumerate(zip(r.spatial_temporal_layers, self.r_qkv)):
             # ---- frame-major: spatial attention over the per_frame tokens of each local (id, frame) pair
             xa2 = xa.view(RA, F)
-            self._ln(xa2, rn_a, st.norm1)
-            ops.gemm(rn_a, pk["spatial_attn"][0], qkv_a, bias=pk["spatial_attn"][1])
+            self._r_lnlin(xa2, rn_a, st.norm1, pk, "rg_spatial_attn", *pk["spatial_attn"], qkv_a)
             ops.attention(qkv_a, qkv_a[:, F:], qkv_a[:, 2 * F:], ra_a, head_dim=hd, heads=heads, nb1=rp.nPA, nb2=1,
                           Sq=per_frame, Skv=per_frame, q_strides=(per_frame * 3 * F, 0, 3 * F),
                           k_strides=(per_frame * 3 * F, 0, 3 * F), v_strides=(per_frame * 3 * F, 0, 3 * F),
                           o_strides=(per_frame * F, 0, F), scale=hd ** -0.5)
-            o = st.spatial_attn.to_out[0]
-            ops.gemm(ra_a, o.weight, xa2, bias=o.bias, res=xa2)
+            self._r_linres(ra_a, pk, "rg_spatial_attn", st.spatial_attn.to_out[0], xa2)
             # ---- location-major: temporal, multi-ID, MLP
             rp.a_to_b(xa, xb)
             xb2 = xb.view(RB, F)
-            self._ln(xb2, rn_b, st.norm2)
-            ops.gemm(rn_b, pk["temporal_attn"][0], qkv_b, bias=pk["temporal_attn"][1])
+            self._r_lnlin(xb2, rn_b, st.norm2, pk, "rg_temporal_attn", *pk["temporal_attn"], qkv_b)
             ops.attn_tiny(qkv_b, qkv_b[:, F:], qkv_b[:, 2 * F:], ra_b, T, heads, n_id, rp.nLB, T * rp.nLB, rp.nLB,
                           3 * F, F, hd ** -0.5)
-            o = st.temporal_attn.to_out[0]
-            ops.gemm(ra_b, o.weight, xb2, bias=o.bias, res=xb2)
-            self._ln(xb2, rn_b, st.norm3)
-            ops.gemm(rn_b, pk["multi_id_attn"][0], qkv_b, bias=pk["multi_id_attn"][1])
+            self._r_linres(ra_b, pk, "rg_temporal_attn", st.temporal_attn.to_out[0], xb2)
+            self._r_lnlin(xb2, rn_b, st.norm3, pk, "rg_multi_id_attn", *pk["multi_id_attn"], qkv_b)
             ops.attn_tiny(qkv_b, qkv_b[:, F:], qkv_b[:, 2 * F:], ra_b, n_id, heads, 1, T * rp.nLB, 0, T * rp.nLB, 3 * F, F,
                           hd ** -0.5)
-            o = st.multi_id_attn.to_out[0]
-            ops.gemm(ra_b, o.weight, xb2, bias=o.bias, res=xb2)
-            self._ln(xb2, rn_b, st.norm4)
-            ops.gemm(rn_b, st.mlp[0].weight, rh_b, bias=st.mlp[0].bias, act="gelu_erf")
-            ops.gemm(rh_b, st.mlp[2].weight, xb2, bias=st.mlp[2].bias, res=xb2)
+            self._r_linres(ra_b, pk, "rg_multi_id_attn", st.multi_id_attn.to_out[0], xb2)
+            self._r_lnlin(xb2, rn_b, st.norm4, pk, "rg_mlp", st.mlp[0].weight, st.mlp[0].bias, rh_b, act="gelu_erf")
+            self._r_linres(rh_b, pk, "rg_mlp", st.mlp[2], xb2)
             if bi + 1 < nblk:
                 rp.b_to_a(xb, xa)
         fp = r.final_proj[0]

@@ -338,3 +338,29 @@ def masks_to_routing_logits(masks, frames=13, h=30, w=45, out=None):
           "bya_masks_to_routing_logits")
     _end(tok)
     return out
+
+
+def pack_rowgemm512(weight, bias, ln_weight=None, ln_bias=None):
+    """Pack a [N, 512] Linear (optionally preceded by LayerNorm(512)) for ``rowgemm512``: gamma folded into the bf16
+    weight, its fp32 row sums, and the fp32 constant vector  W . beta + bias  (see include/bya.h)."""
+    w32 = weight.float()
+    b32 = bias.float() if bias is not None else torch.zeros(weight.shape[0], device=weight.device)
+    if ln_weight is None:
+        return dict(w=weight.to(torch.bfloat16).contiguous(), colsum=None, cvec=b32.contiguous(), ln=False)
+    wg = (w32 * ln_weight.float()[None, :]).to(torch.bfloat16).contiguous()
+    return dict(w=wg, colsum=wg.float().sum(1).contiguous(), cvec=(w32 @ ln_bias.float() + b32).contiguous(), ln=True)
+
+
+def rowgemm512(x, pack, out, res=None, act=None, eps=1e-5, nsplit=0):
+    """out = res + act( LN?(x) @ W.T + b ) for K = 512 (router projections, reference models/router.py:468-493)."""
+    lib = _hip.load()
+    M, K = x.shape
+    N = pack["w"].shape[0]
+    assert K == 512 and x.stride(1) == 1 and out.stride(1) == 1 and out.shape == (M, N)
+    assert res is None or (res.shape == out.shape and res.stride(1) == 1)
+    tok = _begin("bya_rowgemm512", 2.0 * M * N * K)
+    check(lib.bya_rowgemm512(_p(x), _p(pack["w"]), _p(pack["colsum"]), _p(pack["cvec"]), _p(res), _p(out), M, N,
+                             x.stride(0), out.stride(0), res.stride(0) if res is not None else 0, int(pack["ln"]),
+                             float(eps), ACT[act], int(nsplit), _stream()), "bya_rowgemm512")
+    _end(tok)
+    return out

@@ -179,6 +179,24 @@ int bya_unpatchify(const void* y, void* out, int32_t batch, int32_t frames, int3
 int bya_act_add(const void* x, const void* r, void* y, int64_t n, int32_t act, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Row-stationary GEMM for K = 512 with optional fused LayerNorm, GELU(erf) and residual:
+ *     C[M,N] = res + act( LN?(X)[M,512] . W[N,512]^T + bias )
+ * Replaces, inside every SpatialTemporalAttentionBlock of the Embedding Router (models/router.py:468-493), the
+ * pairs  nn.LayerNorm -> to_q|to_k|to_v  and  nn.LayerNorm -> mlp[0] -> GELU  (ln = 1) and the to_out / mlp[2]
+ * projections with their residual adds (ln = 0, res = X of the block).
+ * ln = 1: W must be the gamma-folded weight  Wg[n,k] = W[n,k] * gamma[k]  (bf16),  colsum[n] = sum_k Wg[n,k]  (fp32),
+ *         cvec[n] = sum_k W[n,k] * beta[k] + bias[n]  (fp32);  the kernel computes the row mean / rstd itself and
+ *         applies  rstd * (x . Wg^T - mean * colsum) + cvec.
+ * ln = 0: W as is, cvec = bias (fp32), colsum ignored.
+ * X: bf16 rows of 512 with row stride ldx; C / res: bf16 with row strides ldc / ldres (C may alias res).
+ * N % (64 * nsplit) == 0; nsplit <= 0 lets the library choose how many column groups share a row block.
+ * act: BYA_ACT_NONE or BYA_ACT_GELU_ERF.
+ * --------------------------------------------------------------------------------------------- */
+int bya_rowgemm512(const void* X, const void* W, const float* colsum, const float* cvec, const void* res, void* C,
+                   int32_t M, int32_t N, int32_t ldx, int32_t ldc, int32_t ldres, int32_t ln, float eps, int32_t act,
+                   int32_t nsplit, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Classifier-free-guidance combine + scheduler step in one pass over the latents.
  * Replaces models/pipeline_bindyouravatar.py:924-948: noise = u + g*(c - u) in fp32 on the bf16 prediction
  * (n_pred = 2: [uncond, cond], second sample at pred + pred_stride; n_pred = 1: no guidance), then the
