@@ -3,7 +3,7 @@
 
 The reference has no inference parallelism at all; this is new capability required by
 BASELINE.json.  Partition: the joint sequence ``[text (Tt) | video (N)]`` of S = Tt + N rows is cut into ``world``
-equal contiguous row ranges (S = 17776 divides by 2, 4 and 8).  Everything on the path is row-local EXCEPT:
+contiguous row ranges of equal size (S = 17776 divides by 2, 4 and 8) or sizes differing by one row (other geometries).  Everything on the path is row-local EXCEPT:
 
   * joint self-attention: every rank needs all keys/values -> one all-gather of K and one of V per layer
     (``gather_rows``), queries stay local;
@@ -30,11 +30,16 @@ class SeqShard:
     group: object = None
 
     def __post_init__(self):
-        if self.S % self.world:
-            raise ValueError(f"sequence length {self.S} is not divisible by {self.world} ranks")
-        self.S_loc = self.S // self.world
-        self.r0, self.r1 = self.rank * self.S_loc, (self.rank + 1) * self.S_loc
-        if self.world > 1 and self.Tt > self.S_loc:
+        # contiguous row ranges whose sizes differ by at most one (17776 = 8 * 2222 divides exactly; the 720x1280
+        # geometry of BASELINE config 3, S = 47026, does not)
+        base, extra = divmod(self.S, self.world)
+        self.sizes = [base + (1 if j < extra else 0) for j in range(self.world)]
+        self.starts = [sum(self.sizes[:j]) for j in range(self.world)]
+        self.even = extra == 0
+        self.S_loc, self.S_max = self.sizes[self.rank], max(self.sizes)
+        self.r0 = self.starts[self.rank]
+        self.r1 = self.r0 + self.S_loc
+        if self.world > 1 and self.Tt > self.sizes[0]:
             raise ValueError("text rows must fit inside the first rank's shard")
         self.Tt_loc = max(0, min(self.Tt, self.r1) - self.r0)          # local text rows (rank 0 only)
         self.v0 = max(self.r0, self.Tt) - self.Tt                      # first local video token (global index)
@@ -53,18 +58,39 @@ class SeqShard:
         else:
             dist.all_gather_into_tensor(out, local, group=self.group)
 
+    def _gather_padded(self, local):
+        """[C, S_loc, F] per rank (S_loc may differ by one) -> [C, S, F]: equal-size all-gather of S_max-row pads."""
+        C, _, F = local.shape
+        if self.even:
+            pad = local.contiguous()
+        else:
+            pad = local.new_zeros(C, self.S_max, F)
+            pad[:, :self.S_loc] = local
+        full = torch.empty(self.world * C, self.S_max, F, dtype=local.dtype, device=local.device)
+        self._all_gather(full, pad)                                       # rank-major concatenation along dim 0
+        full = full.view(self.world, C, self.S_max, F)
+        if self.even:
+            return full.permute(1, 0, 2, 3).reshape(C, self.S, F)
+        return torch.cat([full[j, :, :n] for j, n in enumerate(self.sizes)], dim=1)
+
     def gather_rows(self, local, out=None):
-        """[S_loc, F] (every rank the same shape) -> [S, F], rank-major == global row order."""
+        """[S_loc, F] per rank -> [S, F], rank-major == global row order."""
         if self.world == 1:
             return local
-        if out is None:
-            out = torch.empty(self.S, *local.shape[1:], dtype=local.dtype, device=local.device)
-        self._all_gather(out, local.contiguous())
-        return out
+        if self.even:
+            if out is None:
+                out = torch.empty(self.S, *local.shape[1:], dtype=local.dtype, device=local.device)
+            self._all_gather(out, local.contiguous())
+            return out
+        res = self._gather_padded(local.reshape(1, self.S_loc, -1))[0].reshape(self.S, *local.shape[1:])
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     def gather_video_rows(self, local_video, scratch=None):
         """[..., N_loc, F] per rank (rank 0 owns fewer video rows: its shard starts with the text rows)
-        -> [..., N, F].  Implemented as an equal-size row all-gather of Tt_loc junk rows + the video rows."""
+        -> [..., N, F].  Implemented as a row all-gather of Tt_loc junk rows + the video rows."""
         if self.world == 1:
             return local_video
         lead = local_video.shape[:-2]
@@ -75,36 +101,40 @@ class SeqShard:
         pad[:, self.Tt_loc:] = flat
         if self.Tt_loc:
             pad[:, :self.Tt_loc] = 0
-        full = torch.empty(self.world * C, self.S_loc, F, dtype=flat.dtype, device=flat.device)
-        self._all_gather(full, pad)                                       # rank-major concatenation along dim 0
-        full = full.view(self.world, C, self.S_loc, F).permute(1, 0, 2, 3).reshape(C, self.S, F)[:, self.Tt:]
+        full = self._gather_padded(pad)[:, self.Tt:]
         return full.reshape(*lead, self.N, F).contiguous()
 
     # ---- head-parallel ("Ulysses") exchange for the joint self-attention ---------------------------------------
     # All-gathering K and V replicates 2*S*D elements onto every rank (191 MB received per rank and layer at 8 GPUs);
     # trading rows for heads moves every element of q, k, v (and of the output) exactly once: 48 MB per rank and layer.
-    def _a2a_equal(self, out, inp):
+    def _a2a(self, out, inp, out_splits=None, in_splits=None):
         if inp.is_cuda and dist.get_backend(self.group) == "gloo":
             host = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(host, inp.cpu(), group=self.group)
+            dist.all_to_all_single(host, inp.cpu(), out_splits, in_splits, group=self.group)
             out.copy_(host)
         else:
-            dist.all_to_all_single(out, inp, group=self.group)
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
     def rows_to_heads(self, blocks, out=None):
         """blocks [world, S_loc, Dl]: this rank's rows, column block j = the heads owned by rank j
         -> [S, Dl]: ALL rows (global order) of this rank's heads."""
         W, S_loc, Dl = blocks.shape
         if out is None:
-            out = torch.empty(W * S_loc, Dl, dtype=blocks.dtype, device=blocks.device)
-        self._a2a_equal(out.view(-1), blocks.reshape(-1))
+            out = torch.empty(self.S, Dl, dtype=blocks.dtype, device=blocks.device)
+        if self.even:
+            self._a2a(out.view(-1), blocks.reshape(-1))
+        else:
+            self._a2a(out.view(-1), blocks.reshape(-1), [n * Dl for n in self.sizes], [S_loc * Dl] * W)
         return out
 
     def heads_to_rows(self, o_heads, out=None):
         """o_heads [S, Dl] (all rows, this rank's heads) -> [S_loc, world*Dl] (this rank's rows, all heads)."""
         S, Dl = o_heads.shape
         recv = torch.empty(self.world, self.S_loc, Dl, dtype=o_heads.dtype, device=o_heads.device)
-        self._a2a_equal(recv.view(-1), o_heads.reshape(-1))
+        if self.even:
+            self._a2a(recv.view(-1), o_heads.reshape(-1))
+        else:
+            self._a2a(recv.view(-1), o_heads.reshape(-1), [self.S_loc * Dl] * self.world, [n * Dl for n in self.sizes])
         res = recv.permute(1, 0, 2).reshape(self.S_loc, self.world * Dl)
         if out is not None:
             out.copy_(res)

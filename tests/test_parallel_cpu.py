@@ -20,7 +20,7 @@ def _worker(rank, world, port, S, Tt, per_frame, ret):
         H, D = 4, 16
         sh = SeqShard(rank, world, S, Tt, dist.group.WORLD)
         N = S - Tt
-        assert sh.r1 - sh.r0 == S // world and sh.N_loc == sh.v1 - sh.v0
+        assert sh.r1 - sh.r0 in (S // world, S // world + 1) and sh.N_loc == sh.v1 - sh.v0
         assert (sh.Tt_loc == Tt) == (rank == 0)
         # exchange A: K/V all-gather + local queries == full attention on the local rows
         q, k, v = (torch.randn(S, H * D) for _ in range(3))
@@ -73,10 +73,10 @@ def _worker(rank, world, port, S, Tt, per_frame, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("S,Tt,per_frame", [(64, 10, 9), (17776, 226, 1350)])
+@pytest.mark.parametrize("S,Tt,per_frame", [(64, 10, 9), (17776, 226, 1350), (65, 10, 11), (47027, 227, 3600)])
 def test_sequence_shard_world2(S, Tt, per_frame):
     world = 2
-    port = 29500 + (os.getpid() % 2000) + (0 if S == 64 else 1)
+    port = 29500 + (os.getpid() % 2000) + S % 7
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, S, Tt, per_frame, ret), nprocs=world, join=True)
@@ -93,8 +93,12 @@ def test_shard_geometry_single_process():
             covered += sh.N_loc
             assert sh.Tt_loc == (226 if r == 0 else 0)
         assert covered == 17550
+    # uneven geometry (49 x 720 x 1280: 46800 tokens + 226 text rows over 8 ranks): sizes differ by at most one row
+    sizes = [SeqShard(r, 8, 47026, 226).S_loc for r in range(8)]
+    assert sum(sizes) == 47026 and max(sizes) - min(sizes) == 1
+    assert sum(SeqShard(r, 8, 47026, 226).N_loc for r in range(8)) == 46800
     with pytest.raises(ValueError):
-        SeqShard(0, 3, 17776, 226)
+        SeqShard(0, 128, 17776, 226)              # the text rows no longer fit into rank 0's shard
 
 
 def _cfg_worker(rank, world, port, ret):
