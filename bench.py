@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N = 1)")
+    ap.add_argument("--latent-hw", type=int, nargs=2, default=[60, 90], metavar=("H", "W"),
+                    help="latent height / width; anything but 60 90 (= 480x720) is not the headline config")
+    ap.add_argument("--batch", type=int, default=1, help="2 = the CFG pair of BASELINE config 3 (not the headline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,12 +100,16 @@ def main():
     from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel, ops
     from bind_your_avatar_implementation_amd.synth import synth_inputs
 
-    kw = dict(MODEL_KW, num_layers=args.layers)
+    lh, lw = args.latent_hw
+    kw = dict(MODEL_KW, num_layers=args.layers, sample_height=lh, sample_width=lw)
     model = BindyouravatarTransformer3DModel(**kw, device=dev).init_synthetic(seed=0, fast=True)
     if world > 1:
-        from bind_your_avatar_implementation_amd.parallel import shard_sequence
-        shard_sequence(model, dist.group.WORLD)
-    inp = synth_inputs(batch=1, seed=0, device="cpu")
+        from bind_your_avatar_implementation_amd.parallel import shard_cfg, shard_sequence
+        if args.batch == 2:
+            shard_cfg(model, dist.group.WORLD)          # [uncond, cond] on two halves of the ranks
+        else:
+            shard_sequence(model, dist.group.WORLD)
+    inp = synth_inputs(batch=args.batch, height=lh, width=lw, seed=0, device="cpu", uncond_first=args.batch == 2)
     inp = {k: (v.to(dev, torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else
                (v.to(dev) if torch.is_tensor(v) else v)) for k, v in inp.items()}
     inp["image_rotary_emb"] = tuple(t.to(dev, torch.float32) for t in inp["image_rotary_emb"])
@@ -145,6 +152,7 @@ def main():
         torch.cuda.synchronize()
         ktimes = ops.collect_kernel_timers()
 
+    headline = (lh, lw) == (60, 90) and args.batch == 1
     if rank == 0:
         sec_per_step = dt / args.steps
         value = 1.0 / sec_per_step
@@ -153,10 +161,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "latent_frames_per_sec": 13 * value,
-            "mfma_roofline_frac_whole_step": TFLOP_PER_STEP * (args.layers / 42) * value / (world * PEAK_BF16_TFLOPS),
-            "config": {"workload": "BASELINE.json configs[1]: full transformer.forward, 49x480x720 (13x30x45 latent "
-                                   "tokens + 226 text), 2 characters (2 ID + 2 audio), batch 1, random-init 8.6B-param "
-                                   "architecture", "layers": args.layers, "tokens": 17776,
+            "mfma_roofline_frac_whole_step": (TFLOP_PER_STEP * (args.layers / 42) * value / (world * PEAK_BF16_TFLOPS)
+                                              if headline else None),
+            "config": {"workload": ("BASELINE.json configs[1]: full transformer.forward, 49x480x720 (13x30x45 latent "
+                                    "tokens + 226 text), 2 characters (2 ID + 2 audio), batch 1, random-init 8.6B-param "
+                                    "architecture") if headline else
+                                   (f"NOT the headline config: full transformer.forward, 49x{lh * 8}x{lw * 8} "
+                                    f"(13x{lh // 2}x{lw // 2} latent tokens + 226 text), 2 characters, batch {args.batch}"), "layers": args.layers, "tokens": 226 + 13 * (lh // 2) * (lw // 2), "batch": args.batch,
                        "launch": "hipGraph replay" if (args.graph and world == 1) else "eager",
                        "parallelism": "single GPU" if world == 1 else f"sequence-parallel x{world} (K/V all-gather)"},
         }
@@ -167,7 +178,10 @@ def main():
             attn = [t for t in ktimes.get("bya_attn_fwd:joint", [])]
             if attn:
                 avg = sum(attn) / len(attn)
-                ach = ATTN_TFLOP_PER_LAUNCH / world / avg
+                tokens = 226 + 13 * (lh // 2) * (lw // 2)
+                shards = world // 2 if (args.batch == 2 and world > 1) else world       # ranks sharing one sample's attention
+                per_launch = 4 * tokens ** 2 * 3072 / 1e12 * (args.batch if world == 1 else 1)
+                ach = per_launch / max(shards, 1) / avg
                 res["roofline"] = {"kernel": "attn_fwd_kernel<64> (joint 17776-token self-attention)",
                                    "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": attn_traffic(world),
