@@ -66,7 +66,8 @@ def attn_traffic(world):
     if world != 1 or not os.path.exists(path):
         return None
     with open(path) as f:
-        rec = json.load(f).get("attn_fwd_kernel_d64_prescaled")
+        d = json.load(f)
+        rec = d.get("attn_fwd_kernel_d64_bounded") or d.get("attn_fwd_kernel_d64_prescaled")
     return rec["hbm_bytes_per_launch"] if rec else None
 
 
@@ -182,7 +183,7 @@ def main():
                 shards = world // 2 if (args.batch == 2 and world > 1) else world       # ranks sharing one sample's attention
                 per_launch = 4 * tokens ** 2 * 3072 / 1e12 * (args.batch if world == 1 else 1)
                 ach = per_launch / max(shards, 1) / avg
-                res["roofline"] = {"kernel": "attn_fwd_kernel<64> (joint 17776-token self-attention)",
+                res["roofline"] = {"kernel": "attn_fwd_kernel_d64_bounded (joint 17776-token self-attention)",
                                    "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": attn_traffic(world),
                                    "avg_launch_ms": avg * 1e3, "launches": len(attn)}

@@ -25,7 +25,7 @@ class AttnDesc(_c.Structure):
                 ("k_s1", _i64), ("k_s2", _i64), ("k_row", _i64),
                 ("v_s1", _i64), ("v_s2", _i64), ("v_row", _i64),
                 ("o_s1", _i64), ("o_s2", _i64), ("o_row", _i64),
-                ("scale", _f32), ("scores_prescaled", _i32)]
+                ("scale", _f32), ("scores_prescaled", _i32), ("score_bound", _f32)]
 
 
 class SchedCoef(_c.Structure):

@@ -25,6 +25,7 @@ struct AttnArgs {
     long long q_s1, q_s2, q_row, k_s1, k_s2, k_row, v_s1, v_s2, v_row, o_s1, o_s2, o_row;
     float scale_log2;  // scale * log2(e)
     int prescaled;     // scores already in exp2 units (scale folded into k by the producer)
+    float score_bound; // > 0: |score| <= bound guaranteed by the caller -> static-offset softmax (no running maximum)
 };
 
 constexpr int KV_TILE = 64;
@@ -117,7 +118,13 @@ constexpr float RESCALE_THR = 6.0f;   // skip the O rescale while the running ma
 // (one extra v_mul per score).  Things tried and measured slower on MI355X (kept out of the tree): a 3-stage ring with
 // S(t+1) issued before softmax(t) at 2 waves/SIMD (884 vs 910 TFLOP/s), two 32-row query blocks per wave sharing the
 // K/V fragments (884 vs 933), pre-scaling q in the kernel (faster, but the second rounding of q costs 1e-3 accuracy).
-template <int D, bool TAIL, bool PRESCALED>
+// BOUNDED (with PRESCALED): the caller guarantees |score| <= B in exp2 units (the engine derives B from the q/k
+// LayerNorm weights: ||LN(x) * gamma + beta|| <= 8 max|gamma| + ||beta||, RoPE is a rotation) and passes it in ``c``.
+// Softmax is shift-invariant and with B <= 48 nothing can overflow or vanish without a shift at all: every
+// P = exp2(s) lies in [2^-48, 2^48] (bf16 and fp32 share the 8-bit exponent; a row sum stays below 2^48 * Skv), so the
+// whole maximum machinery -- 16 v_max3, the lane swap, the ballot, the rescale path and the two extra MFMAs --
+// disappears from the tile and the score chains start from the MFMA's inline zero.
+template <int D, bool TAIL, bool PRESCALED, bool BOUNDED = false>
 __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase)[D / 32], const bf16x8 (&qf)[D / 16],
                                           f32x16 (&oacc)[D / 32], const bf16x8& ones, bf16x8& mfrag, float& m_run,
                                           float& l_run, bool first, int kv_valid, int r, int hf, float c) {
@@ -128,7 +135,7 @@ __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[u][i] = 0.f;
-        sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mfrag, sacc[u], 0, 0, 0);      // = -m_run everywhere
+        if (!BOUNDED) sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mfrag, sacc[u], 0, 0, 0);  // = -m_run everywhere
         const int krow = u * 32 + r;
 #pragma unroll
         for (int s = 0; s < DSTEPS; ++s) {
@@ -151,8 +158,9 @@ __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase
                 const int kv = u * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
                 if (kv >= kv_valid) sacc[u][i] = -INFINITY;
             }
-            mx = fmaxf(mx, sacc[u][i]);
+            if (!BOUNDED) mx = fmaxf(mx, sacc[u][i]);
         }
+    if (!BOUNDED) {
     {   // partner lane (lane ^ 32) holds the other 32 keys of this query row: one v_permlane32_swap, no LDS
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
         mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));        // row maximum RELATIVE to m_run
@@ -183,6 +191,7 @@ __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[u][i] -= delta;    // this tile's scores were taken against the old m_run
     }
+    }
     float psum = 0.f;
     bf16x8 pf[4];
 #pragma unroll
@@ -211,7 +220,7 @@ __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase
     pv_mfma<D>(fb, pf[3], oacc);
 }
 
-template <int D, bool PRESCALED>
+template <int D, bool PRESCALED, bool BOUNDED = false>
 __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
     constexpr int ROW_BYTES = D * 2;
     constexpr int TILE_BYTES = KV_TILE * ROW_BYTES;
@@ -321,7 +330,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+s"(tz));                       // opaque: keeps hipcc from peeling the first iteration
 #endif
-        attn_tile<D, false, PRESCALED>(kt, vbase, qf, oacc, ones, mfrag, m_run, l_run, tz == 0, KV_TILE, r, hf, p.scale_log2);
+        attn_tile<D, false, PRESCALED, BOUNDED>(kt, vbase, qf, oacc, ones, mfrag, m_run, l_run, tz == 0, KV_TILE, r, hf,
+                                                BOUNDED ? p.score_bound : p.scale_log2);
     }
     if (nfull < ntiles) {                                 // ragged last tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -330,8 +340,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
         uint32_t vbase[DT];
 #pragma unroll
         for (int d = 0; d < DT; ++d) vbase[d] = lds0 + (nfull & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
-        attn_tile<D, true, PRESCALED>(kt, vbase, qf, oacc, ones, mfrag, m_run, l_run, nfull == 0, p.Skv - nfull * KV_TILE, r, hf,
-                                       p.scale_log2);
+        attn_tile<D, true, PRESCALED, BOUNDED>(kt, vbase, qf, oacc, ones, mfrag, m_run, l_run, nfull == 0,
+                                               p.Skv - nfull * KV_TILE, r, hf, BOUNDED ? p.score_bound : p.scale_log2);
     }
 
     // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (r,hf) holds d = 32dt + (i&3) + 8(i>>2) + 4hf
@@ -362,6 +372,10 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel_d64_prescaled(AttnArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_fwd_body<64, true>(p, smem);
 }
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel_d64_bounded(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_fwd_body<64, true, true>(p, smem);
+}
 __global__ __launch_bounds__(256) void attn_fwd_kernel_d128(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_fwd_body<128, false>(p, smem);
@@ -372,7 +386,8 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
     const int nbh = a.nb1 * a.nb2 * a.heads;
     dim3 grid(nbh * a.nqt);
     const size_t lds = 4 * KV_TILE * D * 2;
-    if (D == 64 && a.prescaled) BYA_LAUNCH(attn_fwd_kernel_d64_prescaled, grid, dim3(256), lds, s, a);
+    if (D == 64 && a.prescaled && a.score_bound > 0.f) BYA_LAUNCH(attn_fwd_kernel_d64_bounded, grid, dim3(256), lds, s, a);
+    else if (D == 64 && a.prescaled) BYA_LAUNCH(attn_fwd_kernel_d64_prescaled, grid, dim3(256), lds, s, a);
     else if (D == 64) BYA_LAUNCH(attn_fwd_kernel_d64, grid, dim3(256), lds, s, a);
     else BYA_LAUNCH(attn_fwd_kernel_d128, grid, dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
@@ -400,5 +415,7 @@ extern "C" int bya_attn_fwd(const void* q, const void* k, const void* v, void* o
     a.scale_log2 = d->scale * 1.4426950408889634f;
     a.prescaled = d->scores_prescaled;
     if (a.prescaled && d->head_dim != 64) return BYA_ERR_UNSUPPORTED;
+    // a usable static bound keeps every P = exp2(s - B) >= 2^-96 (a bf16 normal); otherwise the running-max kernel runs
+    a.score_bound = (a.prescaled && d->score_bound > 0.f && d->score_bound <= 48.f) ? d->score_bound : 0.f;
     return d->head_dim == 64 ? launch_attn<64>(a, stream) : launch_attn<128>(a, stream);
 }

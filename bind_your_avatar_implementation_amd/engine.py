@@ -57,6 +57,15 @@ class DenoiseEngine:
         self.mix_before_projection = os.environ.get("BYA_MIX_BEFORE_PROJECTION", "1") != "0"
         self._inv_cache = {}
         self._ws_key, self._ws = None, None
+        # |q.k| * k_scale <= (8 max|gamma_q| + ||beta_q||)(8 max|gamma_k| + ||beta_k||) * k_scale for q, k out of
+        # LayerNorm(64) (||x_hat|| <= 8) followed by RoPE (a rotation); 2 % slack for the bf16 roundings of q and k.
+        # bya_attn_fwd uses the bound as a static softmax offset when it is small enough (include/bya.h).
+        self.score_bound = []
+        for blk in model.transformer_blocks:
+            nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
+            bq = 8.0 * nq.weight.float().abs().max().item() + nq.bias.float().norm().item()
+            bk = 8.0 * nk.weight.float().abs().max().item() + nk.bias.float().norm().item()
+            self.score_bound.append(1.02 * bq * bk * self.k_scale if os.environ.get("BYA_ATTN_BOUNDED", "1") != "0" else 0.0)
         if model.is_train_audio and not model.is_train_face:
             raise RuntimeError("audio injection needs the face router's logits (models/transformer.py:860)")
         self._pack()
@@ -399,7 +408,8 @@ class DenoiseEngine:
                         sh.rows_to_heads(qkvb[:W], qh)
                         sh.rows_to_heads(qkvb[W:2 * W], kh)
                         sh.rows_to_heads(qkvb[2 * W:], vh)
-                        ops.self_attention(qh[None], kh[None], vh[None], oh[None], heads=H // W, tag="joint", prescaled=True)
+                        ops.self_attention(qh[None], kh[None], vh[None], oh[None], heads=H // W, tag="joint", prescaled=True,
+                                           score_bound=self.score_bound[i])
                         sh.heads_to_rows(oh, xn[0])
                         ops.gemm(xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
                                  gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
@@ -411,9 +421,11 @@ class DenoiseEngine:
                     if sh.world > 1:      # exchange A (fallback when heads % world != 0): all-gather K and V
                         sh.gather_rows(k[0], k_full[0])
                         sh.gather_rows(v[0], v_full[0])
-                        ops.self_attention(q, k_full, v_full, xn, heads=H, tag="joint", prescaled=True)
+                        ops.self_attention(q, k_full, v_full, xn, heads=H, tag="joint", prescaled=True,
+                                           score_bound=self.score_bound[i])
                     else:
-                        ops.self_attention(q, k, v, xn, heads=H, tag="joint", prescaled=True)
+                        ops.self_attention(q, k, v, xn, heads=H, tag="joint", prescaled=True,
+                                           score_bound=self.score_bound[i])
                     ops.gemm(xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
                              gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                 else:

@@ -170,7 +170,7 @@ def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6, k_sc
 
 
 def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_strides, v_strides, o_strides,
-              scale, tag="other", prescaled=False):
+              scale, tag="other", prescaled=False, score_bound=0.0):
     """Flash attention with explicit (level-1, level-2, row) element strides for q, k, v, out."""
     lib = _hip.load()
     d = AttnDesc()
@@ -181,6 +181,7 @@ def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_
     d.o_s1, d.o_s2, d.o_row = o_strides
     d.scale = float(scale)
     d.scores_prescaled = int(prescaled)
+    d.score_bound = float(score_bound)
     for t in (q, k, v, out):
         assert t.dtype == torch.bfloat16 and t.is_cuda
     tok = _begin("bya_attn_fwd:" + tag, 4.0 * nb1 * nb2 * heads * Sq * Skv * head_dim)
@@ -189,7 +190,7 @@ def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_
     return out
 
 
-def self_attention(q, k, v, out, heads, head_dim=64, scale=None, tag="other", prescaled=False):
+def self_attention(q, k, v, out, heads, head_dim=64, scale=None, tag="other", prescaled=False, score_bound=0.0):
     """q,k,v,out: [B, S, heads*head_dim] views (row-strided ok)."""
     b, S, _, q_bs, q_ld = _mat(q, "q")
     _, Skv, _, k_bs, k_ld = _mat(k, "k")
@@ -198,7 +199,7 @@ def self_attention(q, k, v, out, heads, head_dim=64, scale=None, tag="other", pr
     scale = head_dim ** -0.5 if scale is None else scale
     return attention(q, k, v, out, head_dim=head_dim, heads=heads, nb1=b, nb2=1, Sq=S, Skv=Skv,
                      q_strides=(q_bs, 0, q_ld), k_strides=(k_bs, 0, k_ld), v_strides=(v_bs, 0, v_ld),
-                     o_strides=(o_bs, 0, o_ld), scale=scale, tag=tag, prescaled=prescaled)
+                     o_strides=(o_bs, 0, o_ld), scale=scale, tag=tag, prescaled=prescaled, score_bound=score_bound)
 
 
 def attn_tiny(q, k, v, out, L, heads, n_outer, n_inner, outer_stride, seq_stride, ld_qkv, ld_o, scale):

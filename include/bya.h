@@ -119,6 +119,11 @@ typedef struct bya_attn_desc {
     float scale;
     int32_t scores_prescaled;   /* 1: q.k is already scale*log2(e)*(q.k) (folded into k upstream); scale is ignored;
                                    head_dim 64 only.  Saves one multiply per score in the VALU-bound softmax. */
+    float score_bound;          /* > 0 (with scores_prescaled): the caller GUARANTEES |score| <= score_bound in exp2
+                                   units for every (q, k) pair, e.g. because q and k come out of a LayerNorm with known
+                                   weights (||q|| <= 8 max|gamma| + ||beta|| at head_dim 64; RoPE is a rotation).  The
+                                   softmax then uses the constant bound instead of a running maximum (mathematically
+                                   identical, shift invariance) -- bounds above 48 are ignored.  0 = unknown. */
 } bya_attn_desc;
 
 int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya_attn_desc* desc,

@@ -486,6 +486,33 @@ def test_act_add(ops, dev):
     check(out, bf(F.gelu(x.float())).float() + r.float(), what="gelu+res")
 
 
+@pytest.mark.parametrize("S", [200, 1350, 4133])
+def test_attn_static_bound_softmax(ops, dev, S):
+    """score_bound: q and k with ||q|| <= 8, ||k|| <= 8 * k_scale (what LayerNorm(64) + RoPE guarantee), so every score is
+    within +-11.6 in exp2 units and the kernel may replace the running maximum by that constant.  Must agree with the
+    fp32 softmax like the running-max kernel does, including rows whose scores sit far below the bound."""
+    H, D = 4, 64
+    g = torch.Generator().manual_seed(S)
+    def unit_rows(scale_rows):
+        x = torch.randn(1, S, H, D, generator=g)
+        x = x / x.norm(dim=-1, keepdim=True) * 8.0 * scale_rows
+        return x
+    k_scale = D ** -0.5 * 1.4426950408889634
+    q = bf(unit_rows(torch.rand(1, S, H, 1, generator=g) * 0.9 + 0.1)).to(dev)        # some rows far below the bound
+    k32 = unit_rows(torch.ones(1, S, H, 1))
+    k = bf(k32 * k_scale).to(dev)                                                    # scale folded into k (prescaled)
+    v = rnd((1, S, H * D), dev, 3)
+    out = torch.empty(1, S, H * D, dtype=torch.bfloat16, device=dev)
+    bound = 1.02 * 64 * k_scale
+    ops.self_attention(q.view(1, S, H * D), k.view(1, S, H * D), v, out, heads=H, prescaled=True, score_bound=bound)
+    qf, kf, vf = (t_.float().view(1, S, H, D).transpose(1, 2) for t_ in (q, k, v))
+    ref = torch.softmax(qf @ kf.transpose(-1, -2) * math.log(2.0), dim=-1) @ vf
+    check(out.view(1, S, H, D).transpose(1, 2), ref, tol=ATTN_TOL, what=f"attention static bound S={S}")
+    out2 = torch.empty_like(out)
+    ops.self_attention(q.view(1, S, H * D), k.view(1, S, H * D), v, out2, heads=H, prescaled=True, score_bound=500.0)
+    check(out2.view(1, S, H, D).transpose(1, 2), ref, tol=ATTN_TOL, what="unusable bound -> running-max kernel")
+
+
 # ----------------------------------------------------------------------------------------------- CFG + scheduler step
 @pytest.mark.parametrize("cfg", [False, True])
 def test_cfg_ddim_step_bit_exact(ops, dev, cfg):
