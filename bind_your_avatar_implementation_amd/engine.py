@@ -302,8 +302,13 @@ class DenoiseEngine:
 
     # ------------------------------------------------------------------------------------------ the step
     @torch.no_grad()
-    def step(self, hidden_states, encoder_hidden_states, timestep, image_rotary_emb, id_cond, id_vit_hidden,
-             audio_embeds, af_matrix, routing_logits_forcing, taps=None):
+    def step(self, *args, **kwargs):
+        """One denoise step (see ``_step``); every launch of the step goes to the stream that is current at entry."""
+        with ops.pinned_stream():
+            return self._step(*args, **kwargs)
+
+    def _step(self, hidden_states, encoder_hidden_states, timestep, image_rotary_emb, id_cond, id_vit_hidden,
+              audio_embeds, af_matrix, routing_logits_forcing, taps=None):
         m, cfg, D, H, n_id = self.m, self.cfg, self.D, self.H, self.N_ID
         B, T, C, Hh, Ww = hidden_states.shape
         ht, wt = Hh // 2, Ww // 2
