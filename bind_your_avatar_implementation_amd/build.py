@@ -11,7 +11,9 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libbya_hip.so")
-SOURCES = ["gemm.hip", "attn.hip", "norm.hip", "misc.hip", "router.hip", "rowgemm.hip"]
+SOURCES = ["gemm.hip", "gemm_w4.hip", "attn.hip", "norm.hip", "misc.hip", "router.hip", "rowgemm.hip"]
+# translation units whose kernels keep their accumulators in AGPRs (one wave per SIMD, 512 registers)
+AGPR_SOURCES = {"gemm_w4.hip"}
 
 
 def _hipcc():
@@ -41,8 +43,8 @@ def build_hip_library(force=False, verbose=True):
         obj = os.path.join(build_dir, src.replace(".hip", ".o"))
         # -amdgpu-mfma-vgpr-form: MFMA results stay in arch VGPRs (gfx950's register file is unified), which removes
         # the v_accvgpr_read/write traffic hipcc otherwise inserts wherever VALU code touches an accumulator.
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-               "-c", os.path.join(CSRC, src), "-o", obj]
+        form = [] if src in AGPR_SOURCES else ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *form, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

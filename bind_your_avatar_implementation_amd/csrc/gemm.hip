@@ -12,28 +12,11 @@
 // block order for L2 reuse.  The MFMA is issued "swapped" (W rows as the A operand) so each lane ends
 // up with 4 consecutive output columns of one output row -> 8-byte epilogue accesses.
 // Epilogue: + bias -> activation -> * gate[row-type] -> + residual -> bf16.
-#include "bya_common.h"
-#include "../../include/bya.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 
 namespace {
 
-struct GemmArgs {
-    const bf16_t* A; const bf16_t* W; const bf16_t* bias; bf16_t* C; const bf16_t* res;
-    const bf16_t* gate0; const bf16_t* gate1;
-    int M, N, K;
-    int lda, ldw, ldc, ldres;
-    long long a_bs, c_bs, res_bs, gate_bs;
-    int gate_split;
-    int act;
-    float leaky;
-    int n_split;            // > 0: output column n goes to C + (n / n_split) * c_split_stride, column n % n_split
-    long long c_split_stride;
-    const float* bias_rowscale;   // optional fp32 [batch*M]: bias is multiplied by bias_rowscale[z*M + m]
-    float alpha;                  // scales (acc + bias) after the activation (local_face_scale)
-};
-
-constexpr int BK = 64;  // bf16 elements per K tile = 128-byte LDS rows
 
 template <int ROWS, int NWAVES>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int ld, int row0, int row_max, int k0,
@@ -55,54 +38,6 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int l
 __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int chunk) {
     const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
     return *reinterpret_cast<const bf16x8*>(tile + off);
-}
-
-template <int ACT>
-__device__ __forceinline__ float apply_act(float v, float leaky) {
-    if constexpr (ACT == 1) return gelu_tanh(v);
-    else if constexpr (ACT == 2) return gelu_erf(v);
-    else if constexpr (ACT == 3) return v > 0.f ? v : 0.f;
-    else if constexpr (ACT == 4) return silu(v);
-    else if constexpr (ACT == 5) return v > 0.f ? v : v * leaky;
-    else return v;
-}
-
-
-// Epilogue for 4 consecutive output columns n4..n4+3 of row m: + bias -> act -> * gate[row type] -> + residual -> bf16
-template <int V> struct IntTag { static constexpr int value = V; };
-template <typename F>
-__device__ __forceinline__ void dispatch_act(int act, F&& f) {
-    switch (act) {
-        case 1: f(IntTag<1>{}); break;
-        case 2: f(IntTag<2>{}); break;
-        case 3: f(IntTag<3>{}); break;
-        case 4: f(IntTag<4>{}); break;
-        case 5: f(IntTag<5>{}); break;
-        default: f(IntTag<0>{}); break;
-    }
-}
-
-template <int ACT>
-__device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n4, const f32x4 acc, const float (&b4)[4]) {
-    float v[4];
-    const float bs = p.bias_rowscale ? p.bias_rowscale[(long long)z * p.M + m] : 1.0f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = p.alpha * apply_act<ACT>(fmaf(bs, b4[e], acc[e]), p.leaky);
-    if (p.gate0) {
-        const bf16_t* g = (m < p.gate_split ? p.gate0 : p.gate1) + (long long)z * p.gate_bs + n4;
-        const u32x2 gv = *reinterpret_cast<const u32x2*>(g);
-        v[0] *= bflo(gv[0]); v[1] *= bfhi(gv[0]); v[2] *= bflo(gv[1]); v[3] *= bfhi(gv[1]);
-    }
-    long long col = n4;
-    if (p.n_split > 0) col = (long long)(n4 / p.n_split) * p.c_split_stride + (n4 % p.n_split);
-    if (p.res) {
-        const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + (long long)z * p.res_bs + (long long)m * p.ldres + n4);
-        v[0] += bflo(rv[0]); v[1] += bfhi(rv[0]); v[2] += bflo(rv[1]); v[3] += bfhi(rv[1]);
-    }
-    u32x2 o;
-    o[0] = pack2bf(v[0], v[1]);
-    o[1] = pack2bf(v[2], v[3]);
-    *reinterpret_cast<u32x2*>(p.C + (long long)z * p.c_bs + (long long)m * p.ldc + col) = o;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -214,10 +149,6 @@ struct FragB { bf16x8 v[2]; };   // 32 cols x 32 k
 // "wait until all but the N youngest reads are back" leaves the prefetch of the next phase in flight.
 // Every wait names the registers it makes valid as "+v" operands: the MFMAs that consume them then depend on the
 // wait statement and cannot be scheduled above it (a bare asm s_waitcnt does not order register-only MFMAs).
-template <int OFF>
-__device__ __forceinline__ void ds_read128(bf16x8& dst, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
-}
 template <int HALF>
 __device__ __forceinline__ void load_frag_a(FragA& f, uint32_t addr) {
     ds_read128<(HALF * 64 + 0) * 128>(f.v[0], addr);
@@ -407,6 +338,8 @@ int launch256(const GemmArgs& a, int batch, hipStream_t s) {
             return BYA_ERR_LAUNCH;
         attr_set = true;
     }
+    static const bool w4 = [] { const char* e = getenv("BYA_GEMM_W4"); return e ? atoi(e) != 0 : false; }();
+    if (w4) return bya_launch_gemm256w4(&a, batch, s);
     BYA_LAUNCH(gemm256_kernel, grid, dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

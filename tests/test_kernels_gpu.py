@@ -180,6 +180,19 @@ def test_rowgemm512(ops, dev, M, N, ln, res, act, nsplit):
     assert torch.isfinite(out.float()).all()
 
 
+def test_gemm_one_wave_per_simd_variant(dev):
+    """BYA_GEMM_W4=1 routes the pipelined-tile shapes to the 4-wave / 128x128-per-wave kernel (AGPR accumulators,
+    register-staged loads, hand-interleaved phases; gemm_w4.hip).  It is an opt-in alternative with the same ABI: the
+    whole GEMM parity suite must pass on it.  Runs in a child process because the choice is read once per process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, BYA_GEMM_W4="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k",
+                        "gemm and not rowgemm and not one_wave"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_gemm_rejects_bad_shapes(ops, dev):
     from bind_your_avatar_implementation_amd._hip import ByaError
     a, w = rnd((64, 96), dev, 1), rnd((64, 96), dev, 2)       # K % 64 != 0
