@@ -15,7 +15,7 @@ the reference repo, so they are "parity unpinned" like the other diffusers-owned
 """
 import math
 from types import SimpleNamespace
-from typing import Callable, Dict, List, Optional
+from typing import Callable, List, Optional
 
 import torch
 
