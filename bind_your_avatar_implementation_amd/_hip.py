@@ -43,6 +43,7 @@ SIGNATURES = {
                       _f32, _vp],
     "bya_qknorm_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _f32, _vp],
     "bya_attn_fwd": [_vp, _vp, _vp, _vp, _c.POINTER(AttnDesc), _vp],
+    "bya_attn_variant": [_c.POINTER(AttnDesc)],
     "bya_attn_tiny": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
     "bya_router_scores": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp],
     "bya_router_head": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp],

@@ -395,6 +395,16 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// Which kernel a descriptor selects (reported to the host so tests and bench.py can say which softmax variant ran).
+extern "C" int bya_attn_variant(const bya_attn_desc* d) {
+    if (!d) return BYA_ERR_SHAPE;
+    if (d->head_dim == 128) return d->scores_prescaled ? BYA_ERR_UNSUPPORTED : BYA_ATTN_D128;
+    if (d->head_dim != 64) return BYA_ERR_UNSUPPORTED;
+    if (!d->scores_prescaled) return BYA_ATTN_D64_RUNNING_MAX;
+    // a usable static bound keeps every P = exp2(s) within [2^-48, 2^48]; otherwise the running-max kernel runs
+    return (d->score_bound > 0.f && d->score_bound <= 48.f) ? BYA_ATTN_D64_STATIC_BOUND : BYA_ATTN_D64_PRESCALED;
+}
+
 extern "C" int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya_attn_desc* d,
                             hipStream_t stream) {
     if (!q || !k || !v || !o || !d) return BYA_ERR_SHAPE;

@@ -24,6 +24,19 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 // etc.); clear it before the launch so the status we return describes THIS launch only.
 #define BYA_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: remember, per kernel, on which devices it has
+// been raised (one bit per device; racing first calls both set it, which is harmless).
+#include <atomic>
+inline int bya_allow_big_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return BYA_ERR_LAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return BYA_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return BYA_ERR_LAUNCH;
+    done.fetch_or(bit, std::memory_order_release);
+    return BYA_OK;
+}
+
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 

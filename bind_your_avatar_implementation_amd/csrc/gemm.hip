@@ -14,6 +14,7 @@
 // Epilogue: + bias -> activation -> * gate[row-type] -> + residual -> bf16.
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -331,15 +332,12 @@ int launch256(const GemmArgs& a, int batch, hipStream_t s) {
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
     dim3 grid(tiles_m * tiles_n, 1, batch);
     const size_t lds = 2 * 512 * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return BYA_ERR_LAUNCH;
-        attr_set = true;
-    }
-    static const bool w4 = [] { const char* e = getenv("BYA_GEMM_W4"); return e ? atoi(e) != 0 : false; }();
-    if (w4) return bya_launch_gemm256w4(&a, batch, s);
+    static std::atomic<unsigned long long> attr_done{0};
+    if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256_kernel), (int)lds, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
+    // tuning switch, read per call so one process can A/B the variants (tools/gemm_probe.py): "w4" = the one-wave-per-
+    // SIMD kernel of gemm_w4.hip
+    const char* variant = getenv("BYA_GEMM_VARIANT");
+    if (variant && variant[0] == 'w' && variant[1] == '4') return bya_launch_gemm256w4(&a, batch, s);
     BYA_LAUNCH(gemm256_kernel, grid, dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
@@ -349,13 +347,9 @@ int launch(const GemmArgs& a, int batch, hipStream_t s) {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, batch);
     const size_t lds = 2 * (BM + BN) * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return BYA_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N>), (int)lds, attr_done) != BYA_OK)
+        return BYA_ERR_LAUNCH;
     BYA_LAUNCH((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(64 * WAVES_M * WAVES_N), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

@@ -354,13 +354,8 @@ int bya_launch_gemm256w4(const void* args, int batch, hipStream_t s) {
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
     dim3 grid(tiles_m * tiles_n, 1, batch);
     const size_t lds = 2 * 512 * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256w4_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return BYA_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256w4_kernel), (int)lds, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
     BYA_LAUNCH(gemm256w4_kernel, grid, dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

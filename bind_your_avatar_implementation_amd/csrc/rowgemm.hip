@@ -255,13 +255,9 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
     const long long total = (long long)((a.M + 32 * NW - 1) / (32 * NW)) * (a.N / CH);
     const int blocks = (int)(total < 256 ? total : 256);
     const size_t lds = (size_t)a.N * 8 + 2 * STAGE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rowgemm512_kernel<LN, RES, ACT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return BYA_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (bya_allow_big_lds(reinterpret_cast<const void*>(rowgemm512_kernel<LN, RES, ACT>), 160 * 1024, attr_done) != BYA_OK)
+        return BYA_ERR_LAUNCH;
     BYA_LAUNCH((rowgemm512_kernel<LN, RES, ACT>), dim3(blocks), dim3(64 * NW), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

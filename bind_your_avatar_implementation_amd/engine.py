@@ -57,23 +57,41 @@ class DenoiseEngine:
         self.mix_before_projection = os.environ.get("BYA_MIX_BEFORE_PROJECTION", "1") != "0"
         self._inv_cache = {}
         self._ws_key, self._ws = None, None
-        # |q.k| * k_scale <= (8 max|gamma_q| + ||beta_q||)(8 max|gamma_k| + ||beta_k||) * k_scale for q, k out of
-        # LayerNorm(64) (||x_hat|| <= 8) followed by RoPE (a rotation); 2 % slack for the bf16 roundings of q and k.
-        # bya_attn_fwd uses the bound as a static softmax offset when it is small enough (include/bya.h).
-        self.score_bound = []
-        for blk in model.transformer_blocks:
-            nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
-            bq = 8.0 * nq.weight.float().abs().max().item() + nq.bias.float().norm().item()
-            bk = 8.0 * nk.weight.float().abs().max().item() + nk.bias.float().norm().item()
-            self.score_bound.append(1.02 * bq * bk * self.k_scale if os.environ.get("BYA_ATTN_BOUNDED", "1") != "0" else 0.0)
         if model.is_train_audio and not model.is_train_face:
             raise RuntimeError("audio injection needs the face router's logits (models/transformer.py:860)")
+        self._tensors = list(model.parameters()) + list(model.buffers())
         self._pack()
+
+    def _fingerprint(self):
+        """Cheap identity of the parameter set the packed copies were made from: storage pointers catch replaced
+        tensors, ``_version`` catches in-place edits (``copy_``, ``load_state_dict`` of a submodule, optimiser steps)."""
+        return (sum(t.data_ptr() for t in self._tensors), sum(t._version for t in self._tensors))
+
+    def refresh_if_stale(self):
+        """A submodule was loaded or edited in place without ``invalidate_engine()``: the packed copies (q|k|v, AdaLN,
+        permuted router weights, folded LayerNorms, score bounds) and everything derived from them (cached
+        conditioning, captured graphs) are stale -> rebuild.  Returns True when it did."""
+        if self._fingerprint() == self._fp:
+            return False
+        self._pack()
+        self._inv_cache = {}
+        self.m._graphs = {}
+        return True
 
     # ------------------------------------------------------------------------------------------ packing
     def _pack(self):
         m, D = self.m, self.D
         cat = torch.cat
+        self._fp = self._fingerprint()
+        # |q.k| * k_scale <= (8 max|gamma_q| + ||beta_q||)(8 max|gamma_k| + ||beta_k||) * k_scale for q, k out of
+        # LayerNorm(64) (||x_hat|| <= 8) followed by RoPE (a rotation); 2 % slack for the bf16 roundings of q and k.
+        # bya_attn_fwd uses the bound as a static softmax offset when it is small enough (include/bya.h).
+        self.score_bound = []
+        for blk in m.transformer_blocks:
+            nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
+            bq = 8.0 * nq.weight.float().abs().max().item() + nq.bias.float().norm().item()
+            bk = 8.0 * nk.weight.float().abs().max().item() + nk.bias.float().norm().item()
+            self.score_bound.append(1.02 * bq * bk * self.k_scale if os.environ.get("BYA_ATTN_BOUNDED", "1") != "0" else 0.0)
         mods_w, mods_b = [], []
         for blk in m.transformer_blocks:
             for nz in (blk.norm1, blk.norm2):
@@ -304,6 +322,7 @@ class DenoiseEngine:
     @torch.no_grad()
     def step(self, *args, **kwargs):
         """One denoise step (see ``_step``); every launch of the step goes to the stream that is current at entry."""
+        self.refresh_if_stale()
         with ops.pinned_stream():
             return self._step(*args, **kwargs)
 

@@ -192,6 +192,11 @@ def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6, k_sc
     _end(tok)
 
 
+# (call tag, softmax variant) -> launches since the last reset; the variant is reported by the library itself
+ATTN_VARIANT_NAMES = {0: "d64_running_max", 1: "d64_prescaled_running_max", 2: "d64_static_bound", 3: "d128_running_max"}
+ATTN_VARIANTS = {}
+
+
 def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_strides, v_strides, o_strides,
               scale, tag="other", prescaled=False, score_bound=0.0):
     """Flash attention with explicit (level-1, level-2, row) element strides for q, k, v, out."""
@@ -207,6 +212,8 @@ def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_
     d.score_bound = float(score_bound)
     for t in (q, k, v, out):
         assert t.dtype == torch.bfloat16 and t.is_cuda
+    var = ATTN_VARIANT_NAMES.get(lib.bya_attn_variant(ctypes.byref(d)), "rejected")
+    ATTN_VARIANTS[tag, var] = ATTN_VARIANTS.get((tag, var), 0) + 1
     tok = _begin("bya_attn_fwd:" + tag, 4.0 * nb1 * nb2 * heads * Sq * Skv * head_dim)
     check(lib.bya_attn_fwd(_p(q), _p(k), _p(v), _p(out), ctypes.byref(d), _stream()), "bya_attn_fwd")
     _end(tok)

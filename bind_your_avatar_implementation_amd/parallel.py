@@ -266,13 +266,35 @@ class CfgSplit:
         self.seq_group = halves[self.half]
         self.pair_group = pairs[me % self.half_size]
 
-    def take(self, obj):
-        """This rank's sample of every batch-2 tensor in a (nested) argument; batch-1 tensors are shared."""
-        if torch.is_tensor(obj):
-            return obj[self.half:self.half + 1] if obj.dim() > 0 and obj.shape[0] == 2 else obj
+    # positions in the engine's argument tuple (hidden_states, encoder_hidden_states, timestep, image_rotary_emb,
+    # id_cond, id_vit_hidden, audio_embeds, af_matrix, routing_logits_forcing) and the rank each batched tensor has
+    # WITH its batch axis.  Everything else (RoPE tables, forcing logits) is shared by both samples and never sliced.
+    BATCHED = {0: 5, 1: 3, 2: 1, 4: 2, 5: 3, 6: None, 7: 3}
+
+    def _slice(self, obj, ndim, what):
+        if obj is None:
+            return None
         if isinstance(obj, (list, tuple)):
-            return type(obj)(self.take(o) for o in obj)
-        return obj
+            return type(obj)(self._slice(o, ndim, what) for o in obj)
+        if not torch.is_tensor(obj):
+            return obj
+        if ndim is not None and obj.dim() != ndim:
+            if obj.dim() == ndim - 1 or obj.dim() == 0:
+                return obj                                   # unbatched form (e.g. a scalar timestep): shared
+            raise ValueError(f"CFG split: {what} has {obj.dim()} dims, expected {ndim} (batch first)")
+        if obj.shape[0] == 1:
+            return obj                                       # broadcast over the batch: shared
+        if obj.shape[0] != 2:
+            raise ValueError(f"CFG split: {what} has batch {obj.shape[0]}, expected 2 ([uncond, cond])")
+        return obj[self.half:self.half + 1]
+
+    def take(self, args):
+        """This rank's sample of the engine's argument tuple: arguments are sliced BY POSITION (only the ones that
+        carry a batch axis), never by a shape heuristic."""
+        names = ("hidden_states", "encoder_hidden_states", "timestep", "image_rotary_emb", "id_cond",
+                 "id_vit_hidden", "audio_embeds", "af_matrix", "routing_logits_forcing")
+        return tuple(self._slice(a, self.BATCHED[i], names[i]) if i in self.BATCHED else a
+                     for i, a in enumerate(args))
 
     def join(self, local):
         """[1, ...] per rank -> [2, ...] on every rank (sample order = half order)."""

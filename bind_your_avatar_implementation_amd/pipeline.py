@@ -272,10 +272,15 @@ class BindyouravatarPipeline:
                     u, c = n32.chunk(2)
                     n32 = u + self.guidance_scale * (c - u)
                 latents = self.scheduler.step(n32, t, latents, return_dict=False)[0].to(dtype)
-            if callback_on_step_end is not None:
-                kw = {k: locals()[k] for k in callback_on_step_end_tensor_inputs}
-                out = callback_on_step_end(self, i, t, kw)
-                latents = out.pop("latents", latents)
+            if callback_on_step_end is not None:         # reference models/pipeline_bindyouravatar.py:950-958
+                scope = locals()                          # (a comprehension has its own scope before Python 3.12)
+                callback_kwargs = {}
+                for k in callback_on_step_end_tensor_inputs:
+                    callback_kwargs[k] = scope[k]
+                callback_outputs = callback_on_step_end(self, i, t, callback_kwargs)
+                latents = callback_outputs.pop("latents", latents)
+                prompt_embeds = callback_outputs.pop("prompt_embeds", prompt_embeds)
+                negative_prompt_embeds = callback_outputs.pop("negative_prompt_embeds", negative_prompt_embeds)
         tr.release_conditioning()
         if not return_dict:
             return (latents,)

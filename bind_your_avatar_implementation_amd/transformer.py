@@ -374,7 +374,7 @@ class BindyouravatarTransformer3DModel(nn.Module):
         return out
 
     def _apply(self, fn, *a, **kw):
-        self._engine = None
+        self.invalidate_engine()          # packed weights, workspaces AND captured graphs point at the old storage
         return super()._apply(fn, *a, **kw)
 
     def init_synthetic(self, seed: int = 0, fast: bool = False):
@@ -430,10 +430,7 @@ class BindyouravatarTransformer3DModel(nn.Module):
         cfg = getattr(self, "_cfg", None)
         if cfg is not None and hidden_states.shape[0] == 2:
             # CFG batch split: this rank computes one sample, the pair exchange restores the [uncond, cond] batch
-            rope, forcing = args[3], args[8]                        # shared by both samples, never sliced
-            loc = list(cfg.take(args))
-            loc[3], loc[8] = rope, forcing
-            return (cfg.join(self._engine.step(*loc)), None, None, None, None)
+            return (cfg.join(self._engine.step(*cfg.take(args))), None, None, None, None)
         if self.use_hip_graph and getattr(self, "_seq_world", 1) == 1 and torch.is_tensor(timestep):
             out = self._graphed_step(args)
         else:
@@ -477,10 +474,15 @@ class BindyouravatarTransformer3DModel(nn.Module):
         """Capture ``engine.step`` once per input signature (shapes / dtypes / which optionals are present) into a HIP
         graph and replay it: the launches are identical, only the host-side launch cost disappears.  Inputs are copied
         into the graph's static buffers before every replay; the returned tensor is a fresh copy of the static output."""
+        self._engine.refresh_if_stale()                # in-place parameter edits drop the captured graphs too
         flat = self._flatten(args, [])
         key = tuple((tuple(t.shape), t.dtype) for t in flat) + tuple(a is None for a in args)
         entry = self._graphs.get(key)
         if entry is None:
+            # a captured graph bakes in raw pointers of the engine's workspace: give every graph a workspace of its
+            # own and keep it alive in the graph's entry (the engine drops its workspace dict whenever the geometry
+            # or batch of an eager call changes)
+            self._engine._ws_key, self._engine._ws = None, None
             static = [t.detach().clone().to(self.device) for t in flat]
             static_args = self._rebuild(args, iter(static))
             cache = self._engine.cache_invariants
@@ -494,8 +496,9 @@ class BindyouravatarTransformer3DModel(nn.Module):
             with torch.cuda.graph(graph):
                 static_out = self._engine.step(*static_args)
             self._engine.cache_invariants = cache
-            entry = self._graphs[key] = (graph, static, static_out)
-        graph, static, static_out = entry
+            entry = self._graphs[key] = (graph, static, static_out, self._engine._ws, self._engine)
+            self._engine._ws_key, self._engine._ws = None, None      # eager calls never write into a graph's buffers
+        graph, static, static_out = entry[:3]
         for dst, src in zip(static, flat):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)

@@ -129,6 +129,15 @@ typedef struct bya_attn_desc {
 int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya_attn_desc* desc,
                  hipStream_t stream);
 
+/* Which softmax variant bya_attn_fwd runs for a descriptor (host-side query, launches nothing): the joint attention
+ * silently falls back from the static-bound kernel to the running-maximum kernel when score_bound > 48, and callers
+ * (tests, bench.py) need to say which one they measured.  Negative = the descriptor is rejected. */
+#define BYA_ATTN_D64_RUNNING_MAX 0   /* online softmax, scores scaled in the kernel */
+#define BYA_ATTN_D64_PRESCALED 1     /* online softmax, scores already in exp2 units */
+#define BYA_ATTN_D64_STATIC_BOUND 2  /* no running maximum: P = exp2(s), |s| <= score_bound <= 48 */
+#define BYA_ATTN_D128 3
+int bya_attn_variant(const bya_attn_desc* desc);
+
 /* Tiny-sequence self-attention (sequence length L <= 16, head_dim 64) used by the router's temporal
  * (L = frames) and multi-ID (L = ids) attentions (models/router.py:482,488).  Element e of sequence
  * `g` lives at row  g_outer(g)*outer_stride + e*seq_stride + g_inner(g)  of the [rows, ld] matrices,

@@ -17,7 +17,15 @@ nothing here is imported by the test-suite at run time).  What it does:
   4. runs ``oracle.model.OracleTransformer`` on the same weights/inputs and prints the deviation,
      which ``tests/test_oracle_golden.py`` re-checks from the fixtures.
 
-Usage:  python tests/golden/make_golden.py [--case base|cfg_forcing|modules] [--layers 2]
+Usage:  python tests/golden/make_golden.py [--case base|cfg_forcing|modules|masks|depth|config0|bars] [--layers 2]
+
+``depth``   : the full 42-layer model at the reference geometry (fp32 reference + the oracle run in bf16 on the same
+              weights: the fixture carries the reference output, strided per-block taps and the bf16 path's own error,
+              which is the bar of tests/test_forward_gpu.py::test_depth_42_layers_vs_golden).
+``config0`` : BASELINE.json configs[0] -- ONE DiT block with every injection (cross_attn_interval = 1), 1 face + 1 audio
+              stream expressed as the 2-stream path with the second identity / audio stream zero-filled
+              ("Single-audio fallback").
+``bars``    : error of the oracle run in bf16 against the stored fp32 reference outputs (tests/golden/bf16_bars.json).
 """
 import argparse
 import json
@@ -127,22 +135,51 @@ MODEL_KW = dict(num_attention_heads=48, attention_head_dim=64, in_channels=48, o
                 audio_attn_interval=1)
 
 
-def build(cls, layers, seed):
+def build(cls, layers, seed, **over):
     t0 = time.time()
     with torch.device("meta"):
-        m = cls(num_layers=layers, **MODEL_KW)
+        m = cls(num_layers=layers, **dict(MODEL_KW, **over))
     pos = None
     m = m.to_empty(device="cpu")
     shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
-    sd = synth_state_dict(shapes, seed=seed)
-    from oracle.model import router_pos_emb
-    sd["router.pos_emb"] = router_pos_emb(13, 45, 30, 512)   # models/router.py:312-316 constants
-    missing, unexpected = m.load_state_dict(sd, strict=False)
-    assert not unexpected and not missing, (missing, unexpected)
+    fill(m, seed)
     m.eval()
     print(f"built {cls.__name__} ({sum(p.numel() for p in m.parameters())/1e9:.2f} B params) "
           f"in {time.time()-t0:.0f}s", flush=True)
     return m, shapes
+
+
+def fill(m, seed, dtype=None, **kw):
+    """Name-keyed synthetic parameters, written tensor by tensor (a 42-layer fp32 model is 34 GB: a second full
+    state dict would not fit next to it)."""
+    from oracle.model import router_pos_emb
+    from bind_your_avatar_implementation_amd.synth import synth_tensor
+    with torch.no_grad():
+        for name, t in m.state_dict().items():
+            if name == "router.pos_emb":
+                v = router_pos_emb(13, 45, 30, 512)          # models/router.py:312-316 constants
+            else:
+                v = synth_tensor(name, t.shape, seed)
+                if name.endswith("pos_embedding"):
+                    v[:, :226] = 0
+            t.copy_(v.to(t.dtype))
+            del v
+
+
+class StridedTaps(dict):
+    """taps dict that keeps a strided sample of every large tensor instead of the tensor (42 layers of taps do not
+    fit in host memory otherwise)."""
+
+    def __init__(self, step):
+        super().__init__()
+        self.step = step
+
+    def __setitem__(self, k, v):
+        if torch.is_tensor(v) and k.startswith("block"):
+            v = v[:, 226:]                  # the oracle taps the joint [text | video] stream; keep the video rows
+        if torch.is_tensor(v) and v.numel() > 4_000_000:
+            v = torch.from_numpy(strided(v, self.step))
+        super().__setitem__(k, v)
 
 
 def strided(t, step=970):
@@ -244,6 +281,105 @@ def run_case(case, layers, seed):
         d = (otaps[f"router{ca}_b{bj}"] - t).abs().max().item()
         print(f"  router call {j}: max-abs diff {d:.3e}")
     assert rel < 1e-5, rel
+
+
+def to_bf16_inputs(inp):
+    out = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
+    out["id_cond"] = [t.to(torch.bfloat16) for t in inp["id_cond"]]
+    out["id_vit_hidden"] = [[t.to(torch.bfloat16) for t in l] for l in inp["id_vit_hidden"]]
+    out["image_rotary_emb"] = inp["image_rotary_emb"]            # fp32 tables, as the pipeline passes them
+    return out
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().reshape(-1), torch.as_tensor(b).double().reshape(-1)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def bf16_oracle_pass(layers, seed, inp, step, **over):
+    """The restatement with bf16 parameters and activations (what the reference's own bf16 inference path computes,
+    infer.py:477) on the same synthetic weights: its distance from the fp32 result is the tolerance bar."""
+    with torch.device("meta"):
+        orc = OracleTransformer(num_layers=layers, **dict(MODEL_KW, **over))
+    orc = orc.to_empty(device="cpu").to(torch.bfloat16)
+    fill(orc, seed)
+    orc.eval()
+    taps = StridedTaps(step)
+    t0 = time.time()
+    with torch.no_grad():
+        out = orc(taps=taps, **to_bf16_inputs(inp))[0]
+    print(f"bf16 oracle forward ({layers} layers) {time.time()-t0:.0f}s", flush=True)
+    return out.float(), taps
+
+
+def run_deep(case, layers, seed, step, over, inp):
+    """fp32 REFERENCE + bf16 oracle on one configuration; strided taps only (memory)."""
+    install_standins()
+    from models.transformer import BindyouravatarTransformer3DModel
+    ref, _ = build(BindyouravatarTransformer3DModel, layers, seed, **over)
+    taps = {}
+
+    def hook(name):
+        def fn(mod, args, out):
+            outs = out if isinstance(out, (tuple, list)) else (out,)
+            taps[name] = strided(outs[0], step)
+        return fn
+
+    for i, blk in enumerate(ref.transformer_blocks):
+        blk.register_forward_hook(hook(f"block{i}"))          # output 0 = the video rows of the hidden stream
+    rtaps = []
+    ref.router.register_forward_hook(lambda m, a, o: rtaps.append(o.detach().float().clone()))
+    t0 = time.time()
+    with torch.no_grad():
+        out = ref(return_dict=False, denoise_step=0, **inp)[0]
+    print(f"reference forward ({case}, {layers} layers) {time.time()-t0:.0f}s |out|={out.norm():.4f}", flush=True)
+    del ref
+    import gc
+    gc.collect()
+    fx = {"output_f16": out.numpy().astype(np.float16), "output_stats": stats(out), "tap_step": np.array(step)}
+    for k, v in taps.items():
+        fx[k + ".strided"] = v
+    for j, r in enumerate(rtaps[:2]):
+        fx[f"router.call{j}"] = r.numpy()
+    out16, taps16 = bf16_oracle_pass(layers, seed, inp, step, **over)
+    fx["bf16_err_output"] = np.array(rel(out16, out))
+    errs = []
+    for i in range(layers):
+        t16 = taps16[f"block{i}"]
+        if t16.numel() != taps[f"block{i}"].size:
+            raise RuntimeError("tap layouts differ")
+        errs.append(rel(t16, taps[f"block{i}"]))
+    fx["bf16_err_blocks"] = np.array(errs)
+    print(f"[{case}] bf16-oracle vs fp32 reference: output {fx['bf16_err_output']:.3e}; blocks "
+          + " ".join(f"{e:.2e}" for e in errs), flush=True)
+    np.savez_compressed(os.path.join(HERE, f"ref_forward_{case}_L{layers}_seed{seed}.npz"), **fx)
+
+
+def config0_inputs(seed):
+    """BASELINE.json configs[0]: 1 audio + 1 face stream = the 2-stream call with the second identity's
+    ``id_cond`` / ``id_vit_hidden`` and the second audio stream zero-filled."""
+    inp = synth_inputs(batch=1, seed=seed)
+    inp["id_cond"][1] = torch.zeros_like(inp["id_cond"][1])
+    inp["id_vit_hidden"][1] = [torch.zeros_like(t) for t in inp["id_vit_hidden"][1]]
+    inp["audio_embeds"][:, 1] = 0
+    return inp
+
+
+def run_bars(seed):
+    """bf16-oracle error against the STORED fp32 reference outputs of the 2-layer fixtures."""
+    bars = {}
+    for case, batch in (("base", 1), ("cfg_forcing", 2)):
+        fxp = os.path.join(HERE, f"ref_forward_{case}_L2_seed{seed}.npz")
+        fx = np.load(fxp)
+        inp = synth_inputs(batch=batch, seed=seed, uncond_first=(batch == 2))
+        if case == "cfg_forcing":
+            inp["af_matrix"] = (1 - torch.eye(2))[None].repeat(batch, 1, 1)
+            inp["routing_logits_forcing"] = torch.from_numpy(fx["forcing_u8"].astype(np.float32))
+        out16, _ = bf16_oracle_pass(2, seed, inp, 970)
+        bars[case] = rel(out16, torch.from_numpy(fx["output_f16"].astype(np.float32)))
+        print(f"{case}: bf16 oracle vs stored fp32 reference output = {bars[case]:.3e}", flush=True)
+    with open(os.path.join(HERE, "bf16_bars.json"), "w") as f:
+        json.dump(bars, f, indent=1)
 
 
 def module_cases(seed):
@@ -357,7 +493,8 @@ def run_masks(seed):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--case", default="base", choices=["base", "cfg_forcing", "modules", "masks"])
+    ap.add_argument("--case", default="base", choices=["base", "cfg_forcing", "modules", "masks", "depth", "config0",
+                                                        "bars"])
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
@@ -367,5 +504,12 @@ if __name__ == "__main__":
         run_masks(a.seed)
     elif a.case == "modules":
         run_modules(a.seed)
+    elif a.case == "depth":
+        # the oracle taps the joint stream, the reference hook the video rows: sample the video rows on both sides
+        run_deep("depth", 42 if a.layers == 2 else a.layers, a.seed, 9973, {}, synth_inputs(batch=1, seed=a.seed))
+    elif a.case == "config0":
+        run_deep("config0", 1, a.seed, 970, dict(cross_attn_interval=1), config0_inputs(a.seed))
+    elif a.case == "bars":
+        run_bars(a.seed)
     else:
         run_case(a.case, a.layers, a.seed)

@@ -180,16 +180,17 @@ def test_rowgemm512(ops, dev, M, N, ln, res, act, nsplit):
     assert torch.isfinite(out.float()).all()
 
 
-def test_gemm_one_wave_per_simd_variant(dev):
-    """BYA_GEMM_W4=1 routes the pipelined-tile shapes to the 4-wave / 128x128-per-wave kernel (AGPR accumulators,
-    register-staged loads, hand-interleaved phases; gemm_w4.hip).  It is an opt-in alternative with the same ABI: the
-    whole GEMM parity suite must pass on it.  Runs in a child process because the choice is read once per process."""
+@pytest.mark.parametrize("variant", ["w4"])
+def test_gemm_alternative_variants(dev, variant):
+    """BYA_GEMM_VARIANT routes the pipelined-tile shapes to an alternative kernel with the same ABI ("w4": 4 waves,
+    128x128 per wave, AGPR accumulators, register-staged loads; gemm_w4.hip): the whole GEMM parity suite must pass
+    on it.  Runs in a child process so the variable cannot leak into other tests."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, BYA_GEMM_W4="1")
+    env = dict(os.environ, BYA_GEMM_VARIANT=variant)
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k",
-                        "gemm and not rowgemm and not one_wave"], env=env, capture_output=True, text=True, timeout=900)
+                        "gemm and not rowgemm and not alternative"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -467,6 +468,59 @@ def test_routed_mix_then_projection_equals_project_then_combine(ops, dev, mode):
     feat = o.float() @ w_out.float().T + b_out.float()                     # [B, NID, N, D]
     ref = x.float() + torch.einsum("bni,bind->bnd", wgt, feat)
     check(out, ref, tol=2e-3, what=f"routed mix {mode}")
+
+
+@pytest.mark.parametrize("mode", ["face", "audio"])
+@pytest.mark.parametrize("M", [300, 17550])
+def test_routed_mix_projection_exact_row_selection(ops, dev, mode, M):
+    """The DEFAULT engine path (``routed_mix`` -> ``bya_gemm_bf16`` with residual / row-scaled bias, engine.py G1/G2)
+    on hard one-hot masks, integer-valued features, a permutation matrix as ``to_out`` and integer biases: every
+    intermediate is exactly representable, so the result must equal the reference's order of operations
+    (models/transformer.py:821-832 face; :895-936 audio with the ``[1,0]`` swap, ``1 - x`` and the af mixing)
+    BIT FOR BIT -- a swapped identity, a wrong row or a wrong mask column cannot hide behind a tolerance.
+    M = 17550 with K = N = 1024 runs the pipelined 256x256 GEMM (+ its 128x128 tail split) like the full-size step."""
+    B, NID = 2, 2
+    Dp, D = (256, 512) if M < 1024 else (1024, 1024)
+    g = torch.Generator().manual_seed(77 + M)
+    o = torch.randint(-8, 9, (B, NID, M, Dp), generator=g).to(torch.bfloat16).to(dev)
+    perm = torch.randperm(Dp, generator=g)
+    w_out = torch.zeros(D, Dp)
+    w_out[torch.arange(D), perm[torch.arange(D) % Dp]] = 1.0             # out[:, j] = z[:, perm[j % Dp]]
+    w_out = w_out.to(torch.bfloat16).to(dev)
+    b_out = torch.randint(-3, 4, (D,), generator=g).to(torch.bfloat16).to(dev)
+    x = torch.randint(-16, 17, (B, M, D), generator=g).to(torch.bfloat16).to(dev)
+    lab = torch.randint(-1, NID, (1, M), generator=g)                     # -1 = background, else the identity
+    r = torch.zeros(1, M, NID)
+    for i in range(NID):
+        r[0, lab[0] == i, i] = 1.0
+    r = r.to(torch.bfloat16).to(dev)
+    af = torch.stack([torch.eye(2), 1 - torch.eye(2)]).to(torch.bfloat16).to(dev)      # sample 0: eye, sample 1: swap
+    z = torch.empty(B, M, Dp, dtype=torch.bfloat16, device=dev)
+    wsum = torch.empty(B, M, dtype=torch.float32, device=dev)
+    out = x.clone()
+    if mode == "face":
+        ops.routed_mix(o, r, None, "face", z)
+        ops.gemm(z, w_out, out, res=out, alpha=1.0)
+        wgt = r.float().expand(B, -1, -1)
+        bias = torch.zeros(D, device=dev)
+    else:
+        ops.routed_mix(o, r, af, "audio", z, wsum)
+        ops.gemm(z, w_out, out, bias=b_out, res=out, bias_rowscale=wsum)
+        av = (af.float() @ r.float().expand(B, -1, -1).transpose(-2, -1)).transpose(-2, -1)      # [B, M, 2]
+        wgt = 1 - av[:, :, [1, 0]]
+        bias = b_out.float()
+    # reference order: project every identity (+ bias), then combine with the mask weights, then add
+    feat = o.float()[..., perm[torch.arange(D) % Dp].to(dev)] + bias                            # [B, NID, M, D]
+    ref = x.float() + torch.einsum("bni,bind->bnd", wgt, feat)
+    assert ref.abs().max() < 256                                                                 # exact in bf16
+    assert torch.equal(out.float(), ref), f"{mode}: {(out.float() - ref).abs().max().item()}"
+    # and the selection really happened: foreground rows carry exactly one identity's features
+    k = int((lab[0] == 0).nonzero()[0])
+    if mode == "face":
+        assert torch.equal(out[0, k].float() - x[0, k].float(), feat[0, 0, k])
+    else:       # sample 0 (af = eye): id 0's region hears id 0 only; sample 1 (af swapped): it hears id 1 only
+        assert torch.equal(out[0, k].float() - x[0, k].float(), feat[0, 0, k])
+        assert torch.equal(out[1, k].float() - x[1, k].float(), feat[1, 1, k])
 
 
 def test_patchify_unpatchify_exact(ops, dev):

@@ -112,10 +112,24 @@ def _cfg_worker(rank, world, port, ret):
         assert dist.get_world_size(cs.seq_group) == world // 2 and dist.get_world_size(cs.pair_group) == 2
         torch.manual_seed(0)
         batch = torch.randn(2, 3, 5)
-        nested = [batch, [batch + 1, (batch + 2, torch.arange(7.0))], None, 3]
-        mine = cs.take(nested)
-        assert torch.equal(mine[0], batch[cs.half:cs.half + 1]) and torch.equal(mine[1][1][0], batch[cs.half:cs.half + 1] + 2)
-        assert torch.equal(mine[1][1][1], torch.arange(7.0)) and mine[2] is None and mine[3] == 3
+        h = slice(cs.half, cs.half + 1)
+        # the engine's argument tuple, sliced BY POSITION: tensors that merely happen to have a leading 2 (a 2-row
+        # RoPE table, a [1 or 2, N, 2] forcing tensor, an unbatched [2, 2] af_matrix) must stay whole
+        hid, enc, ts = torch.randn(2, 3, 4, 2, 2), torch.randn(2, 5, 8), torch.tensor([999, 999])
+        rope = (torch.randn(2, 64), torch.randn(2, 64))
+        idc = [torch.randn(2, 1280), torch.randn(2, 1280)]
+        vit = [[torch.randn(2, 7, 16) for _ in range(5)] for _ in range(2)]
+        audio, af, forcing = torch.randn(2, 2, 13, 12, 8), torch.eye(2)[None].repeat(2, 1, 1), torch.randn(2, 6, 2)
+        mine = cs.take((hid, enc, ts, rope, idc, vit, audio, af, forcing))
+        assert torch.equal(mine[0], hid[h]) and torch.equal(mine[1], enc[h]) and torch.equal(mine[2], ts[h])
+        assert mine[3][0] is rope[0] and mine[8] is forcing
+        assert torch.equal(mine[4][1], idc[1][h]) and torch.equal(mine[5][1][4], vit[1][4][h])
+        assert torch.equal(mine[6], audio[h]) and torch.equal(mine[7], af[h])
+        shared = cs.take((hid, enc, torch.tensor(999), None, None, None, None, torch.eye(2), None))
+        assert shared[2].dim() == 0 and shared[7].shape == (2, 2) and shared[3] is None
+        with pytest.raises(ValueError):
+            cs.take((torch.randn(3, 3, 4, 2, 2), enc, ts, rope, idc, vit, audio, af, forcing))
+        mine = [batch[h]]
         # each half computes f(sample) on its own (sequence-sharded inside the half when it has 2 ranks) ...
         f = lambda x: x * 2 + 1
         local = mine[0]
