@@ -70,10 +70,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// GELU(tanh):  0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = k0 (x + k1 x^3).  One v_exp_f32 and one v_rcp_f32 (1 ulp
+// each, far below the bf16 output step) instead of expf + an IEEE division: the FF1 epilogue evaluates it 218 M times
+// per launch (128 values per lane of a 256x256 tile), where the division sequence alone was ~10 instructions a value.
 __device__ __forceinline__ float gelu_tanh(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u2 = x * fmaf(x * x, 2.0f * k0 * k1, 2.0f * k0);                  // 2u
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * u2);            // exp(-2u): 0 .. inf, never NaN for finite x
+    return x * __builtin_amdgcn_rcpf(1.0f + e);                                   // x / (1 + exp(-2u)); e = inf -> 0
+}
+// the round-1 form (expf + IEEE division), kept for A/B in tools/gemm_probe.py as activation code 6
+__device__ __forceinline__ float gelu_tanh_ieee(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
     float u = k0 * (x + k1 * x * x * x);
-    // tanh(u) = 1 - 2/(exp(2u)+1)
     float e = __expf(2.0f * u);
     float t = 1.0f - 2.0f / (e + 1.0f);
     return 0.5f * x * (1.0f + t);

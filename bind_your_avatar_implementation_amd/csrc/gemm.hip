@@ -106,21 +106,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(GemmA
     // ---- epilogue: lane holds C[m][n4..n4+3], m = m0 + wm*WM + j*16 + fr, n4 = n0 + wn*WN + i*16 + fq*4
     // (one fully unrolled, switch-free copy per activation: a runtime-indexed accumulator array would go to scratch)
     auto run = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int n4 = n0 + wn * WN + i * 16 + fq * 4;
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n4 < p.N) {
-                const u32x2 bv = *reinterpret_cast<const u32x2*>(p.bias + n4);
-                b4[0] = bflo(bv[0]); b4[1] = bfhi(bv[0]); b4[2] = bflo(bv[1]); b4[3] = bfhi(bv[1]);
-            }
-#pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                const int m = m0 + wm * WM + j * 16 + fr;
-                if (m < p.M && n4 < p.N) epilogue4<ACT>(p, z, m, n4, acc[i][j], b4);
-            }
-        }
+        epilogue_block<decltype(act_tag)::value, NI, MI, (NI * MI > 16 ? 1 : NI)>(p, z, m0 + wm * WM + fr, n0 + wn * WN + fq * 4, acc);
     };
     dispatch_act(p.act, run);
 }
@@ -309,23 +295,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 
     // ---- epilogue (same lane map as the small-tile kernel): acc[i][j] -> C[m][n4..n4+3]
     auto run = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n4 = n0 + wn * 64 + i * 16 + fq * 4;
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n4 < p.N) {
-                const u32x2 bv = *reinterpret_cast<const u32x2*>(p.bias + n4);
-                b4[0] = bflo(bv[0]); b4[1] = bfhi(bv[0]); b4[2] = bflo(bv[1]); b4[3] = bfhi(bv[1]);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = m0 + wm * 128 + j * 16 + fr;
-                if (m < p.M && n4 < p.N) epilogue4<ACT>(p, z, m, n4, acc[i][j], b4);
-            }
-        }
+        epilogue_block<decltype(act_tag)::value, 4, 8, 2>(p, z, m0 + wm * 128 + fr, n0 + wn * 64 + fq * 4, acc);
     };
-    dispatch_act(p.act, run);
+    dispatch_act_big(p.act, run);
 }
 
 int launch256(const GemmArgs& a, int batch, hipStream_t s) {
@@ -338,6 +310,7 @@ int launch256(const GemmArgs& a, int batch, hipStream_t s) {
     // SIMD kernel of gemm_w4.hip
     const char* variant = getenv("BYA_GEMM_VARIANT");
     if (variant && variant[0] == 'w' && variant[1] == '4') return bya_launch_gemm256w4(&a, batch, s);
+    if (variant && variant[0] == 'v' && variant[1] == '3') return bya_launch_gemm256v3(&a, batch, s);
     BYA_LAUNCH(gemm256_kernel, grid, dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
@@ -355,8 +328,8 @@ int launch(const GemmArgs& a, int batch, hipStream_t s) {
 }
 
 // Tile choice: fewest "CU rounds" (wave quantisation on 256 CUs) weighted by the tile's relative efficiency.
-inline int pick_tile(int M, int N, int K, int batch, int forced) {
-    if (forced >= 0) return forced;
+inline int pick_tile(int M, int N, int K, int batch, int forced, int act) {
+    if (forced >= 0) return (forced >= 4 && !act_on_big_tiles(act)) ? 1 : forced;
     if (N <= 64) return 0;
     auto rounds = [&](int bm, int bn, int per_cu) {
         const long long blocks = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
@@ -367,7 +340,7 @@ inline int pick_tile(int M, int N, int K, int batch, int forced) {
     const double t256x128 = rounds(256, 128, 1) / 0.95;
     const double t256 = rounds(256, 256, 1) / 1.00;
     (void)t256x128;
-    if (M < 1024 || N < 512 || K < 1024) return 1;     // short K loops: the pipelined kernel's prologue/epilogue dominate
+    if (M < 1024 || N < 512 || K < 1024 || !act_on_big_tiles(act)) return 1;     // short K loops: the pipelined kernel's prologue/epilogue dominate
     // the pipelined 256x256 kernel is ~1.2x the 128x128 one per unit of tile area when its grid fills the CUs
     return (t256 / 1.2 <= t128) ? 4 : 1;
 }
@@ -382,7 +355,7 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
     if (d->lda % 8 || d->ldw % 8 || d->ldc % 4 || (res && d->ldres % 4)) return BYA_ERR_ALIGN;
     if (((uintptr_t)A | (uintptr_t)W) & 15) return BYA_ERR_ALIGN;
     if (((uintptr_t)C | (uintptr_t)res | (uintptr_t)bias | (uintptr_t)gate0 | (uintptr_t)gate1) & 7) return BYA_ERR_ALIGN;
-    if (d->act < 0 || d->act > 5) return BYA_ERR_UNSUPPORTED;
+    if (d->act < 0 || d->act > 6) return BYA_ERR_UNSUPPORTED;
     GemmArgs a;
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.C = (bf16_t*)C;
     a.res = (const bf16_t*)res; a.gate0 = (const bf16_t*)gate0; a.gate1 = (const bf16_t*)(gate1 ? gate1 : gate0);
@@ -394,7 +367,7 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
     a.bias_rowscale = d->bias_rowscale; a.alpha = d->alpha == 0.0f ? 1.0f : d->alpha;
     if (d->n_split < 0 || (d->n_split > 0 && (d->n_split % 4 || d->c_split_stride % 4 || res))) return BYA_ERR_SHAPE;
     static const int forced = [] { const char* e = getenv("BYA_GEMM_TILE"); return e ? atoi(e) : -1; }();
-    switch (pick_tile(d->M, d->N, d->K, d->batch, forced)) {
+    switch (pick_tile(d->M, d->N, d->K, d->batch, forced, d->act)) {
         case 0: return launch<128, 64, 2, 2>(a, d->batch, stream);
         case 1: return launch<128, 128, 2, 2>(a, d->batch, stream);
         case 2: return launch<256, 128, 4, 2>(a, d->batch, stream);

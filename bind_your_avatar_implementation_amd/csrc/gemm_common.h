@@ -22,6 +22,22 @@ struct GemmArgs {
 
 constexpr int BK = 64;  // bf16 elements per K tile = 128-byte LDS rows
 
+template <int V> struct IntTag { static constexpr int value = V; };
+
+// The pipelined 256x256 kernels instantiate their (fully unrolled, 128-accumulator) epilogue for these activations only --
+// none, GELU(tanh) of the DiT MLP and its A/B twin; every other activation sits on small GEMMs that run on the 128x128
+// kernel (pick_tile), so seven copies of a 3000-line epilogue are not carried around (they also cost registers: the
+// seven-way merge made hipcc copy half the accumulators).
+__host__ __device__ constexpr bool act_on_big_tiles(int act) { return act == 0 || act == 1 || act == 6; }
+template <typename F>
+__device__ __forceinline__ void dispatch_act_big(int act, F&& f) {
+    switch (act) {
+        case 1: f(IntTag<1>{}); break;
+        case 6: f(IntTag<6>{}); break;
+        default: f(IntTag<0>{}); break;
+    }
+}
+
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v, float leaky) {
     if constexpr (ACT == 1) return gelu_tanh(v);
@@ -29,12 +45,12 @@ __device__ __forceinline__ float apply_act(float v, float leaky) {
     else if constexpr (ACT == 3) return v > 0.f ? v : 0.f;
     else if constexpr (ACT == 4) return silu(v);
     else if constexpr (ACT == 5) return v > 0.f ? v : v * leaky;
+    else if constexpr (ACT == 6) return gelu_tanh_ieee(v);
     else return v;
 }
 
 
 // Epilogue for 4 consecutive output columns n4..n4+3 of row m: + bias -> act -> * gate[row type] -> + residual -> bf16
-template <int V> struct IntTag { static constexpr int value = V; };
 template <typename F>
 __device__ __forceinline__ void dispatch_act(int act, F&& f) {
     switch (act) {
@@ -43,31 +59,98 @@ __device__ __forceinline__ void dispatch_act(int act, F&& f) {
         case 3: f(IntTag<3>{}); break;
         case 4: f(IntTag<4>{}); break;
         case 5: f(IntTag<5>{}); break;
+        case 6: f(IntTag<6>{}); break;
         default: f(IntTag<0>{}); break;
     }
 }
 
-template <int ACT>
-__device__ __forceinline__ void epilogue4(const GemmArgs& p, int z, int m, int n4, const f32x4 acc, const float (&b4)[4]) {
-    float v[4];
-    const float bs = p.bias_rowscale ? p.bias_rowscale[(long long)z * p.M + m] : 1.0f;
+// Fused epilogue of one wave: the lane holds C[m_j][n_i .. n_i + 3] for m_j = m_base + 16 j, n_i = n_base + 16 i
+// (the transposed 16x16x32 accumulator layout of every GEMM kernel here), acc[i][j] = the four columns.
+//   v = alpha * act(acc + rowscale[m] * bias[n]);  v *= gate[row type][n];  v += res[m][n];  C[m][n] = bf16(v)
+// Everything the epilogue READS (bias, both gate vectors, the residual rows, the per-row bias scale) is requested up front
+// in one burst, with clamped addresses instead of branches, and only then consumed: a load inside the per-tile bounds
+// branch made hipcc wait for it -- and, since vmcnt counts stores too, for the previous tile's store -- once per
+// 16x16 tile, 32 to 64 serialized memory round trips per wave (measured: the gate + residual epilogue cost 32 % of the
+// attention-output GEMM, 780 vs 1152 TFLOP/s).  The residual may alias C (x += ...): a lane only ever reads the
+// elements it later writes.
+template <int ACT, int NI, int NJ, int IB = NI>
+__device__ __forceinline__ void epilogue_block(const GemmArgs& p, int z, int m_base, int n_base, const f32x4 (&acc)[NI][NJ]) {
+    // IB = column groups per burst: the burst's residual values occupy IB * NJ * 2 registers (the 8-wave kernel has only
+    // 256 registers per lane with 128 of them accumulators, so it bursts one column group at a time).
+    // Residual loads and C stores go through buffer descriptors: 32-bit per-lane byte offsets (one register per row, no
+    // 64-bit pointer per access) and the hardware range check instead of branches -- an element outside M x N gets the
+    // offset 0xffffffff, whose load returns zero and whose store is dropped.  Every tensor here is far below 2 GiB.
+    static_assert(NI % IB == 0, "burst size must divide the tile");
+    const bool has_res = p.res != nullptr, has_gate = p.gate0 != nullptr, has_bias = p.bias != nullptr;
+    const bool has_rs = p.bias_rowscale != nullptr;
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((has_res ? p.res : p.C) + (long long)z * p.res_bs), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.C + (long long)z * p.c_bs), 0, 0x7fffffff, 0x00020000);
+    const char* g0base = reinterpret_cast<const char*>(p.gate0 + (long long)z * p.gate_bs);
+    const char* g1base = reinterpret_cast<const char*>(p.gate1 + (long long)z * p.gate_bs);
+    float rs[NJ];
+    bool mok[NJ];
+    uint32_t roff[NJ], coff[NJ];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = p.alpha * apply_act<ACT>(fmaf(bs, b4[e], acc[e]), p.leaky);
-    if (p.gate0) {
-        const bf16_t* g = (m < p.gate_split ? p.gate0 : p.gate1) + (long long)z * p.gate_bs + n4;
-        const u32x2 gv = *reinterpret_cast<const u32x2*>(g);
-        v[0] *= bflo(gv[0]); v[1] *= bfhi(gv[0]); v[2] *= bflo(gv[1]); v[3] *= bfhi(gv[1]);
+    for (int j = 0; j < NJ; ++j) {
+        const int m = m_base + 16 * j;
+        mok[j] = m < p.M;
+        const uint32_t mc = mok[j] ? (uint32_t)m : 0u;
+        rs[j] = has_rs ? p.bias_rowscale[(long long)z * p.M + mc] : 1.0f;
+        roff[j] = mok[j] ? mc * (uint32_t)(p.ldres * 2) : 0xffffffffu;
+        coff[j] = mok[j] ? mc * (uint32_t)(p.ldc * 2) : 0xffffffffu;
     }
-    long long col = n4;
-    if (p.n_split > 0) col = (long long)(n4 / p.n_split) * p.c_split_stride + (n4 % p.n_split);
-    if (p.res) {
-        const u32x2 rv = *reinterpret_cast<const u32x2*>(p.res + (long long)z * p.res_bs + (long long)m * p.ldres + n4);
-        v[0] += bflo(rv[0]); v[1] += bfhi(rv[0]); v[2] += bflo(rv[1]); v[3] += bfhi(rv[1]);
+#pragma unroll
+    for (int ib = 0; ib < NI; ib += IB) {
+        u32x2 bv[IB], g0[IB], g1[IB], rv[IB][NJ];
+        bool nok[IB];
+        uint32_t ncb[IB];
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+            const int n4 = n_base + 16 * (ib + ii);
+            nok[ii] = n4 < p.N;
+            ncb[ii] = nok[ii] ? (uint32_t)n4 * 2u : 0u;
+            bv[ii] = has_bias ? *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(p.bias) + ncb[ii]) : u32x2{0u, 0u};
+            if (has_gate) {
+                g0[ii] = *reinterpret_cast<const u32x2*>(g0base + ncb[ii]);
+                g1[ii] = *reinterpret_cast<const u32x2*>(g1base + ncb[ii]);
+            }
+            if (has_res) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)       // (0xffffffff + a column offset wraps: clamp invalid rows explicitly)
+                    rv[ii][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                        rsR, mok[j] ? roff[j] + ncb[ii] : 0xffffffffu, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+            const int n4 = n_base + 16 * (ib + ii);
+            uint32_t colb = (uint32_t)n4 * 2u;
+            if (p.n_split > 0) colb = ((uint32_t)(n4 / p.n_split) * (uint32_t)p.c_split_stride + (uint32_t)(n4 % p.n_split)) * 2u;
+            const float b4[4] = {bflo(bv[ii][0]), bfhi(bv[ii][0]), bflo(bv[ii][1]), bfhi(bv[ii][1])};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int m = m_base + 16 * j;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = p.alpha * apply_act<ACT>(fmaf(rs[j], b4[e], acc[ib + ii][j][e]), p.leaky);
+                if (has_gate) {
+                    const u32x2 gv = m < p.gate_split ? g0[ii] : g1[ii];
+                    v[0] *= bflo(gv[0]); v[1] *= bfhi(gv[0]); v[2] *= bflo(gv[1]); v[3] *= bfhi(gv[1]);
+                }
+                if (has_res) {
+                    v[0] += bflo(rv[ii][j][0]); v[1] += bfhi(rv[ii][j][0]);
+                    v[2] += bflo(rv[ii][j][1]); v[3] += bfhi(rv[ii][j][1]);
+                }
+                u32x2 o;
+                o[0] = pack2bf(v[0], v[1]);
+                o[1] = pack2bf(v[2], v[3]);
+                __builtin_amdgcn_raw_buffer_store_b64(o, rsC, (mok[j] && nok[ii]) ? coff[j] + colb : 0xffffffffu, 0, 0);
+            }
+        }
     }
-    u32x2 o;
-    o[0] = pack2bf(v[0], v[1]);
-    o[1] = pack2bf(v[2], v[3]);
-    *reinterpret_cast<u32x2*>(p.C + (long long)z * p.c_bs + (long long)m * p.ldc + col) = o;
 }
 
 template <int OFF>
@@ -78,3 +161,5 @@ __device__ __forceinline__ void ds_read128(bf16x8& dst, uint32_t addr) {
 
 // defined in gemm_w4.hip (compiled with its own register-allocation flags), called from bya_gemm_bf16
 int bya_launch_gemm256w4(const void* args, int batch, hipStream_t stream);
+// defined in gemm_v3.hip (same flags): one wave per SIMD, LDS-DMA two K-tiles ahead
+int bya_launch_gemm256v3(const void* args, int batch, hipStream_t stream);

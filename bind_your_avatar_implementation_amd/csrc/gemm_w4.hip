@@ -328,23 +328,9 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(GemmArgs p) {
 
     // ---- epilogue: acc[i][j] -> C[m][n4..n4+3], m = m0 + 128 wm + 16 j + fr, n4 = n0 + 128 wn + 16 i + 4 fq
     auto run = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n4 = n0 + wn * 128 + i * 16 + fq * 4;
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n4 < p.N) {
-                const u32x2 bv = *reinterpret_cast<const u32x2*>(p.bias + n4);
-                b4[0] = bflo(bv[0]); b4[1] = bfhi(bv[0]); b4[2] = bflo(bv[1]); b4[3] = bfhi(bv[1]);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = m0 + wm * 128 + j * 16 + fr;
-                if (m < p.M && n4 < p.N) epilogue4<ACT>(p, z, m, n4, acc[i][j], b4);
-            }
-        }
+        epilogue_block<decltype(act_tag)::value, 8, 8, 4>(p, z, m0 + wm * 128 + fr, n0 + wn * 128 + fq * 4, acc);
     };
-    dispatch_act(p.act, run);
+    dispatch_act_big(p.act, run);
 }
 
 }  // namespace

@@ -8,6 +8,7 @@
 // (models/audio_model.py:249), diffusers Attention.norm_q/norm_k + apply_rotary_emb (transformer.py:204-208).
 #include "bya_common.h"
 #include "../../include/bya.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -111,6 +112,7 @@ struct QkArgs {
     long long ld, bs;
     float eps;
     float k_scale;     // multiplies the finished k (fp32, before the single rounding to bf16); 1 = off
+    int table_sc1;     // 1: read cos / sin past the vector L1 (sc1 loads) -- see tools/timeslice/repro.py
 };
 
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
@@ -149,8 +151,20 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
     if (s >= p.text_rows) {
         const float* c = p.cos + (long long)(s - p.text_rows) * 64 + d0;
         const float* sn = p.sin + (long long)(s - p.text_rows) * 64 + d0;
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sn), s1 = *reinterpret_cast<const f32x4*>(sn + 4);
+        f32x4 c0, c1, s0, s1;
+        if (p.table_sc1) {
+            // the eight head groups of a wave read the SAME eight 32-byte pieces of a table row; served past the L1
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.cos, 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)p.sin, 0, 0x7fffffff, 0x00020000);
+            const uint32_t off = (uint32_t)(((long long)(s - p.text_rows) * 64 + d0) * 4);
+            c0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 16));
+            c1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, off + 16, 0, 16));
+            s0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsn, off, 0, 16));
+            s1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsn, off + 16, 0, 16));
+        } else {
+            c0 = *reinterpret_cast<const f32x4*>(c); c1 = *reinterpret_cast<const f32x4*>(c + 4);
+            s0 = *reinterpret_cast<const f32x4*>(sn); s1 = *reinterpret_cast<const f32x4*>(sn + 4);
+        }
         const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
         const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
         float o[8];
@@ -209,6 +223,10 @@ extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb,
     a.q = (bf16_t*)q; a.k = (bf16_t*)k; a.qw = (const bf16_t*)qw; a.qb = (const bf16_t*)qb;
     a.kw = (const bf16_t*)kw; a.kb = (const bf16_t*)kb; a.cos = cos; a.sin = sin;
     a.batch = batch; a.S = S; a.heads = heads; a.text_rows = text_rows; a.ld = ld; a.bs = batch_stride; a.eps = eps; a.k_scale = k_scale == 0.0f ? 1.0f : k_scale;
+    {   // experiment switch, read per call (tools/timeslice/repro.py); the product default is decided in DESIGN.md section 5
+        const char* e = getenv("BYA_QKNORM_TABLE_SC1");
+        a.table_sc1 = e ? atoi(e) : 0;
+    }
     const long long total = ((long long)batch * S * heads * 2 + 7) / 8;      // waves: 8 (row, head) pairs each
     dim3 grid((unsigned)((total + 3) / 4));
     BYA_LAUNCH(qknorm_rope_kernel, grid, dim3(256), 0, stream, a);

@@ -11,7 +11,8 @@ import torch
 from . import _hip
 from ._hip import AttnDesc, GemmDesc, check
 
-ACT = {None: 0, "none": 0, "gelu_tanh": 1, "gelu_erf": 2, "relu": 3, "silu": 4, "leaky_relu": 5}
+ACT = {None: 0, "none": 0, "gelu_tanh": 1, "gelu_erf": 2, "relu": 3, "silu": 4, "leaky_relu": 5,
+       "gelu_tanh_ieee": 6}        # 6: round-1 GELU form (expf + IEEE division), GEMM epilogue only, kept for A/B
 
 
 _PINNED_STREAM = None

@@ -29,7 +29,8 @@ typedef struct ihipStream_t* hipStream_t;
 #endif
 
 enum { BYA_ACT_NONE = 0, BYA_ACT_GELU_TANH = 1, BYA_ACT_GELU_ERF = 2, BYA_ACT_RELU = 3, BYA_ACT_SILU = 4,
-       BYA_ACT_LEAKY_RELU = 5 };
+       BYA_ACT_LEAKY_RELU = 5,
+       BYA_ACT_GELU_TANH_IEEE = 6 /* bya_gemm_bf16 only: GELU(tanh) through expf + IEEE division (A/B reference) */ };
 
 /* library / build identification: returns the ABI version (bumped when a signature changes). */
 int bya_abi_version(void);

@@ -71,6 +71,9 @@ class Smi(threading.Thread):
                 "sclk_mhz_avg": avg(sclk), "sclk_mhz_min": min(sclk) if sclk else None}
 
 
+RAW = {}
+
+
 def median(a):
     a = sorted(a)
     return a[len(a) // 2]
@@ -138,19 +141,24 @@ def main():
                                  bias=bias)
                     if "split" not in kw:
                         arms[f"bya_{v}_plain_epilogue"] = plain
+                    if kw.get("act") == "gelu_tanh":
+                        def ieee(v=v):
+                            os.environ["BYA_GEMM_VARIANT"] = v
+                            ops.gemm(a, w, out, bias=bias, act="gelu_tanh_ieee")
+                        arms[f"bya_{v}_gelu_ieee_div"] = ieee
             times = {k: [] for k in arms}
-            for k, fn in arms.items():               # warm-up
-                time_once(fn, 2)
+            est = {k: time_once(fn, 2) for k, fn in arms.items()}               # warm-up + rough duration
             smi = {}
             for r in range(rounds):
                 for k, fn in arms.items():
                     mon = Smi() if (r == 0 and not args.quick) else None
                     if mon:
                         mon.start()
-                        time_once(fn, 60)                # ~60 ms or more under the sampler
+                        time_once(fn, max(20, int(1.5 / est[k])))       # ~1.5 s under the sampler
                         mon.stop_flag = True
                         mon.join()
                         smi[k] = mon.summary()
+                        RAW.setdefault("first_sample", mon.samples[0] if mon.samples else None)
                     times[k].append(time_once(fn, iters))
             row = {k: {"ms_median": round(median(t) * 1e3, 4), "ms_min": round(min(t) * 1e3, 4),
                        "tflops_median": round(fl / median(t), 1), "tflops_best": round(fl / min(t), 1),
@@ -164,6 +172,7 @@ def main():
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         with open(args.out, "w") as f:
             json.dump({"device": torch.cuda.get_device_name(0), "rounds": rounds, "iters": iters,
+                       "smi_raw_first_sample": RAW.get("first_sample"),
                        "note": "TFLOP/s = 2MNK / time; vendor_plain = torch F.linear (hipBLASLt) with bias, no fused "
                                "epilogue; bya_* = bya_gemm_bf16 with the engine's epilogue for that call site; "
                                "*_plain_epilogue = same kernel, bias only", "results": res}, f, indent=1)

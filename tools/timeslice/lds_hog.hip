@@ -31,6 +31,39 @@ __global__ __launch_bounds__(256) void rmw_victim(const float* __restrict__ in, 
     reinterpret_cast<float4*>(out)[v] = x;
 }
 
+// "broadcast-table" victim: the access pattern of the q/k-norm + RoPE kernel reduced to its loads.  A wave handles 8
+// consecutive (row, head) pairs, 8 lanes each; all pairs of one row read the SAME 256-byte row of a table (8 lanes x 32
+// bytes), i.e. every table address is requested by 8 lanes spread over the whole wave.  out = x * table (out of place).
+__global__ __launch_bounds__(256) void bcast_victim(const float* __restrict__ x, const float* __restrict__ table,
+                                                    float* __restrict__ out, long long npairs, int heads, int sc1) {
+    const int lane = threadIdx.x & 63;
+    const long long pair = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+    if (pair >= npairs) return;
+    const long long row = pair / heads;
+    const int d0 = (lane & 7) * 8;
+    const float* t = table + row * 64 + d0;
+    float4 a, b;
+    if (sc1) {
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, 0x7fffffff, 0x00020000);
+        const unsigned off = (unsigned)((row * 64 + d0) * 4);
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 ra = __builtin_amdgcn_raw_buffer_load_b128(rt, off, 0, 16), rb = __builtin_amdgcn_raw_buffer_load_b128(rt, off + 16, 0, 16);
+        a = __builtin_bit_cast(float4, ra); b = __builtin_bit_cast(float4, rb);
+    } else {
+        a = reinterpret_cast<const float4*>(t)[0]; b = reinterpret_cast<const float4*>(t)[1];
+    }
+    const float4 x0 = reinterpret_cast<const float4*>(x + pair * 64 + d0)[0], x1 = reinterpret_cast<const float4*>(x + pair * 64 + d0)[1];
+    float4 o0 = {x0.x * a.x, x0.y * a.y, x0.z * a.z, x0.w * a.w}, o1 = {x1.x * b.x, x1.y * b.y, x1.z * b.z, x1.w * b.w};
+    reinterpret_cast<float4*>(out + pair * 64 + d0)[0] = o0;
+    reinterpret_cast<float4*>(out + pair * 64 + d0)[1] = o1;
+}
+
+extern "C" int bcast_launch(const float* x, const float* table, float* out, long long npairs, int heads, int sc1,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(bcast_victim, dim3((unsigned)((npairs + 31) / 32)), dim3(256), 0, stream, x, table, out, npairs, heads, sc1);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int hog_launch(int* sink, int blocks, int iters, int lds_bytes, hipStream_t stream) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(lds_hog), hipFuncAttributeMaxDynamicSharedMemorySize,
                             lds_bytes) != hipSuccess) return -1;

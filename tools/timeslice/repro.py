@@ -39,12 +39,18 @@ def load_hog():
     lib = ctypes.CDLL(LIB)
     lib.hog_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.victim_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
+    lib.bcast_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
+                                 ctypes.c_int, ctypes.c_void_p]
     return lib
 
 
+# *_sentinel: the same disturber, but EVERY buffer of the disturber process (plus a 3 GiB ballast allocated first, so that
+# it covers the virtual addresses the victim process uses) holds the bit pattern of fp32 123.0 -- a victim output that
+# shows the sentinel proves that bytes crossed from the other process.
 DISTURBERS = ["none", "hog64", "hog96", "hog128", "hog132", "hog136", "hog144", "hog160", "rowgemm_n512_132k",
-              "rowgemm_n1536_140k", "gemm256_128k", "attn_32k", "torch_matmul"]
-VICTIMS = ["rmw_inplace", "rmw_out", "qknorm_rope_inplace", "layernorm_out", "layernorm_inplace", "torch_mul_inplace",
+              "rowgemm_n1536_140k", "gemm256_128k", "attn_32k", "torch_matmul", "rowgemm_sentinel"]
+VICTIMS = ["rmw_inplace", "rmw_out", "qknorm_rope_inplace", "qknorm_rope_sc1_inplace", "bcast_table", "bcast_table_sc1",
+           "qknorm_norope_inplace", "layernorm_out", "layernorm_inplace", "torch_mul_inplace",
            "torch_layernorm_out"]
 
 
@@ -53,6 +59,7 @@ def disturber_main(cmd_q, ack_q):
     from bind_your_avatar_implementation_amd import ops
     dev = torch.device("cuda:0")
     hog = load_hog()
+    ballast = torch.full((3 << 28,), 0x42F60000, dtype=torch.int32, device=dev)       # 3 GiB of fp32 123.0, allocated FIRST
     sink = torch.zeros(4, dtype=torch.int32, device=dev)
     bf = lambda *s: (torch.randn(*s, device=dev)).to(torch.bfloat16)
     x512, o1536, o512 = bf(35100, 512), torch.empty(35100, 1536, dtype=torch.bfloat16, device=dev), bf(35100, 512)
@@ -62,12 +69,21 @@ def disturber_main(cmd_q, ack_q):
     aq, ak, av = bf(1, 4096, 3072), bf(1, 4096, 3072), bf(1, 4096, 3072)
     ao = torch.empty_like(aq)
     stream = torch.cuda.current_stream().cuda_stream
+    sent = lambda *s: torch.full(s, 123.0, dtype=torch.bfloat16, device=dev)
+    sx, so = sent(35100, 512), sent(35100, 1536)
+    spk = ops.pack_rowgemm512(sent(1536, 512), sent(1536), sent(512), sent(512))
+    for k in ("colsum", "cvec"):
+        spk[k].fill_(123.0)
+    print("disturber: ballast at", hex(ballast.data_ptr()), "x512 at", hex(x512.data_ptr()), flush=True)
 
     def once(name):
         if name.startswith("hog"):
             assert hog.hog_launch(sink.data_ptr(), 256, 40, int(name[3:]) * 1024, stream) == 0
         elif name == "rowgemm_n1536_140k":
             ops.rowgemm512(x512, pk1536, o1536)
+        elif name == "rowgemm_sentinel":
+            ops.rowgemm512(sx, spk, so)
+            so.fill_(123.0)
         elif name == "rowgemm_n512_132k":
             ops.rowgemm512(x512, pk512, o512)
         elif name == "gemm256_128k":
@@ -124,6 +140,9 @@ def main():
     wD = (1 + 0.1 * torch.randn(D, device=dev, generator=g)).to(torch.bfloat16)
     bD = (0.05 * torch.randn(D, device=dev, generator=g)).to(torch.bfloat16)
     cos, sin = torch.randn(S - 226, 64, device=dev, generator=g), torch.randn(S - 226, 64, device=dev, generator=g)
+    npairs = pris_f.numel() // 64
+    table = torch.randn((npairs + 47) // 48, 64, device=dev, generator=g)          # one 256-byte row per 48 pairs
+    print("victim: cos at", hex(cos.data_ptr()), "table at", hex(table.data_ptr()), "pris_q at", hex(pris_q.data_ptr()), flush=True)
     wf, wq, wk = torch.empty_like(pris_f), torch.empty_like(pris_q), torch.empty_like(pris_k)
     of, oq = torch.empty_like(pris_f), torch.empty_like(pris_q)
 
@@ -141,6 +160,24 @@ def main():
             wq.copy_(pris_q)
             wk.copy_(pris_k)
             ops.qknorm_rope(wq, wk, w64, b64, w64, b64, cos, sin, heads=48, text_rows=226, k_scale=0.18)
+            return (wq, wk)
+        if name == "qknorm_rope_sc1_inplace":           # same kernel, cos / sin read past the vector L1
+            os.environ["BYA_QKNORM_TABLE_SC1"] = "1"
+            try:
+                wq.copy_(pris_q)
+                wk.copy_(pris_k)
+                ops.qknorm_rope(wq, wk, w64, b64, w64, b64, cos, sin, heads=48, text_rows=226, k_scale=0.18)
+            finally:
+                os.environ.pop("BYA_QKNORM_TABLE_SC1", None)
+            return (wq, wk)
+        if name in ("bcast_table", "bcast_table_sc1"):   # self-contained: the load pattern alone, out of place
+            assert hog.bcast_launch(pris_f.data_ptr(), table.data_ptr(), of.data_ptr(), npairs, 48,
+                                    int(name.endswith("sc1")), stream) == 0
+            return (of[:npairs * 64],)
+        if name == "qknorm_norope_inplace":             # same kernel, no cos / sin reads (every row is a "text" row)
+            wq.copy_(pris_q)
+            wk.copy_(pris_k)
+            ops.qknorm_rope(wq, wk, w64, b64, w64, b64, None, None, heads=48, text_rows=S, k_scale=0.18)
             return (wq, wk)
         if name == "layernorm_out":
             wq.copy_(pris_q)
@@ -170,13 +207,48 @@ def main():
             torch.cuda.synchronize()
             assert all(torch.equal(a, b) for a, b in zip(outs, golden[v])), f"{v} is not deterministic on its own"
 
+    # what a corrupted (row, head) group of the in-place q/k-norm looks like: the untouched input (the write never
+    # happened), the kernel applied TWICE (a replayed read-modify-write), or something else
+    def classify_qk(outs):
+        info = {"groups": 0, "equal_input": 0, "equal_applied_twice": 0, "other": 0, "examples": []}
+        for name, o, g1, x, g2 in (("q", outs[0], golden["qknorm_rope_inplace"][0], pris_q, twice[0]),
+                                   ("k", outs[1], golden["qknorm_rope_inplace"][1], pris_k, twice[1])):
+            og, gg, xg, tg = (t.view(-1, 64) for t in (o, g1, x, g2))
+            bad = (og != gg).any(dim=1).nonzero().flatten()
+            if bad.numel() == 0:
+                continue
+            eq_in = (og[bad] == xg[bad]).all(dim=1)
+            eq_tw = (og[bad] == tg[bad]).all(dim=1) & ~eq_in
+            info["groups"] += int(bad.numel())
+            info["equal_input"] += int(eq_in.sum())
+            info["equal_applied_twice"] += int(eq_tw.sum())
+            info["other"] += int((~eq_in & ~eq_tw).sum())
+            b = bad.cpu().tolist()
+            runs, start = [], b[0]
+            for a, c in zip(b, b[1:] + [None]):
+                if c != a + 1:
+                    runs.append((start, a - start + 1))
+                    start = c
+            info["examples"].append({"tensor": name, "bad_groups": len(b), "first_runs(group,len)": runs[:12],
+                                     "rows": sorted({g // 48 for g in b})[:12]})
+        return info
+
+    twice = None
+    if "qknorm_rope_inplace" in victims:
+        wq.copy_(pris_q)
+        wk.copy_(pris_k)
+        for _ in range(2):
+            ops.qknorm_rope(wq, wk, w64, b64, w64, b64, cos, sin, heads=48, text_rows=226, k_scale=0.18)
+        torch.cuda.synchronize()
+        twice = (wq.clone(), wk.clone())
+
     table = {}
     for d in args.disturbers.split(","):
         cmd_q.put(d)
         assert ack_q.get(timeout=120) == d
         row = {}
         for v in victims:
-            bad_runs, bad_elems = 0, 0
+            bad_runs, bad_elems, detail = 0, 0, None
             t0 = time.time()
             for _ in range(args.runs):
                 outs = victim(v)
@@ -184,8 +256,20 @@ def main():
                 n = sum(int((a != b).sum()) for a, b in zip(outs, golden[v]))
                 bad_runs += n > 0
                 bad_elems += n
+                if n > 0 and detail is None:
+                    detail = classify_qk(outs) if v == "qknorm_rope_inplace" else {}
+                    a, b = outs[0].reshape(-1), golden[v][0].reshape(-1)
+                    idx = (a != b).nonzero().flatten()
+                    detail["wrong_values_sample"] = [float(x) for x in a[idx[:16]].float().cpu()]
+                    detail["golden_values_sample"] = [float(x) for x in b[idx[:16]].float().cpu()]
+                    detail["max_abs_wrong"] = float(a[idx].float().abs().max())
+                    detail["wrong_lane_groups_mod64"] = sorted({int(i) % 512 // 64 for i in idx[:4096].cpu()}) \
+                        if v.startswith("bcast") else None
             row[v] = {"bad_runs": bad_runs, "runs": args.runs, "wrong_elements": bad_elems,
                       "ms_per_run": round((time.time() - t0) / args.runs * 1e3, 2)}
+            if detail is not None:
+                row[v]["first_bad_run"] = detail
+                print("   ", json.dumps(detail)[:600], flush=True)
         table[d] = row
         print(f"{d:20s} " + "  ".join(f"{v}:{row[v]['bad_runs']}/{args.runs}" for v in victims), flush=True)
     cmd_q.put("quit")
