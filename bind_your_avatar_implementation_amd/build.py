@@ -11,9 +11,9 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libbya_hip.so")
-SOURCES = ["gemm.hip", "gemm_w4.hip", "gemm_v3.hip", "attn.hip", "norm.hip", "misc.hip", "router.hip", "rowgemm.hip"]
+SOURCES = ["gemm.hip", "gemm_w4.hip", "gemm_v3.hip", "gemm_v4.hip", "attn.hip", "norm.hip", "misc.hip", "router.hip", "rowgemm.hip"]
 # translation units whose kernels keep their accumulators in AGPRs (one wave per SIMD, 512 registers)
-AGPR_SOURCES = {"gemm_w4.hip", "gemm_v3.hip"}
+AGPR_SOURCES = {"gemm_w4.hip", "gemm_v3.hip", "gemm_v4.hip"}
 
 
 def _hipcc():

@@ -306,11 +306,17 @@ int launch256(const GemmArgs& a, int batch, hipStream_t s) {
     const size_t lds = 2 * 512 * BK * 2;
     static std::atomic<unsigned long long> attr_done{0};
     if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256_kernel), (int)lds, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
-    // tuning switch, read per call so one process can A/B the variants (tools/gemm_probe.py): "w4" = the one-wave-per-
-    // SIMD kernel of gemm_w4.hip
+    // Kernel choice for the 256x256 tile shapes.  Default: the persistent one-wave-per-SIMD kernel (gemm_v4.hip) whenever
+    // its 16-byte epilogue accesses are aligned and K has at least three K-tiles, else the 8-wave kernel below.
+    // BYA_GEMM_VARIANT (read per call so one process can A/B them, tools/gemm_probe.py): "w8" = this file's 8-wave
+    // kernel, "w4" = gemm_w4.hip, "v3" = gemm_v3.hip, "v4" = gemm_v4.hip.
     const char* variant = getenv("BYA_GEMM_VARIANT");
+    const bool v4_ok = a.K >= 3 * BK && a.N % 8 == 0 && a.n_split % 8 == 0 && a.ldc % 8 == 0 && (!a.res || a.ldres % 8 == 0) &&
+        !(((uintptr_t)a.C | (uintptr_t)a.res | (uintptr_t)a.bias | (uintptr_t)a.gate0 | (uintptr_t)a.gate1) & 15) &&
+        a.c_bs % 8 == 0 && a.res_bs % 8 == 0 && a.gate_bs % 8 == 0 && a.c_split_stride % 8 == 0;
     if (variant && variant[0] == 'w' && variant[1] == '4') return bya_launch_gemm256w4(&a, batch, s);
     if (variant && variant[0] == 'v' && variant[1] == '3') return bya_launch_gemm256v3(&a, batch, s);
+    if (v4_ok && !(variant && variant[0] == 'w' && variant[1] == '8')) return bya_launch_gemm256p(&a, batch, s);
     BYA_LAUNCH(gemm256_kernel, grid, dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

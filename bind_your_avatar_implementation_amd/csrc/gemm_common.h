@@ -163,3 +163,5 @@ __device__ __forceinline__ void ds_read128(bf16x8& dst, uint32_t addr) {
 int bya_launch_gemm256w4(const void* args, int batch, hipStream_t stream);
 // defined in gemm_v3.hip (same flags): one wave per SIMD, LDS-DMA two K-tiles ahead
 int bya_launch_gemm256v3(const void* args, int batch, hipStream_t stream);
+// defined in gemm_v4.hip (same flags): persistent form of v3 with cross-tile prefetch and 16-byte epilogue accesses
+int bya_launch_gemm256p(const void* args, int batch, hipStream_t stream);

@@ -1,0 +1,823 @@
+// Persistent 256x256x64 bf16 GEMM: ONE wave per SIMD, LDS-DMA two K-tiles ahead, next output tile prefetched under the drain.
+//
+// Same operands, fused epilogue and ABI as gemm256_kernel (gemm.hip).  The K-loop is the one of gemm_v3.hip (4 waves,
+// 128 x 128 per wave, 256 accumulator registers in AGPRs, both k-steps' fragments in 128 VGPRs, a 2-stage 128 KiB LDS
+// ring whose stages are released in HALVES so that an LDS-DMA piece has one and a half K-tile periods to land).  What
+// this kernel adds is everything AROUND the K-loop, which at K = 3072 was a fifth of the time:
+//
+//  * PERSISTENT workgroups: one per CU, each walks its share of the output tiles (every XCD owns a contiguous range of
+//    the group-M tile order, so the A / W panels a round of 32 tiles shares are served by that XCD's L2).
+//  * NO PROLOGUE BUBBLE: the first two K-tiles of the NEXT output tile are requested while the current one drains --
+//    K-tile 0 during the last-but-one K-tile (its stage is free after that K-tile's barrier 3), K-tile 1 during the last
+//    K-tile -- so they have landed when the epilogue ends and the next K-loop starts with its fragment reads.
+//  * NO ACCUMULATOR ZEROING: the first K-tile's first k-step issues its MFMAs with C = 0.
+//  * 16-BYTE EPILOGUE ACCESSES: the W rows of a wave's 128-column span are staged in a permuted order (LDS slot (i, r)
+//    holds column ((r & 3) * 4 + (r >> 2)) * 8 + i), which makes a lane's eight accumulator tiles i = 0..7 hold EIGHT
+//    CONSECUTIVE output columns: bias / gate / residual are read and C is written 16 bytes per lane, 64 contiguous
+//    bytes per row and instruction -- half the memory instructions of the 8-byte epilogue, all requested in bursts
+//    (gemm_common.h explains why that matters: one serialized round trip per access otherwise).
+//
+// K-tile variants (tools/gen_gemm_v4_schedule.py holds the placement tables and rewrites the GENERATED block):
+//   A first (C = 0), B steady, C last-but-one (+ next tile's K-tile 0), D last (+ next tile's K-tile 1).  K >= 192.
+//
+// Inline-asm MFMAs are invisible to hipcc: (1) nothing tells it that an LDS return must not land in a register a queued
+// MFMA still has to read, so every fragment stays allocated to its fragment for the whole K-tile (KEEP8; without it the
+// drain tile of gemm_v3 computed wrong sums); (2) it pads no MFMA -> accvgpr_read hazard, so the epilogue starts behind
+// explicit s_nops.  This translation unit is compiled WITHOUT -amdgpu-mfma-vgpr-form (accumulators in AGPRs).
+#include "gemm_common.h"
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 raw_rsrc(const void* base, uint32_t bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
+    r.y = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// one 1-KiB LDS-DMA piece: 64 lanes x 16 bytes from per-lane global offsets to LDS [m0 .. m0 + 1024)
+template <int LDS_OFF>
+__device__ __forceinline__ void dma_piece(uint32_t lds_base, uint32_t voff, const i32x4& rsrc, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_base + LDS_OFF), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
+struct TileCoord { int z, m0, n0; bool valid; };
+
+// Wide epilogue of one wave.  The lane (fr = lane & 15, fq = lane >> 4) holds, for row block j and accumulator register e,
+// the EIGHT consecutive columns  n8 = n_wave + (4 e + fq) * 8 + i,  i = 0..7  in acc[i][j][e]  (W rows are staged in the
+// permuted order described at the top), of row  m = m_wave + 16 j + fr.
+template <int ACT, int JB>
+__device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wave, int n_wave, int fr, int fq,
+                                              const f32x4 (&acc)[8][8]) {
+    const bool has_res = p.res != nullptr, has_gate = p.gate0 != nullptr, has_bias = p.bias != nullptr;
+    const bool has_rs = p.bias_rowscale != nullptr;
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((has_res ? p.res : p.C) + (long long)z * p.res_bs), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.C + (long long)z * p.c_bs), 0, 0x7fffffff, 0x00020000);
+    const char* g0base = reinterpret_cast<const char*>(p.gate0 + (long long)z * p.gate_bs);
+    const char* g1base = reinterpret_cast<const char*>(p.gate1 + (long long)z * p.gate_bs);
+    u32x4 bv[4], g0[4], g1[4];
+    uint32_t ncb[4], colb[4];
+    bool nok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n8 = n_wave + (4 * e + fq) * 8;
+        nok[e] = n8 < p.N;                                       // N % 8 == 0 on this kernel's shapes (checked by the launcher)
+        ncb[e] = nok[e] ? (uint32_t)n8 * 2u : 0u;
+        colb[e] = (uint32_t)n8 * 2u;
+        if (p.n_split > 0) colb[e] = ((uint32_t)(n8 / p.n_split) * (uint32_t)p.c_split_stride + (uint32_t)(n8 % p.n_split)) * 2u;
+        bv[e] = has_bias ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.bias) + ncb[e]) : u32x4{0u, 0u, 0u, 0u};
+        if (has_gate) {
+            g0[e] = *reinterpret_cast<const u32x4*>(g0base + ncb[e]);
+            g1[e] = *reinterpret_cast<const u32x4*>(g1base + ncb[e]);
+        }
+    }
+#pragma unroll
+    for (int jb = 0; jb < 8; jb += JB) {
+        u32x4 rv[JB][4];
+        float rs[JB];
+        bool mok[JB];
+        uint32_t roff[JB], coff[JB];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+            const int m = m_wave + 16 * (jb + jj) + fr;
+            mok[jj] = m < p.M;
+            const uint32_t mc = mok[jj] ? (uint32_t)m : 0u;
+            rs[jj] = has_rs ? p.bias_rowscale[(long long)z * p.M + mc] : 1.0f;
+            roff[jj] = mc * (uint32_t)(p.ldres * 2);
+            coff[jj] = mc * (uint32_t)(p.ldc * 2);
+            if (has_res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    rv[jj][e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rsR, (mok[jj] && nok[e]) ? roff[jj] + ncb[e] : 0xffffffffu, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+            const int j = jb + jj;
+            const int m = m_wave + 16 * j + fr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float b8[8], v[8];
+                unpack8(bv[e], b8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = p.alpha * apply_act<ACT>(fmaf(rs[jj], b8[i], acc[i][j][e]), p.leaky);
+                if (has_gate) {
+                    float g8[8];
+                    unpack8(m < p.gate_split ? g0[e] : g1[e], g8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= g8[i];
+                }
+                if (has_res) {
+                    float r8[8];
+                    unpack8(rv[jj][e], r8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += r8[i];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(pack8(v), rsC, (mok[jj] && nok[e]) ? coff[jj] + colb[e] : 0xffffffffu, 0, 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_m, int tiles_n, int batch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 256, STAGE = (BM + BN) * BK * 2, TILE_A = BM * BK * 2;
+    static_assert(STAGE == 65536, "stage flip uses one address bit");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = p.K / BK;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // ---- this workgroup's output tiles: XCD x (= blockIdx % 8 under round-robin dispatch; speed only) owns a contiguous
+    // range of the tile order, its workgroups take every (gridDim / 8)-th tile of it, round after round
+    const int per_z = tiles_m * tiles_n, total = per_z * batch;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int cq = total >> 3, cr = total & 7;
+    const int base = (xcd < cr) ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+    const int end = base + cq + (xcd < cr ? 1 : 0);
+    auto coord = [&](int id) {
+        TileCoord c;
+        c.valid = id < end;
+        const int idz = c.valid ? id : base;
+        c.z = idz / per_z;
+        const int idt = idz - c.z * per_z;
+        constexpr int GM = 4;                      // group-M order: 4 row tiles sweep a column tile before moving on
+        const int per_group = GM * tiles_n;
+        const int group = idt / per_group, first_m = group * GM;
+        const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+        const int in_g = idt - group * per_group;
+        c.m0 = (first_m + in_g % gsz) * BM;
+        c.n0 = (in_g / gsz) * BN;
+        return c;
+    };
+    int id = base + slot;
+    TileCoord cur = coord(id);
+    if (!cur.valid) return;
+
+    // fragment read addresses (XOR swizzle on (row >> 1) & 7; row blocks are 16 rows = 2048 bytes apart)
+    const int a_row = wm * 128 + fr, w_row = wn * 128 + fr;
+    const int a_sw = (a_row >> 1) & 7, w_sw = (w_row >> 1) & 7;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+    uint32_t cA0 = lds0 + a_row * 128 + ((fq ^ a_sw) << 4), cA1 = lds0 + a_row * 128 + (((4 + fq) ^ a_sw) << 4);
+    uint32_t cW0 = lds0 + TILE_A + w_row * 128 + ((fq ^ w_sw) << 4);
+    uint32_t cW1 = lds0 + TILE_A + w_row * 128 + (((4 + fq) ^ w_sw) << 4);
+    uint32_t fill = __builtin_amdgcn_readfirstlane(lds0 + wave * 64 * 128);     // this wave's first A piece, current stage
+
+    // staging: wave w moves LDS slot rows [64w, 64w + 64) of the A tile and of the W tile, 8 one-KiB pieces (8 rows) each.
+    // A slot rows are tile rows; W slot row s = 128 h + 16 i + r holds tile column 128 h + ((r & 3) * 4 + (r >> 2)) * 8 + i
+    // (see the top).  The lane loads the source chunk that belongs at its linear LDS position (source-side XOR swizzle).
+    // The per-lane byte offsets are relative to the TILE origin and never change; the tile origin lives in the buffer
+    // descriptor (base advanced to the tile's first row, size = what is left of the matrix), so rows past M / N fall
+    // outside the descriptor and arrive as zeros, and an invalid (past-the-end) tile gets an empty descriptor.
+    uint32_t voA[8], voW[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int rl = wave * 64 + q * 8 + (lane >> 3);
+        const int r = rl & 15, i = (rl >> 4) & 7;
+        const int wcol = (rl & 128) + (((r & 3) << 2) | (r >> 2)) * 8 + i;
+        const int chunk16 = ((lane & 7) ^ ((rl >> 1) & 7)) * 16;
+        voA[q] = (uint32_t)rl * (uint32_t)(p.lda * 2) + chunk16;
+        voW[q] = (uint32_t)wcol * (uint32_t)(p.ldw * 2) + chunk16;
+    }
+    auto a_rsrc = [&](const TileCoord& c) {
+        const long long left = ((long long)(p.M - 1 - c.m0) * p.lda + p.K) * 2;
+        return raw_rsrc(p.A + (long long)c.z * p.a_bs + (long long)c.m0 * p.lda, c.valid && left > 0 ? (uint32_t)left : 0u);
+    };
+    auto w_rsrc = [&](const TileCoord& c) {
+        const long long left = ((long long)(p.N - 1 - c.n0) * p.ldw + p.K) * 2;
+        return raw_rsrc(p.W + (long long)c.n0 * p.ldw, c.valid && left > 0 ? (uint32_t)left : 0u);
+    };
+    i32x4 rsA = a_rsrc(cur), rsW = w_rsrc(cur);
+
+#define DMA_A(Q, BASE, VO, RS, SOFF) dma_piece<(Q) * 1024>(BASE, VO[Q], RS, SOFF)
+#define DMA_W(Q, BASE, VO, RS, SOFF) dma_piece<TILE_A + (Q) * 1024>(BASE, VO[Q], RS, SOFF)
+#define ALL8(M, ...) M(0, __VA_ARGS__); M(1, __VA_ARGS__); M(2, __VA_ARGS__); M(3, __VA_ARGS__); \
+                     M(4, __VA_ARGS__); M(5, __VA_ARGS__); M(6, __VA_ARGS__); M(7, __VA_ARGS__)
+    // ---- prologue of the FIRST tile only: K-tiles 0 and 1
+    ALL8(DMA_A, fill, voA, rsA, 0u);
+    ALL8(DMA_W, fill, voW, rsW, 0u);
+    ALL8(DMA_A, fill ^ STAGE, voA, rsA, (uint32_t)(BK * 2));
+    ALL8(DMA_W, fill ^ STAGE, voW, rsW, (uint32_t)(BK * 2));
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+
+    f32x4 acc[8][8];
+    bf16x8 fa[2][8], fw[2][8];
+
+    for (;;) {
+        // ---- K-tile 0 of this output tile has landed for this wave (prologue wait / the wait in front of the previous
+        // epilogue); make that true for everybody, then fetch its k-step-0 fragments
+        asm volatile("s_barrier" ::: "memory");
+#define RA(S, J) ds_read128<(J) * 2048>(fa[S][J], (S) ? cA1 : cA0)
+#define RW(S, I) ds_read128<(I) * 2048>(fw[S][I], (S) ? cW1 : cW0)
+        RA(0, 0); RA(0, 1); RA(0, 2); RA(0, 3); RA(0, 4); RA(0, 5); RA(0, 6); RA(0, 7);
+        RW(0, 0); RW(0, 1); RW(0, 2); RW(0, 3); RW(0, 4); RW(0, 5); RW(0, 6); RW(0, 7);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        const TileCoord nxt = coord(id + slots);
+        const i32x4 rsAn = a_rsrc(nxt), rsWn = w_rsrc(nxt);
+
+        // One K-tile, variant V (see the top); t = its index inside the output tile.
+        auto ktile = [&](int t, auto v_c) {
+            constexpr char V = decltype(v_c)::value;
+            const uint32_t soff = (uint32_t)((t + 2) * (BK * 2));
+#define MF(S, I, J) \
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(fw[S][I]), "v"(fa[S][J]))
+#define MFZ(S, I, J) \
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[I][J]) : "v"(fw[S][I]), "v"(fa[S][J]))
+#define DA(Q) DMA_A(Q, fill, voA, rsA, soff)
+#define DW(Q) DMA_W(Q, fill, voW, rsW, soff)
+#define PA(Q) DMA_A(Q, fill, voA, rsAn, 0u)
+#define PW(Q) DMA_W(Q, fill, voW, rsWn, 0u)
+#define QA(Q) DMA_A(Q, fill, voA, rsAn, (uint32_t)(BK * 2))
+#define QW(Q) DMA_W(Q, fill, voW, rsWn, (uint32_t)(BK * 2))
+#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define BAR() asm volatile("s_barrier" ::: "memory")
+#define FLIP0() do { cA0 ^= STAGE; cW0 ^= STAGE; } while (0)
+#define FLIP1() do { cA1 ^= STAGE; cW1 ^= STAGE; fill ^= STAGE; } while (0)
+            // GENERATED-BEGIN (tools/gen_gemm_v4_schedule.py)
+        if constexpr (V == 'A') {
+            MFZ(0, 0, 0);  RA(1, 0);
+            MFZ(0, 0, 1);  RA(1, 1);
+            MFZ(0, 0, 2);  RA(1, 2);
+            MFZ(0, 0, 3);  RA(1, 3);
+            MFZ(0, 0, 4);  RA(1, 4);
+            MFZ(0, 0, 5);  RA(1, 5);
+            MFZ(0, 0, 6);  RA(1, 6);
+            MFZ(0, 0, 7);  RA(1, 7);
+            MFZ(0, 1, 0);
+            MFZ(0, 1, 1);
+            MFZ(0, 1, 2);
+            MFZ(0, 1, 3);
+            MFZ(0, 1, 4);
+            MFZ(0, 1, 5);
+            MFZ(0, 1, 6);
+            MFZ(0, 1, 7);  WAIT_LGKM0(); BAR();
+            MFZ(0, 2, 0);  DA(0);
+            MFZ(0, 2, 1);
+            MFZ(0, 2, 2);  RW(1, 0);
+            MFZ(0, 2, 3);
+            MFZ(0, 2, 4);  DA(1);
+            MFZ(0, 2, 5);
+            MFZ(0, 2, 6);  RW(1, 1);
+            MFZ(0, 2, 7);
+            MFZ(0, 3, 0);  DA(2);
+            MFZ(0, 3, 1);
+            MFZ(0, 3, 2);  RW(1, 2);
+            MFZ(0, 3, 3);
+            MFZ(0, 3, 4);  DA(3);
+            MFZ(0, 3, 5);
+            MFZ(0, 3, 6);  RW(1, 3);
+            MFZ(0, 3, 7);
+            MFZ(0, 4, 0);  DA(4);
+            MFZ(0, 4, 1);
+            MFZ(0, 4, 2);  RW(1, 4);
+            MFZ(0, 4, 3);
+            MFZ(0, 4, 4);  DA(5);
+            MFZ(0, 4, 5);
+            MFZ(0, 4, 6);  RW(1, 5);
+            MFZ(0, 4, 7);
+            MFZ(0, 5, 0);  DA(6);
+            MFZ(0, 5, 1);
+            MFZ(0, 5, 2);  RW(1, 6);
+            MFZ(0, 5, 3);
+            MFZ(0, 5, 4);  DA(7);
+            MFZ(0, 5, 5);
+            MFZ(0, 5, 6);  RW(1, 7);
+            MFZ(0, 5, 7);
+            MFZ(0, 6, 0);
+            MFZ(0, 6, 1);
+            MFZ(0, 6, 2);
+            MFZ(0, 6, 3);
+            MFZ(0, 6, 4);
+            MFZ(0, 6, 5);
+            MFZ(0, 6, 6);
+            MFZ(0, 6, 7);  WAIT_LGKM0(); BAR();
+            MFZ(0, 7, 0);  DW(0);
+            MFZ(0, 7, 1);
+            MFZ(0, 7, 2);
+            MFZ(0, 7, 3);
+            MFZ(0, 7, 4);  DW(1);
+            MFZ(0, 7, 5);
+            MFZ(0, 7, 6);
+            MFZ(0, 7, 7);
+            MF(1, 0, 0);  DW(2);
+            MF(1, 0, 1);
+            MF(1, 0, 2);
+            MF(1, 0, 3);
+            MF(1, 0, 4);  DW(3);
+            MF(1, 0, 5);
+            MF(1, 0, 6);
+            MF(1, 0, 7);
+            MF(1, 1, 0);  DW(4);
+            MF(1, 1, 1);
+            MF(1, 1, 2);
+            MF(1, 1, 3);  WAIT_VM(13); BAR(); FLIP0();
+            MF(1, 1, 4);  RA(0, 0);
+            MF(1, 1, 5);
+            MF(1, 1, 6);  DW(5);
+            MF(1, 1, 7);  RA(0, 1);
+            MF(1, 2, 0);
+            MF(1, 2, 1);
+            MF(1, 2, 2);  RA(0, 2);
+            MF(1, 2, 3);
+            MF(1, 2, 4);
+            MF(1, 2, 5);  RA(0, 3);
+            MF(1, 2, 6);
+            MF(1, 2, 7);
+            MF(1, 3, 0);  RA(0, 4);
+            MF(1, 3, 1);
+            MF(1, 3, 2);  DW(6);
+            MF(1, 3, 3);  RA(0, 5);
+            MF(1, 3, 4);
+            MF(1, 3, 5);
+            MF(1, 3, 6);  RA(0, 6);
+            MF(1, 3, 7);
+            MF(1, 4, 0);
+            MF(1, 4, 1);  RA(0, 7);
+            MF(1, 4, 2);
+            MF(1, 4, 3);
+            MF(1, 4, 4);  RW(0, 0);
+            MF(1, 4, 5);
+            MF(1, 4, 6);  DW(7);
+            MF(1, 4, 7);  RW(0, 1);
+            MF(1, 5, 0);
+            MF(1, 5, 1);
+            MF(1, 5, 2);  RW(0, 2);
+            MF(1, 5, 3);
+            MF(1, 5, 4);
+            MF(1, 5, 5);  RW(0, 3);
+            MF(1, 5, 6);
+            MF(1, 5, 7);
+            MF(1, 6, 0);  RW(0, 4);
+            MF(1, 6, 1);
+            MF(1, 6, 2);
+            MF(1, 6, 3);  RW(0, 5);
+            MF(1, 6, 4);
+            MF(1, 6, 5);
+            MF(1, 6, 6);  RW(0, 6);
+            MF(1, 6, 7);
+            MF(1, 7, 0);
+            MF(1, 7, 1);  RW(0, 7);
+            MF(1, 7, 2);
+            MF(1, 7, 3);
+            MF(1, 7, 4);
+            MF(1, 7, 5);
+            MF(1, 7, 6);
+            MF(1, 7, 7);  WAIT_LGKM0(); FLIP1();
+        } else if constexpr (V == 'B') {
+            MF(0, 0, 0);  RA(1, 0);
+            MF(0, 0, 1);  RA(1, 1);
+            MF(0, 0, 2);  RA(1, 2);
+            MF(0, 0, 3);  RA(1, 3);
+            MF(0, 0, 4);  RA(1, 4);
+            MF(0, 0, 5);  RA(1, 5);
+            MF(0, 0, 6);  RA(1, 6);
+            MF(0, 0, 7);  RA(1, 7);
+            MF(0, 1, 0);
+            MF(0, 1, 1);
+            MF(0, 1, 2);
+            MF(0, 1, 3);
+            MF(0, 1, 4);
+            MF(0, 1, 5);
+            MF(0, 1, 6);
+            MF(0, 1, 7);  WAIT_LGKM0(); BAR();
+            MF(0, 2, 0);  DA(0);
+            MF(0, 2, 1);
+            MF(0, 2, 2);  RW(1, 0);
+            MF(0, 2, 3);
+            MF(0, 2, 4);  DA(1);
+            MF(0, 2, 5);
+            MF(0, 2, 6);  RW(1, 1);
+            MF(0, 2, 7);
+            MF(0, 3, 0);  DA(2);
+            MF(0, 3, 1);
+            MF(0, 3, 2);  RW(1, 2);
+            MF(0, 3, 3);
+            MF(0, 3, 4);  DA(3);
+            MF(0, 3, 5);
+            MF(0, 3, 6);  RW(1, 3);
+            MF(0, 3, 7);
+            MF(0, 4, 0);  DA(4);
+            MF(0, 4, 1);
+            MF(0, 4, 2);  RW(1, 4);
+            MF(0, 4, 3);
+            MF(0, 4, 4);  DA(5);
+            MF(0, 4, 5);
+            MF(0, 4, 6);  RW(1, 5);
+            MF(0, 4, 7);
+            MF(0, 5, 0);  DA(6);
+            MF(0, 5, 1);
+            MF(0, 5, 2);  RW(1, 6);
+            MF(0, 5, 3);
+            MF(0, 5, 4);  DA(7);
+            MF(0, 5, 5);
+            MF(0, 5, 6);  RW(1, 7);
+            MF(0, 5, 7);
+            MF(0, 6, 0);
+            MF(0, 6, 1);
+            MF(0, 6, 2);
+            MF(0, 6, 3);
+            MF(0, 6, 4);
+            MF(0, 6, 5);
+            MF(0, 6, 6);
+            MF(0, 6, 7);  WAIT_LGKM0(); BAR();
+            MF(0, 7, 0);  DW(0);
+            MF(0, 7, 1);
+            MF(0, 7, 2);
+            MF(0, 7, 3);
+            MF(0, 7, 4);  DW(1);
+            MF(0, 7, 5);
+            MF(0, 7, 6);
+            MF(0, 7, 7);
+            MF(1, 0, 0);  DW(2);
+            MF(1, 0, 1);
+            MF(1, 0, 2);
+            MF(1, 0, 3);
+            MF(1, 0, 4);  DW(3);
+            MF(1, 0, 5);
+            MF(1, 0, 6);
+            MF(1, 0, 7);
+            MF(1, 1, 0);  DW(4);
+            MF(1, 1, 1);
+            MF(1, 1, 2);
+            MF(1, 1, 3);  WAIT_VM(13); BAR(); FLIP0();
+            MF(1, 1, 4);  RA(0, 0);
+            MF(1, 1, 5);
+            MF(1, 1, 6);  DW(5);
+            MF(1, 1, 7);  RA(0, 1);
+            MF(1, 2, 0);
+            MF(1, 2, 1);
+            MF(1, 2, 2);  RA(0, 2);
+            MF(1, 2, 3);
+            MF(1, 2, 4);
+            MF(1, 2, 5);  RA(0, 3);
+            MF(1, 2, 6);
+            MF(1, 2, 7);
+            MF(1, 3, 0);  RA(0, 4);
+            MF(1, 3, 1);
+            MF(1, 3, 2);  DW(6);
+            MF(1, 3, 3);  RA(0, 5);
+            MF(1, 3, 4);
+            MF(1, 3, 5);
+            MF(1, 3, 6);  RA(0, 6);
+            MF(1, 3, 7);
+            MF(1, 4, 0);
+            MF(1, 4, 1);  RA(0, 7);
+            MF(1, 4, 2);
+            MF(1, 4, 3);
+            MF(1, 4, 4);  RW(0, 0);
+            MF(1, 4, 5);
+            MF(1, 4, 6);  DW(7);
+            MF(1, 4, 7);  RW(0, 1);
+            MF(1, 5, 0);
+            MF(1, 5, 1);
+            MF(1, 5, 2);  RW(0, 2);
+            MF(1, 5, 3);
+            MF(1, 5, 4);
+            MF(1, 5, 5);  RW(0, 3);
+            MF(1, 5, 6);
+            MF(1, 5, 7);
+            MF(1, 6, 0);  RW(0, 4);
+            MF(1, 6, 1);
+            MF(1, 6, 2);
+            MF(1, 6, 3);  RW(0, 5);
+            MF(1, 6, 4);
+            MF(1, 6, 5);
+            MF(1, 6, 6);  RW(0, 6);
+            MF(1, 6, 7);
+            MF(1, 7, 0);
+            MF(1, 7, 1);  RW(0, 7);
+            MF(1, 7, 2);
+            MF(1, 7, 3);
+            MF(1, 7, 4);
+            MF(1, 7, 5);
+            MF(1, 7, 6);
+            MF(1, 7, 7);  WAIT_LGKM0(); FLIP1();
+        } else if constexpr (V == 'C') {
+            MF(0, 0, 0);  RA(1, 0);
+            MF(0, 0, 1);  RA(1, 1);
+            MF(0, 0, 2);  RA(1, 2);
+            MF(0, 0, 3);  RA(1, 3);
+            MF(0, 0, 4);  RA(1, 4);
+            MF(0, 0, 5);  RA(1, 5);
+            MF(0, 0, 6);  RA(1, 6);
+            MF(0, 0, 7);  RA(1, 7);
+            MF(0, 1, 0);
+            MF(0, 1, 1);
+            MF(0, 1, 2);
+            MF(0, 1, 3);
+            MF(0, 1, 4);
+            MF(0, 1, 5);
+            MF(0, 1, 6);
+            MF(0, 1, 7);  WAIT_LGKM0();
+            MF(0, 2, 0);
+            MF(0, 2, 1);
+            MF(0, 2, 2);  RW(1, 0);
+            MF(0, 2, 3);
+            MF(0, 2, 4);
+            MF(0, 2, 5);
+            MF(0, 2, 6);  RW(1, 1);
+            MF(0, 2, 7);
+            MF(0, 3, 0);
+            MF(0, 3, 1);
+            MF(0, 3, 2);  RW(1, 2);
+            MF(0, 3, 3);
+            MF(0, 3, 4);
+            MF(0, 3, 5);
+            MF(0, 3, 6);  RW(1, 3);
+            MF(0, 3, 7);
+            MF(0, 4, 0);
+            MF(0, 4, 1);
+            MF(0, 4, 2);  RW(1, 4);
+            MF(0, 4, 3);
+            MF(0, 4, 4);
+            MF(0, 4, 5);
+            MF(0, 4, 6);  RW(1, 5);
+            MF(0, 4, 7);
+            MF(0, 5, 0);
+            MF(0, 5, 1);
+            MF(0, 5, 2);  RW(1, 6);
+            MF(0, 5, 3);
+            MF(0, 5, 4);
+            MF(0, 5, 5);
+            MF(0, 5, 6);  RW(1, 7);
+            MF(0, 5, 7);
+            MF(0, 6, 0);
+            MF(0, 6, 1);
+            MF(0, 6, 2);
+            MF(0, 6, 3);
+            MF(0, 6, 4);
+            MF(0, 6, 5);
+            MF(0, 6, 6);
+            MF(0, 6, 7);  WAIT_LGKM0();
+            MF(0, 7, 0);
+            MF(0, 7, 1);
+            MF(0, 7, 2);
+            MF(0, 7, 3);
+            MF(0, 7, 4);
+            MF(0, 7, 5);
+            MF(0, 7, 6);
+            MF(0, 7, 7);
+            MF(1, 0, 0);
+            MF(1, 0, 1);
+            MF(1, 0, 2);
+            MF(1, 0, 3);
+            MF(1, 0, 4);
+            MF(1, 0, 5);
+            MF(1, 0, 6);
+            MF(1, 0, 7);
+            MF(1, 1, 0);
+            MF(1, 1, 1);
+            MF(1, 1, 2);
+            MF(1, 1, 3);  WAIT_VM(0); BAR(); FLIP0();
+            MF(1, 1, 4);  RA(0, 0);
+            MF(1, 1, 5);  PA(0);
+            MF(1, 1, 6);
+            MF(1, 1, 7);  RA(0, 1);
+            MF(1, 2, 0);  PA(1);
+            MF(1, 2, 1);
+            MF(1, 2, 2);  RA(0, 2);
+            MF(1, 2, 3);  PA(2);
+            MF(1, 2, 4);
+            MF(1, 2, 5);  RA(0, 3);
+            MF(1, 2, 6);  PA(3);
+            MF(1, 2, 7);
+            MF(1, 3, 0);  RA(0, 4);
+            MF(1, 3, 1);  PA(4);
+            MF(1, 3, 2);
+            MF(1, 3, 3);  RA(0, 5);
+            MF(1, 3, 4);  PA(5);
+            MF(1, 3, 5);
+            MF(1, 3, 6);  RA(0, 6);
+            MF(1, 3, 7);  PA(6);
+            MF(1, 4, 0);
+            MF(1, 4, 1);  RA(0, 7);
+            MF(1, 4, 2);  PA(7);
+            MF(1, 4, 3);
+            MF(1, 4, 4);  RW(0, 0);
+            MF(1, 4, 5);  PW(0);
+            MF(1, 4, 6);
+            MF(1, 4, 7);  RW(0, 1);
+            MF(1, 5, 0);  PW(1);
+            MF(1, 5, 1);
+            MF(1, 5, 2);  RW(0, 2);
+            MF(1, 5, 3);  PW(2);
+            MF(1, 5, 4);
+            MF(1, 5, 5);  RW(0, 3);
+            MF(1, 5, 6);  PW(3);
+            MF(1, 5, 7);
+            MF(1, 6, 0);  RW(0, 4);
+            MF(1, 6, 1);  PW(4);
+            MF(1, 6, 2);
+            MF(1, 6, 3);  RW(0, 5);
+            MF(1, 6, 4);  PW(5);
+            MF(1, 6, 5);
+            MF(1, 6, 6);  RW(0, 6);
+            MF(1, 6, 7);  PW(6);
+            MF(1, 7, 0);
+            MF(1, 7, 1);  RW(0, 7);
+            MF(1, 7, 2);  PW(7);
+            MF(1, 7, 3);
+            MF(1, 7, 4);
+            MF(1, 7, 5);
+            MF(1, 7, 6);
+            MF(1, 7, 7);  WAIT_LGKM0(); FLIP1();
+        } else if constexpr (V == 'D') {
+            MF(0, 0, 0);  RA(1, 0);
+            MF(0, 0, 1);  RA(1, 1);
+            MF(0, 0, 2);  RA(1, 2);
+            MF(0, 0, 3);  RA(1, 3);
+            MF(0, 0, 4);  RA(1, 4);
+            MF(0, 0, 5);  RA(1, 5);
+            MF(0, 0, 6);  RA(1, 6);
+            MF(0, 0, 7);  RA(1, 7);
+            MF(0, 1, 0);
+            MF(0, 1, 1);
+            MF(0, 1, 2);
+            MF(0, 1, 3);
+            MF(0, 1, 4);
+            MF(0, 1, 5);
+            MF(0, 1, 6);
+            MF(0, 1, 7);  WAIT_LGKM0();
+            MF(0, 2, 0);
+            MF(0, 2, 1);
+            MF(0, 2, 2);  RW(1, 0);
+            MF(0, 2, 3);
+            MF(0, 2, 4);
+            MF(0, 2, 5);
+            MF(0, 2, 6);  RW(1, 1);
+            MF(0, 2, 7);
+            MF(0, 3, 0);
+            MF(0, 3, 1);
+            MF(0, 3, 2);  RW(1, 2);
+            MF(0, 3, 3);
+            MF(0, 3, 4);
+            MF(0, 3, 5);
+            MF(0, 3, 6);  RW(1, 3);
+            MF(0, 3, 7);
+            MF(0, 4, 0);
+            MF(0, 4, 1);
+            MF(0, 4, 2);  RW(1, 4);
+            MF(0, 4, 3);
+            MF(0, 4, 4);
+            MF(0, 4, 5);
+            MF(0, 4, 6);  RW(1, 5);
+            MF(0, 4, 7);
+            MF(0, 5, 0);
+            MF(0, 5, 1);
+            MF(0, 5, 2);  RW(1, 6);
+            MF(0, 5, 3);
+            MF(0, 5, 4);
+            MF(0, 5, 5);
+            MF(0, 5, 6);  RW(1, 7);
+            MF(0, 5, 7);
+            MF(0, 6, 0);
+            MF(0, 6, 1);
+            MF(0, 6, 2);
+            MF(0, 6, 3);
+            MF(0, 6, 4);
+            MF(0, 6, 5);
+            MF(0, 6, 6);
+            MF(0, 6, 7);  WAIT_LGKM0(); BAR();
+            MF(0, 7, 0);
+            MF(0, 7, 1);  QA(0);
+            MF(0, 7, 2);
+            MF(0, 7, 3);
+            MF(0, 7, 4);  QA(1);
+            MF(0, 7, 5);
+            MF(0, 7, 6);
+            MF(0, 7, 7);  QA(2);
+            MF(1, 0, 0);
+            MF(1, 0, 1);
+            MF(1, 0, 2);  QA(3);
+            MF(1, 0, 3);
+            MF(1, 0, 4);
+            MF(1, 0, 5);  QA(4);
+            MF(1, 0, 6);
+            MF(1, 0, 7);
+            MF(1, 1, 0);  QA(5);
+            MF(1, 1, 1);
+            MF(1, 1, 2);
+            MF(1, 1, 3);  QA(6);
+            MF(1, 1, 4);
+            MF(1, 1, 5);
+            MF(1, 1, 6);  QA(7);
+            MF(1, 1, 7);
+            MF(1, 2, 0);
+            MF(1, 2, 1);  QW(0);
+            MF(1, 2, 2);
+            MF(1, 2, 3);
+            MF(1, 2, 4);  QW(1);
+            MF(1, 2, 5);
+            MF(1, 2, 6);
+            MF(1, 2, 7);  QW(2);
+            MF(1, 3, 0);
+            MF(1, 3, 1);
+            MF(1, 3, 2);  QW(3);
+            MF(1, 3, 3);
+            MF(1, 3, 4);
+            MF(1, 3, 5);  QW(4);
+            MF(1, 3, 6);
+            MF(1, 3, 7);
+            MF(1, 4, 0);  QW(5);
+            MF(1, 4, 1);
+            MF(1, 4, 2);
+            MF(1, 4, 3);  QW(6);
+            MF(1, 4, 4);
+            MF(1, 4, 5);
+            MF(1, 4, 6);  QW(7);
+            MF(1, 4, 7);
+            MF(1, 5, 0);
+            MF(1, 5, 1);
+            MF(1, 5, 2);
+            MF(1, 5, 3);
+            MF(1, 5, 4);
+            MF(1, 5, 5);
+            MF(1, 5, 6);
+            MF(1, 5, 7);
+            MF(1, 6, 0);
+            MF(1, 6, 1);
+            MF(1, 6, 2);
+            MF(1, 6, 3);
+            MF(1, 6, 4);
+            MF(1, 6, 5);
+            MF(1, 6, 6);
+            MF(1, 6, 7);
+            MF(1, 7, 0);
+            MF(1, 7, 1);
+            MF(1, 7, 2);
+            MF(1, 7, 3);
+            MF(1, 7, 4);
+            MF(1, 7, 5);
+            MF(1, 7, 6);
+            MF(1, 7, 7);  FLIP0(); FLIP1();
+        }
+            // GENERATED-END
+#define KEEP8(F, S) asm volatile("" :: "v"(F[S][0]), "v"(F[S][1]), "v"(F[S][2]), "v"(F[S][3]), "v"(F[S][4]), \
+                                      "v"(F[S][5]), "v"(F[S][6]), "v"(F[S][7]))
+            KEEP8(fa, 0); KEEP8(fw, 0); KEEP8(fa, 1); KEEP8(fw, 1);
+#undef KEEP8
+#undef MF
+#undef MFZ
+#undef DA
+#undef DW
+#undef PA
+#undef PW
+#undef QA
+#undef QW
+#undef WAIT_LGKM0
+#undef WAIT_VM
+#undef BAR
+#undef FLIP0
+#undef FLIP1
+        };
+        ktile(0, IntTag<'A'>{});
+        for (int t = 1; t + 2 < nk; ++t) ktile(t, IntTag<'B'>{});
+        ktile(nk - 2, IntTag<'C'>{});
+        ktile(nk - 1, IntTag<'D'>{});
+#undef RA
+#undef RW
+        // K-tile 0 of the next output tile (16 pieces, requested during variant C) has landed once all but the 16 younger
+        // pieces of its K-tile 1 have; the MFMAs are inline asm, so pad their last results before the epilogue reads them
+        asm volatile("s_waitcnt vmcnt(16)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+        auto run = [&](auto act_tag) {
+            epilogue_wide<decltype(act_tag)::value, 2>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc);
+        };
+        dispatch_act_big(p.act, run);
+
+        if (!nxt.valid) break;
+        id += slots;
+        cur = nxt;
+        rsA = rsAn;
+        rsW = rsWn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the (empty-descriptor) prefetch pieces of the tile after the last
+}
+
+}  // namespace
+
+int bya_launch_gemm256p(const void* args, int batch, hipStream_t s) {
+    const GemmArgs& a = *static_cast<const GemmArgs*>(args);
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+    const long long total = (long long)tiles_m * tiles_n * batch;
+    int blocks = (int)(total < 256 ? (total + 7) / 8 * 8 : 256);
+    const size_t lds = 2 * 512 * BK * 2;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256p_kernel), (int)lds, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
+    BYA_LAUNCH(gemm256p_kernel, dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, batch);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}

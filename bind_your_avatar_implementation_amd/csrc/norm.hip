@@ -115,6 +115,10 @@ struct QkArgs {
     int table_sc1;     // 1: read cos / sin past the vector L1 (sc1 loads) -- see tools/timeslice/repro.py
 };
 
+// DBG (tools/timeslice/repro.py, experiment builds only; 0 = the product kernel):
+//   1: the cos / sin loads are drained (vmcnt(0)) before any later instruction may touch their address registers
+//   2: 32-bit index arithmetic (no 64-bit division sequences in front of the RoPE branch)
+template <int DBG>
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
     // one 8-lane group per (row, head) pair, pairs enumerated row-major over all batches: any head count works
     const int lane = threadIdx.x & 63;
@@ -123,9 +127,18 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
     if (pair >= 2 * pairs_per_tensor) return;
     const int which = pair >= pairs_per_tensor;      // 0 = q, 1 = k
     long long rest = pair - which * pairs_per_tensor;
-    const int head = (int)(rest % p.heads); rest /= p.heads;
-    const int s = (int)(rest % p.S);
-    const int z = (int)(rest / p.S);
+    int head, s, z;
+    if constexpr (DBG == 2) {
+        const unsigned r32 = (unsigned)rest, h32 = (unsigned)p.heads, S32 = (unsigned)p.S;
+        head = (int)(r32 % h32);
+        const unsigned r2 = r32 / h32;
+        s = (int)(r2 % S32);
+        z = (int)(r2 / S32);
+    } else {
+        head = (int)(rest % p.heads); rest /= p.heads;
+        s = (int)(rest % p.S);
+        z = (int)(rest / p.S);
+    }
     const int d0 = (lane & 7) * 8;
     bf16_t* base = (which ? p.k : p.q) + z * p.bs + (long long)s * p.ld + head * 64 + d0;
     const bf16_t* w = (which ? p.kw : p.qw) + d0;
@@ -164,6 +177,11 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
         } else {
             c0 = *reinterpret_cast<const f32x4*>(c); c1 = *reinterpret_cast<const f32x4*>(c + 4);
             s0 = *reinterpret_cast<const f32x4*>(sn); s1 = *reinterpret_cast<const f32x4*>(sn + 4);
+        }
+        if constexpr (DBG == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(s0), "+v"(s1));
+            __builtin_amdgcn_sched_barrier(0);
         }
         const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
         const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
@@ -229,6 +247,10 @@ extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb,
     }
     const long long total = ((long long)batch * S * heads * 2 + 7) / 8;      // waves: 8 (row, head) pairs each
     dim3 grid((unsigned)((total + 3) / 4));
-    BYA_LAUNCH(qknorm_rope_kernel, grid, dim3(256), 0, stream, a);
+    const char* dbg = getenv("BYA_QKNORM_DBG");
+    const int d = dbg ? atoi(dbg) : 0;
+    if (d == 1) BYA_LAUNCH(qknorm_rope_kernel<1>, grid, dim3(256), 0, stream, a);
+    else if (d == 2) BYA_LAUNCH(qknorm_rope_kernel<2>, grid, dim3(256), 0, stream, a);
+    else BYA_LAUNCH(qknorm_rope_kernel<0>, grid, dim3(256), 0, stream, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

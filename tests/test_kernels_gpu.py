@@ -180,20 +180,19 @@ def test_rowgemm512(ops, dev, M, N, ln, res, act, nsplit):
     assert torch.isfinite(out.float()).all()
 
 
-@pytest.mark.parametrize("variant", ["default", "w4", "v3"])
+@pytest.mark.parametrize("variant", ["v4", "w8", "w4", "v3"])
 def test_gemm_big_tile_kernels_whole_suite(dev, variant):
     """Every GEMM parity test again with the 256x256 pipelined kernels FORCED for all shapes (BYA_GEMM_TILE=4: ragged M / N,
     K of one, two and three K-tiles -- the prologue / drain paths of the software pipelines -- batches, split outputs,
-    gate + residual epilogues) and, per parameter, the kernel variant BYA_GEMM_VARIANT selects: "default" = 8 waves
-    (gemm.hip), "w4" = 4 waves with register-staged loads (gemm_w4.hip), "v3" = 4 waves with LDS-DMA two K-tiles ahead
-    (gemm_v3.hip).  Runs in a child process so the variables cannot leak into other tests."""
+    gate + residual epilogues) and, per parameter, the kernel variant BYA_GEMM_VARIANT selects: "v4" = the default
+    (persistent, gemm_v4.hip), "w8" = 8 waves (gemm.hip), "w4" = 4 waves with register-staged loads (gemm_w4.hip), "v3" = 4 waves with LDS-DMA two K-tiles ahead
+    (gemm_v3.hip), "v4" = its persistent form with cross-tile prefetch and 16-byte epilogue accesses (gemm_v4.hip; K >= 192,
+    shorter K falls back to the default kernel).  Runs in a child process so the variables cannot leak into other tests."""
     import os
     import subprocess
     import sys
     env = dict(os.environ, BYA_GEMM_TILE="4")
-    env.pop("BYA_GEMM_VARIANT", None)
-    if variant != "default":
-        env["BYA_GEMM_VARIANT"] = variant
+    env["BYA_GEMM_VARIANT"] = variant
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k",
                         "gemm and not rowgemm and not whole_suite"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

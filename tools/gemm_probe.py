@@ -116,7 +116,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="one round, few iterations (for rocprofv3 passes)")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--variants", default="default,w4")
+    ap.add_argument("--variants", default="v4,w8")
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--data", default="gaussian,zeros")
     ap.add_argument("--rounds", type=int, default=5)

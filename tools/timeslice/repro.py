@@ -49,7 +49,8 @@ def load_hog():
 # shows the sentinel proves that bytes crossed from the other process.
 DISTURBERS = ["none", "hog64", "hog96", "hog128", "hog132", "hog136", "hog144", "hog160", "rowgemm_n512_132k",
               "rowgemm_n1536_140k", "gemm256_128k", "attn_32k", "torch_matmul", "rowgemm_sentinel"]
-VICTIMS = ["rmw_inplace", "rmw_out", "qknorm_rope_inplace", "qknorm_rope_sc1_inplace", "bcast_table", "bcast_table_sc1",
+VICTIMS = ["rmw_inplace", "rmw_out", "qknorm_rope_inplace", "qknorm_rope_dbg1_inplace", "qknorm_rope_dbg2_inplace",
+           "qknorm_rope_sc1_inplace", "bcast_table", "bcast_table_sc1",
            "qknorm_norope_inplace", "layernorm_out", "layernorm_inplace", "torch_mul_inplace",
            "torch_layernorm_out"]
 
@@ -161,6 +162,16 @@ def main():
             wk.copy_(pris_k)
             ops.qknorm_rope(wq, wk, w64, b64, w64, b64, cos, sin, heads=48, text_rows=226, k_scale=0.18)
             return (wq, wk)
+        if name in ("qknorm_rope_dbg1_inplace", "qknorm_rope_dbg2_inplace"):
+            # experiment builds of the kernel: 1 = table loads drained before anything else runs, 2 = 32-bit index maths
+            os.environ["BYA_QKNORM_DBG"] = name[15]
+            try:
+                wq.copy_(pris_q)
+                wk.copy_(pris_k)
+                ops.qknorm_rope(wq, wk, w64, b64, w64, b64, cos, sin, heads=48, text_rows=226, k_scale=0.18)
+            finally:
+                os.environ.pop("BYA_QKNORM_DBG", None)
+            return (wq, wk)
         if name == "qknorm_rope_sc1_inplace":           # same kernel, cos / sin read past the vector L1
             os.environ["BYA_QKNORM_TABLE_SC1"] = "1"
             try:
@@ -242,7 +253,7 @@ def main():
         torch.cuda.synchronize()
         twice = (wq.clone(), wk.clone())
 
-    table = {}
+    results = {}
     for d in args.disturbers.split(","):
         cmd_q.put(d)
         assert ack_q.get(timeout=120) == d
@@ -270,7 +281,7 @@ def main():
             if detail is not None:
                 row[v]["first_bad_run"] = detail
                 print("   ", json.dumps(detail)[:600], flush=True)
-        table[d] = row
+        results[d] = row
         print(f"{d:20s} " + "  ".join(f"{v}:{row[v]['bad_runs']}/{args.runs}" for v in victims), flush=True)
     cmd_q.put("quit")
     try:
@@ -280,7 +291,7 @@ def main():
     child.join(timeout=30)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
-        json.dump({"runs": args.runs, "table": table,
+        json.dump({"runs": args.runs, "table": results,
                    "note": "bad_runs = victim runs whose output differed bit-wise from the run with an idle disturber; "
                            "two processes share cuda:0"}, f, indent=1)
     print("wrote", args.out)
