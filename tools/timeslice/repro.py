@@ -208,6 +208,8 @@ def main():
         raise KeyError(name)
 
     victims = args.victims.split(",")
+    if "qknorm_rope_inplace" in victims and "qknorm_norope_inplace" not in victims:
+        victims.append("qknorm_norope_inplace")
     golden = {}
     for v in victims:                      # disturber idle
         outs = victim(v)
@@ -221,7 +223,9 @@ def main():
     # what a corrupted (row, head) group of the in-place q/k-norm looks like: the untouched input (the write never
     # happened), the kernel applied TWICE (a replayed read-modify-write), or something else
     def classify_qk(outs):
-        info = {"groups": 0, "equal_input": 0, "equal_applied_twice": 0, "other": 0, "examples": []}
+        info = {"groups": 0, "equal_input": 0, "equal_applied_twice": 0, "equal_norm_without_rope": 0, "all_zero": 0,
+                "other": 0, "examples": []}
+        nr = golden.get("qknorm_norope_inplace")
         for name, o, g1, x, g2 in (("q", outs[0], golden["qknorm_rope_inplace"][0], pris_q, twice[0]),
                                    ("k", outs[1], golden["qknorm_rope_inplace"][1], pris_k, twice[1])):
             og, gg, xg, tg = (t.view(-1, 64) for t in (o, g1, x, g2))
@@ -230,10 +234,15 @@ def main():
                 continue
             eq_in = (og[bad] == xg[bad]).all(dim=1)
             eq_tw = (og[bad] == tg[bad]).all(dim=1) & ~eq_in
+            eq_nr = torch.zeros_like(eq_in)
+            if nr is not None:          # the q/k LayerNorm was applied but the RoPE branch was not taken
+                eq_nr = (og[bad] == nr[0 if name == "q" else 1].view(-1, 64)[bad]).all(dim=1) & ~eq_in & ~eq_tw
             info["groups"] += int(bad.numel())
             info["equal_input"] += int(eq_in.sum())
             info["equal_applied_twice"] += int(eq_tw.sum())
-            info["other"] += int((~eq_in & ~eq_tw).sum())
+            info["equal_norm_without_rope"] += int(eq_nr.sum())
+            info["all_zero"] += int((og[bad] == 0).all(dim=1).sum())
+            info["other"] += int((~eq_in & ~eq_tw & ~eq_nr).sum())
             b = bad.cpu().tolist()
             runs, start = [], b[0]
             for a, c in zip(b, b[1:] + [None]):
