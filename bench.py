@@ -38,17 +38,43 @@ PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chi
 
 
 CONFIG0_TFLOP = 12.1            # one DiT block + every injection at 17776 tokens
+BLOCK_TFLOP = 7.9               # one CogVideoXBlock at 17776 tokens
 
 
-def cpu_baseline(threads, budget_s=45.0):
-    """Bounded CPU sample in the form SURVEY.md section 8d asks for: BASELINE configs[0] -- ONE DiT block with every
-    injection (face perceiver + Embedding Router + masked combine, audio cross-attention + combine, LocalFacialExtractor,
-    audio projector, patch embed / head) at 13x30x45 + 226 tokens -- through the oracle's restatement of
-    transformer.forward, on this box's host cores: bf16 (1 warm-up + up to 3 timed) and fp32 (1 timed) inside a time
-    budget, extrapolated linearly by FLOPs (12.1 of 443.9 TFLOP) to a full 42-layer step.  Baseline only."""
+def cpu_baseline(threads, config0=False):
+    """Bounded CPU sample on this box's host cores (baseline only -- never the thing measured).
+
+    Default (about 30 s): the oracle's CogVideoXBlock (7.9 of the 443.9 TFLOP of a step) at 17776 tokens in bf16, one
+    warm-up + one timed forward, extrapolated linearly by FLOPs.
+    ``config0`` (--cpu-baseline-config0; SURVEY.md section 8d form, minutes: one bf16 forward took 133 s on the 256-core
+    host of the round-2 GPU box, profiles/README.md): BASELINE configs[0] -- ONE DiT block with every injection (face
+    perceiver + Embedding Router + masked combine, audio cross-attention + combine, LocalFacialExtractor, audio
+    projector, patch embed / head), 1 face + 1 audio stream -- through the oracle's restatement of transformer.forward,
+    bf16 warm-up + up to 3 timed and one fp32 forward."""
+    torch.set_num_threads(threads)
+    if not config0:
+        from oracle.model import CogVideoXBlock
+        from oracle.layers import get_3d_rotary_pos_embed
+        with torch.no_grad():
+            blk = CogVideoXBlock(dim=3072, num_attention_heads=48, attention_head_dim=64, time_embed_dim=512,
+                                 attention_bias=True).to(torch.bfloat16).eval()
+            hid = torch.randn(1, 17550, 3072).to(torch.bfloat16)
+            enc = torch.randn(1, 226, 3072).to(torch.bfloat16)
+            temb = torch.randn(1, 512).to(torch.bfloat16)
+            rope = get_3d_rotary_pos_embed(64, ((0, 0), (30, 45)), (30, 45), 13)
+            ts = []
+            for _ in range(2):
+                t0 = time.time()
+                blk(hid, enc, temb, rope)
+                ts.append(time.time() - t0)
+        dt = ts[1]
+        return {"value": 1.0 / (dt * TFLOP_PER_STEP / BLOCK_TFLOP), "unit": "steps/s", "cores": threads, "kind": "port",
+                "block_forward_s": {"bf16_warmup": round(ts[0], 2), "bf16": round(ts[1], 2)},
+                "sample": f"1 CogVideoXBlock forward ({BLOCK_TFLOP} of {TFLOP_PER_STEP} TFLOP/step) at 17776 tokens, bf16, "
+                          f"oracle restatement on torch CPU, {dt:.1f} s after one warm-up; extrapolated linearly by FLOPs "
+                          f"to a full step (the config-0 form with every injection: --cpu-baseline-config0)"}
     from oracle.model import OracleTransformer
     from bind_your_avatar_implementation_amd.synth import synth_inputs
-    torch.set_num_threads(threads)
     kw = dict(MODEL_KW, num_layers=1, cross_attn_interval=1)
     with torch.device("meta"):
         orc = OracleTransformer(**kw)
@@ -77,30 +103,26 @@ def cpu_baseline(threads, budget_s=45.0):
         return out
 
     times = {"bf16": [], "fp32": []}
-    t_start = time.time()
     with torch.no_grad():
         o16, i16 = orc.to(torch.bfloat16), cast(torch.bfloat16)
         t0 = time.time()
         o16(**i16)                                    # warm-up (thread pools, oneDNN primitive caches)
         warm = time.time() - t0
-        while len(times["bf16"]) < 3 and (not times["bf16"] or time.time() - t_start + warm < budget_s * 0.6):
+        for _ in range(3):
             t0 = time.time()
             o16(**i16)
             times["bf16"].append(time.time() - t0)
-        if time.time() - t_start < budget_s:
-            o32, i32 = orc.float(), cast(torch.float32)
-            t0 = time.time()
-            o32(**i32)
-            times["fp32"].append(time.time() - t0)
+        o32, i32 = orc.float(), cast(torch.float32)
+        t0 = time.time()
+        o32(**i32)
+        times["fp32"].append(time.time() - t0)
     dt = sorted(times["bf16"])[len(times["bf16"]) // 2]
-    steps_per_s = 1.0 / (dt * TFLOP_PER_STEP / CONFIG0_TFLOP)
-    return {"value": steps_per_s, "unit": "steps/s", "cores": threads, "kind": "port",
+    return {"value": 1.0 / (dt * TFLOP_PER_STEP / CONFIG0_TFLOP), "unit": "steps/s", "cores": threads, "kind": "port",
             "config0_forward_s": {"bf16_warmup": round(warm, 2), "bf16": [round(t, 2) for t in times["bf16"]],
                                   "fp32": [round(t, 2) for t in times["fp32"]]},
             "sample": f"BASELINE configs[0]: 1 DiT block + all injections (1 face + 1 audio stream), 17776 tokens, oracle "
-                      f"restatement on torch CPU, bf16 median {dt:.1f} s over {len(times['bf16'])} timed runs after a "
-                      f"warm-up ({CONFIG0_TFLOP} of {TFLOP_PER_STEP} TFLOP/step); value = extrapolated linearly by FLOPs "
-                      f"to the 42-layer step"}
+                      f"restatement on torch CPU, bf16 median {dt:.1f} s over 3 timed runs after a warm-up "
+                      f"({CONFIG0_TFLOP} of {TFLOP_PER_STEP} TFLOP/step); value = extrapolated linearly by FLOPs"}
 
 
 def pmc_traffic(world, *kernels):
@@ -126,6 +148,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=42, help="debug only: anything but 42 is not the headline config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-config0", action="store_true",
+                    help="time the config-0 form (1 block + every injection) instead of the block alone: minutes of CPU")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N = 1)")
     ap.add_argument("--latent-hw", type=int, nargs=2, default=[60, 90], metavar=("H", "W"),
@@ -262,7 +286,7 @@ def main():
                 if len(cands) > 1:
                     res["attn_roofline" if cands[1] is attn_roof else "gemm_roofline"] = cands[1]
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            res["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1, config0=args.cpu_baseline_config0)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

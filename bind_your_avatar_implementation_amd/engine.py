@@ -57,6 +57,7 @@ class DenoiseEngine:
         self.mix_before_projection = os.environ.get("BYA_MIX_BEFORE_PROJECTION", "1") != "0"
         self._inv_cache = {}
         self._ws_key, self._ws = None, None
+        self._parts = {}
         if model.is_train_audio and not model.is_train_face:
             raise RuntimeError("audio injection needs the face router's logits (models/transformer.py:860)")
         self._tensors = list(model.parameters()) + list(model.buffers())
@@ -144,6 +145,21 @@ class DenoiseEngine:
             self.conv_w = cw.permute(0, 2, 1).reshape(cw.shape[0], -1).contiguous()
 
     # ------------------------------------------------------------------------------------------ helpers
+    def _shard(self, rank, world, S, Tt, group):
+        """The row partition object of this geometry; cached, because it owns the preallocated exchange buffers."""
+        key = ("seq", rank, world, S, Tt, id(group))
+        sh = self._parts.get(key)
+        if sh is None:
+            sh = self._parts[key] = SeqShard(rank, world, S, Tt, group)
+        return sh
+
+    def _router_partition(self, sh, pairs, per_frame):
+        key = ("router", sh.rank, sh.world, pairs, per_frame, id(sh.group))
+        rp = self._parts.get(key)
+        if rp is None:
+            rp = self._parts[key] = RouterPartition(sh.rank, sh.world, pairs, per_frame, sh.group)
+        return rp
+
     def _buf(self, name, *shape):
         t = self._ws.get(name)
         if t is None or tuple(t.shape) != tuple(shape):
@@ -334,7 +350,7 @@ class DenoiseEngine:
         per_frame, N = ht * wt, T * ht * wt
         Tt = encoder_hidden_states.shape[1]
         S = Tt + N
-        sh = SeqShard(getattr(m, "_seq_rank", 0), getattr(m, "_seq_world", 1), S, Tt, getattr(m, "_seq_group", None))
+        sh = self._shard(getattr(m, "_seq_rank", 0), getattr(m, "_seq_world", 1), S, Tt, getattr(m, "_seq_group", None))
         if sh.world > 1 and B != 1:
             raise NotImplementedError("sequence-parallel execution shards ONE sample; split a CFG batch over rank groups")
         S_loc, Tt_loc, N_loc, v0, v1 = sh.S_loc, sh.Tt_loc, sh.N_loc, sh.v0, sh.v1
@@ -425,13 +441,17 @@ class DenoiseEngine:
                         # exchange A, head-parallel: the projection writes per-destination column blocks, q/k-norm +
                         # RoPE run on the local rows, then rows are traded for heads (every element moves once)
                         ops.gemm(xn[0], self.qkv_w[i], qkvb[0], bias=self.qkv_b[i], split=(Dl, S_loc * Dl))
+                        # v needs no norm: its exchange runs on the RCCL stream underneath the q/k-norm + RoPE kernel
+                        pending = [sh.rows_to_heads(qkvb[2 * W:], vh, async_op=True)]
                         ops.qknorm_rope(qkvb[:W], qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
                                         at.norm_k.bias, cos, sin, heads=H // W,
                                         text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
                                         k_scale=self.k_scale)
-                        sh.rows_to_heads(qkvb[:W], qh)
-                        sh.rows_to_heads(qkvb[W:2 * W], kh)
-                        sh.rows_to_heads(qkvb[2 * W:], vh)
+                        pending += [sh.rows_to_heads(qkvb[:W], qh, async_op=True),
+                                    sh.rows_to_heads(qkvb[W:2 * W], kh, async_op=True)]
+                        for h in pending:
+                            if h is not None:
+                                h.wait()            # the compute stream waits (no host synchronisation)
                         ops.self_attention(qh[None], kh[None], vh[None], oh[None], heads=H // W, tag="joint", prescaled=True,
                                            score_bound=self.score_bound[i])
                         sh.heads_to_rows(oh, xn[0])
@@ -537,7 +557,8 @@ class DenoiseEngine:
                       scale0=mo[:, D:], shift1=mo, scale1=mo[:, D:], split=0, mod_batch_stride=mbs)
         co = m.proj_out.weight.shape[0]
         y = ops.gemm(xo, m.proj_out.weight, buf("y", B, N_loc, co), bias=m.proj_out.bias)
-        y = sh.gather_video_rows(y)                             # every rank returns the full latent prediction
+        if sh.world > 1:                                        # every rank returns the full latent prediction
+            y = sh.gather_video_rows(y, out=buf("y_full", B, N, co))
         out = torch.empty(B, T, co // 4, Hh, Ww, dtype=torch.bfloat16, device=self.dev)
         ops.unpatchify(y, out)
         return out
@@ -578,7 +599,8 @@ class DenoiseEngine:
                               eps=r.norm.eps)
         # exchange B: the spatial / temporal attentions mix tokens across the whole clip -> gather the 512-wide
         # router rows (36 MB) and run the four small blocks replicated
-        rs = sh.gather_video_rows(rs)
+        if sh.world > 1:
+            rs = sh.gather_video_rows(rs, out=buf("r_s_full", B, n_id, N, F))
         R = B * n_id * N
         rs2, rn = rs.view(R, F), buf("r_n", R, F)
         qkv, ra, rh = buf("r_qkv", R, 3 * F), buf("r_a", R, F), buf("r_h", R, F)
@@ -623,7 +645,7 @@ class DenoiseEngine:
         r = m.router
         N, N_loc, F = T * per_frame, sh.N_loc, r.feat_dim
         pairs = n_id * T
-        rp = RouterPartition(sh.rank, sh.world, pairs, per_frame, sh.group)
+        rp = self._router_partition(sh, pairs, per_frame)
         qk = qp.shape[-1]
         qn = buf("r_qn", 1, N_loc, qk)
         ops.layernorm(qp, qn, self.r_nq_w, self.r_nq_b, eps=r.norm_q.eps)
@@ -631,7 +653,7 @@ class DenoiseEngine:
         rs_loc = buf("r_s_loc", 1, n_id, N_loc, F)
         ops.router_scores(qr[0], kr[0].contiguous(), r.norm.weight, r.norm.bias, self.r_pos[sh.v0:sh.v1], rs_loc[0],
                           n_id, N_loc, eps=r.norm.eps)
-        rs_full = sh.gather_video_rows(rs_loc)                                # token ranges -> everyone (36 MB, once)
+        rs_full = sh.gather_video_rows(rs_loc, out=buf("r_s_full", 1, n_id, N, F))     # token ranges -> everyone (36 MB, once)
         xa = buf("rp_xa", rp.nPA, per_frame, F)
         xa.copy_(rs_full.view(pairs, per_frame, F)[rp.pa0:rp.pa1])
         RA, RB = rp.nPA * per_frame, pairs * rp.nLB
@@ -668,7 +690,7 @@ class DenoiseEngine:
         fp = r.final_proj[0]
         lb = buf("rp_logits_b", T * rp.nLB, n_id)
         ops.router_head(xb.view(n_id, T * rp.nLB, F), fp.weight, fp.bias, lb, n_id, T * rp.nLB)
-        logits = rp.gather_b_rows(lb.view(T, rp.nLB, n_id)).view(1, N, n_id)
+        logits = rp.gather_b_rows(lb.view(T, rp.nLB, n_id), out=buf("rp_logits", T, per_frame, n_id)).view(1, N, n_id)
         if taps is not None:
             taps[f"router{ca}_b0"] = logits.clone()
         return logits[:, sh.v0:sh.v1].contiguous()

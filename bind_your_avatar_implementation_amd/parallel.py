@@ -46,12 +46,25 @@ class SeqShard:
         self.v1 = self.r1 - self.Tt
         self.N_loc = self.v1 - self.v0
         self.N = self.S - self.Tt
+        self._bufs = {}
+
+    # ---- exchange buffers: allocated once per (name, shape), reused by every layer of every step --------------------
+    def buf(self, name, shape, like, zero=False):
+        key = (name, tuple(shape), like.dtype, like.device)
+        t = self._bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(*shape, dtype=like.dtype, device=like.device)
+            self._bufs[key] = t
+        return t
+
+    def staged(self, t):
+        """gloo has no device collectives (single-GPU functional tests, CPU tests): stage through host memory."""
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
 
     # ---- collectives ------------------------------------------------------------------------------------
     def _all_gather(self, out, local):
-        """RCCL all-gather; with the gloo backend (single-GPU functional tests, CPU tests) device tensors are
-        staged through host memory because gloo has no device all-gather."""
-        if local.is_cuda and dist.get_backend(self.group) == "gloo":
+        """RCCL all-gather; with the gloo backend device tensors are staged through host memory."""
+        if self.staged(local):
             host_out = torch.empty(out.shape, dtype=out.dtype)
             dist.all_gather_into_tensor(host_out, local.cpu(), group=self.group)
             out.copy_(host_out)
@@ -64,14 +77,18 @@ class SeqShard:
         if self.even:
             pad = local.contiguous()
         else:
-            pad = local.new_zeros(C, self.S_max, F)
+            pad = self.buf("gp_pad", (C, self.S_max, F), local, zero=True)
             pad[:, :self.S_loc] = local
-        full = torch.empty(self.world * C, self.S_max, F, dtype=local.dtype, device=local.device)
+        full = self.buf("gp_full", (self.world * C, self.S_max, F), local)
         self._all_gather(full, pad)                                       # rank-major concatenation along dim 0
         full = full.view(self.world, C, self.S_max, F)
+        out = self.buf("gp_out", (C, self.S, F), local)
         if self.even:
-            return full.permute(1, 0, 2, 3).reshape(C, self.S, F)
-        return torch.cat([full[j, :, :n] for j, n in enumerate(self.sizes)], dim=1)
+            out.view(C, self.world, self.S_max, F).copy_(full.permute(1, 0, 2, 3))
+        else:
+            for j, n in enumerate(self.sizes):
+                out[:, self.starts[j]:self.starts[j] + n] = full[j, :, :n]
+        return out
 
     def gather_rows(self, local, out=None):
         """[S_loc, F] per rank -> [S, F], rank-major == global row order."""
@@ -86,60 +103,67 @@ class SeqShard:
         if out is not None:
             out.copy_(res)
             return out
-        return res
+        return res.clone()                  # (res lives in a reused staging buffer)
 
-    def gather_video_rows(self, local_video, scratch=None):
+    def gather_video_rows(self, local_video, scratch=None, out=None):
         """[..., N_loc, F] per rank (rank 0 owns fewer video rows: its shard starts with the text rows)
-        -> [..., N, F].  Implemented as a row all-gather of Tt_loc junk rows + the video rows."""
+        -> [..., N, F].  Implemented as a row all-gather of Tt_loc junk rows + the video rows.  ``out``: where the result
+        goes (the engine passes a workspace tensor; without it a fresh tensor is returned); the staging buffers of the
+        exchange itself are allocated once per shape and reused."""
         if self.world == 1:
             return local_video
         lead = local_video.shape[:-2]
         F = local_video.shape[-1]
         flat = local_video.reshape(-1, self.N_loc, F)
         C = flat.shape[0]
-        pad = torch.empty(C, self.S_loc, F, dtype=flat.dtype, device=flat.device) if scratch is None else scratch
+        pad = self.buf("gv_pad", (C, self.S_loc, F), flat, zero=True) if scratch is None else scratch
         pad[:, self.Tt_loc:] = flat
-        if self.Tt_loc:
+        if self.Tt_loc and scratch is not None:
             pad[:, :self.Tt_loc] = 0
         full = self._gather_padded(pad)[:, self.Tt:]
-        return full.reshape(*lead, self.N, F).contiguous()
+        if out is None:
+            out = torch.empty(*lead, self.N, F, dtype=flat.dtype, device=flat.device)
+        out.view(C, self.N, F).copy_(full)
+        return out
 
     # ---- head-parallel ("Ulysses") exchange for the joint self-attention ---------------------------------------
     # All-gathering K and V replicates 2*S*D elements onto every rank (191 MB received per rank and layer at 8 GPUs);
     # trading rows for heads moves every element of q, k, v (and of the output) exactly once: 48 MB per rank and layer.
-    def _a2a(self, out, inp, out_splits=None, in_splits=None):
-        if inp.is_cuda and dist.get_backend(self.group) == "gloo":
+    def _a2a(self, out, inp, out_splits=None, in_splits=None, async_op=False):
+        """all_to_all_single.  ``async_op``: the exchange is enqueued on the process group's own RCCL stream (behind the
+        work already on the compute stream) and a handle is returned; kernels launched afterwards on the compute stream
+        overlap with it until ``handle.wait()`` makes the compute stream wait (no host synchronisation either way)."""
+        if self.staged(inp):
             host = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(host, inp.cpu(), out_splits, in_splits, group=self.group)
             out.copy_(host)
-        else:
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+            return None
+        return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
 
-    def rows_to_heads(self, blocks, out=None):
+    def rows_to_heads(self, blocks, out=None, async_op=False):
         """blocks [world, S_loc, Dl]: this rank's rows, column block j = the heads owned by rank j
-        -> [S, Dl]: ALL rows (global order) of this rank's heads."""
+        -> [S, Dl]: ALL rows (global order) of this rank's heads.  Returns ``out`` (or the async handle)."""
         W, S_loc, Dl = blocks.shape
         if out is None:
             out = torch.empty(self.S, Dl, dtype=blocks.dtype, device=blocks.device)
         if self.even:
-            self._a2a(out.view(-1), blocks.reshape(-1))
+            h = self._a2a(out.view(-1), blocks.reshape(-1), async_op=async_op)
         else:
-            self._a2a(out.view(-1), blocks.reshape(-1), [n * Dl for n in self.sizes], [S_loc * Dl] * W)
-        return out
+            h = self._a2a(out.view(-1), blocks.reshape(-1), [n * Dl for n in self.sizes], [S_loc * Dl] * W, async_op=async_op)
+        return h if async_op else out
 
     def heads_to_rows(self, o_heads, out=None):
         """o_heads [S, Dl] (all rows, this rank's heads) -> [S_loc, world*Dl] (this rank's rows, all heads)."""
         S, Dl = o_heads.shape
-        recv = torch.empty(self.world, self.S_loc, Dl, dtype=o_heads.dtype, device=o_heads.device)
+        recv = self.buf("h2r_recv", (self.world, self.S_loc, Dl), o_heads)
         if self.even:
             self._a2a(recv.view(-1), o_heads.reshape(-1))
         else:
             self._a2a(recv.view(-1), o_heads.reshape(-1), [self.S_loc * Dl] * self.world, [n * Dl for n in self.sizes])
-        res = recv.permute(1, 0, 2).reshape(self.S_loc, self.world * Dl)
-        if out is not None:
-            out.copy_(res)
-            return out
-        return res.contiguous()
+        if out is None:
+            out = torch.empty(self.S_loc, self.world * Dl, dtype=o_heads.dtype, device=o_heads.device)
+        out.view(self.S_loc, self.world, Dl).copy_(recv.permute(1, 0, 2))        # one strided copy, no temporaries
+        return out
 
     def frame_segments(self, per_frame):
         """Local video rows split at frame boundaries: [(frame, local_start, length)]."""
@@ -183,6 +207,15 @@ class RouterPartition:
         self.pa0, self.pa1 = self.PA[rank]
         self.lb0, self.lb1 = self.LB[rank]
         self.nPA, self.nLB = self.pa1 - self.pa0, self.lb1 - self.lb0
+        self._bufs = {}
+
+    def buf(self, name, shape, like, zero=False):
+        key = (name, tuple(shape), like.dtype, like.device)
+        t = self._bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(*shape, dtype=like.dtype, device=like.device)
+            self._bufs[key] = t
+        return t
 
     def _a2a(self, out, inp, out_splits, in_splits):
         if inp.is_cuda and dist.get_backend(self.group) == "gloo":      # single-GPU functional test path
@@ -195,10 +228,14 @@ class RouterPartition:
     def a_to_b(self, xa, xb=None):
         """xa [nPA, per_frame, F] -> xb [pairs, nLB, F]."""
         F = xa.shape[-1]
-        send = torch.cat([xa[:, a:b].reshape(-1) for a, b in self.LB])
+        in_splits = [self.nPA * (b - a) * F for a, b in self.LB]
+        send = self.buf("a2b_send", (sum(in_splits),), xa)
+        off = 0
+        for (a, b), n in zip(self.LB, in_splits):                  # pack per destination: W slice copies, no temporaries
+            send[off:off + n].view(self.nPA, b - a, F).copy_(xa[:, a:b])
+            off += n
         if xb is None:
             xb = torch.empty(self.pairs, self.nLB, F, dtype=xa.dtype, device=xa.device)
-        in_splits = [self.nPA * (b - a) * F for a, b in self.LB]
         out_splits = [(b - a) * self.nLB * F for a, b in self.PA]
         self._a2a(xb.view(-1), send, out_splits, in_splits)
         return xb
@@ -210,7 +247,7 @@ class RouterPartition:
             xa = torch.empty(self.nPA, self.per_frame, F, dtype=xb.dtype, device=xb.device)
         in_splits = [(b - a) * self.nLB * F for a, b in self.PA]
         out_splits = [self.nPA * (b - a) * F for a, b in self.LB]
-        recv = torch.empty(sum(out_splits), dtype=xb.dtype, device=xb.device)
+        recv = self.buf("b2a_recv", (sum(out_splits),), xb)
         self._a2a(recv, xb.reshape(-1), out_splits, in_splits)
         off = 0
         for a, b in self.LB:
@@ -219,13 +256,13 @@ class RouterPartition:
             off += n
         return xa
 
-    def gather_b_rows(self, yb):
+    def gather_b_rows(self, yb, out=None):
         """yb [T_or_pairs, nLB, C] per rank (location-major) -> [T_or_pairs, per_frame, C] on every rank."""
         lead, C = yb.shape[0], yb.shape[-1]
         nmax = max(b - a for a, b in self.LB)
-        pad = torch.zeros(lead, nmax, C, dtype=yb.dtype, device=yb.device)
+        pad = self.buf("gb_pad", (lead, nmax, C), yb, zero=True)
         pad[:, :self.nLB] = yb
-        full = torch.empty(self.world * lead, nmax, C, dtype=yb.dtype, device=yb.device)
+        full = self.buf("gb_full", (self.world * lead, nmax, C), yb)
         if pad.is_cuda and dist.get_backend(self.group) == "gloo":
             host = torch.empty(full.shape, dtype=full.dtype)
             dist.all_gather_into_tensor(host, pad.cpu(), group=self.group)
@@ -233,7 +270,11 @@ class RouterPartition:
         else:
             dist.all_gather_into_tensor(full, pad, group=self.group)
         full = full.view(self.world, lead, nmax, C)
-        return torch.cat([full[j, :, :b - a] for j, (a, b) in enumerate(self.LB)], dim=1).contiguous()
+        if out is None:
+            out = torch.empty(lead, self.per_frame, C, dtype=yb.dtype, device=yb.device)
+        for j, (a, b) in enumerate(self.LB):
+            out[:, a:b] = full[j, :, :b - a]
+        return out
 
 
 def shard_sequence(model, group=None):
