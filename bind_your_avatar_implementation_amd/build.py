@@ -11,7 +11,13 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libbya_hip.so")
-SOURCES = ["gemm.hip", "gemm_w4.hip", "gemm_v3.hip", "gemm_v4.hip", "attn.hip", "norm.hip", "misc.hip", "router.hip", "rowgemm.hip"]
+SOURCES = ["gemm.hip", "gemm_w4.hip", "gemm_v3.hip", "gemm_v4.hip", "attn.hip", "norm.hip", "misc.hip", "router.hip", "rowgemm.hip", "comm.hip"]
+# VALU-only kernels are built WITHOUT the SLP vectoriser, i.e. without packed-fp32 (v_pk_mul/fma/mov_f32) instructions:
+# with them the q/k-norm + RoPE kernel returned wrong values in lanes 48..63 of some waves whenever ANOTHER PROCESS kept
+# MFMA-heavy workgroups resident on the same CUs (19-20 of 20 runs; 0 of 20 for the same source built with
+# -fno-slp-vectorize; tools/timeslice/repro.py, profiles/r2_timeslice_repro_run*.json).  These
+# kernels are HBM-bound, the packed forms bought nothing.
+NO_SLP_SOURCES = {"norm.hip", "misc.hip", "router.hip"}
 # translation units whose kernels keep their accumulators in AGPRs (one wave per SIMD, 512 registers)
 AGPR_SOURCES = {"gemm_w4.hip", "gemm_v3.hip", "gemm_v4.hip"}
 
@@ -27,7 +33,8 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG_DIR, "..", "include", "bya.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG_DIR, "..", "include", "bya.h"),
+                                                               os.path.abspath(__file__)]       # (compile flags live here)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -44,6 +51,8 @@ def build_hip_library(force=False, verbose=True):
         # -amdgpu-mfma-vgpr-form: MFMA results stay in arch VGPRs (gfx950's register file is unified), which removes
         # the v_accvgpr_read/write traffic hipcc otherwise inserts wherever VALU code touches an accumulator.
         form = [] if src in AGPR_SOURCES else ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+        if src in NO_SLP_SOURCES:
+            form = form + ["-fno-slp-vectorize"]
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *form, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -54,7 +63,7 @@ def build_hip_library(force=False, verbose=True):
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

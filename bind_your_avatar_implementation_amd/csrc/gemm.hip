@@ -372,7 +372,8 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
     a.n_split = d->n_split; a.c_split_stride = d->c_split_stride;
     a.bias_rowscale = d->bias_rowscale; a.alpha = d->alpha == 0.0f ? 1.0f : d->alpha;
     if (d->n_split < 0 || (d->n_split > 0 && (d->n_split % 4 || d->c_split_stride % 4 || res))) return BYA_ERR_SHAPE;
-    static const int forced = [] { const char* e = getenv("BYA_GEMM_TILE"); return e ? atoi(e) : -1; }();
+    const char* tile_env = getenv("BYA_GEMM_TILE");            // tuning / test switch, read per call
+    const int forced = tile_env ? atoi(tile_env) : -1;
     switch (pick_tile(d->M, d->N, d->K, d->batch, forced, d->act)) {
         case 0: return launch<128, 64, 2, 2>(a, d->batch, stream);
         case 1: return launch<128, 128, 2, 2>(a, d->batch, stream);

@@ -237,6 +237,23 @@ int bya_cfg_scheduler_step(const void* pred, int32_t n_pred, int64_t pred_stride
 int bya_masks_to_routing_logits(const void* masks, void* logits, int32_t n_id, int32_t in_frames, int32_t in_h,
                                 int32_t in_w, int32_t frames, int32_t h, int32_t w, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU exchanges of the sharded step over RCCL.  ``comm`` is the caller's ncclComm_t (one
+ * process per GPU); both calls only ENQUEUE on ``stream`` -- give them a stream of their own to overlap with compute.
+ * The reference has no inference parallelism; these have no counterpart there.  (The Python module of this package
+ * issues the same exchanges through torch.distributed's nccl backend = RCCL, because torch does not expose its
+ * communicator.)  BYA_ERR_UNSUPPORTED: no RCCL in the process.
+ * --------------------------------------------------------------------------------------------- */
+/* Exchange A, K/V form: k_local / v_local [rows_local, row_elems] bf16 of this rank -> k_full / v_full
+ * [world * rows_local, row_elems] on every rank (rank-major = global row order), one grouped call. */
+int bya_allgather_kv(const void* k_local, const void* v_local, void* k_full, void* v_full, int64_t rows_local,
+                     int64_t row_elems, void* comm, hipStream_t stream);
+/* Exchange A head-parallel form and exchange B (router repartition frame-major <-> location-major): uneven all-to-all
+ * of bf16 elements.  send_counts[p] elements go to rank p from send + sum(send_counts[:p]); recv_counts[p] elements
+ * arrive from rank p at recv + sum(recv_counts[:p]).  Grouped point-to-point: every element crosses one xGMI link once. */
+int bya_alltoall_router(const void* send, void* recv, const int64_t* send_counts, const int64_t* recv_counts,
+                        int32_t world, void* comm, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

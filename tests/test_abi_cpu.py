@@ -46,6 +46,19 @@ def test_python_binding_table_matches_header(lib_path):
     assert lib.bya_gemm_bf16(None, None, None, None, None, None, None, ctypes.byref(d), None) == -1
     a = _hip.AttnDesc()
     assert lib.bya_attn_fwd(None, None, None, None, ctypes.byref(a), None) == -1
+    # the softmax-variant query mirrors bya_attn_fwd's kernel choice (host-side, launches nothing)
+    a.head_dim, a.scores_prescaled, a.score_bound = 64, 1, 11.8
+    assert lib.bya_attn_variant(ctypes.byref(a)) == 2
+    a.score_bound = 60.0
+    assert lib.bya_attn_variant(ctypes.byref(a)) == 1
+    a.scores_prescaled = 0
+    assert lib.bya_attn_variant(ctypes.byref(a)) == 0
+    a.head_dim = 128
+    assert lib.bya_attn_variant(ctypes.byref(a)) == 3
+    # the RCCL entry points validate their arguments before touching a communicator
+    assert lib.bya_allgather_kv(None, None, None, None, 1, 1, None, None) == -1
+    cnt = (ctypes.c_int64 * 2)(1, 1)
+    assert lib.bya_alltoall_router(None, None, cnt, cnt, 2, None, None) == -1
 
 
 def test_struct_layout_matches_header():

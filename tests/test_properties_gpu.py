@@ -1,6 +1,8 @@
-"""Size-independent properties at the FULL BASELINE sizes (49x480x720: 17550 video tokens, 17776 joint rows), where an
-fp32 oracle run would take minutes: round trips, idempotence, linearity, convexity, permutation equivariance.  They
-complement the oracle / golden comparisons of test_kernels_gpu.py and test_forward_gpu.py (small sizes, exact values)."""
+"""Size-independent properties at the FULL BASELINE sizes, where an fp32 oracle run would take minutes: round trips,
+idempotence, linearity, convexity, permutation equivariance.  Every test runs at both full geometries of BASELINE.json:
+49x480x720 (configs[1]: 13x30x45 = 17550 video tokens, 17776 joint rows) and 49x720x1280 (configs[3]: 13x45x80 = 46800
+video tokens, 47026 joint rows -- an ODD row count with ragged 256-row tiles everywhere).  They complement the oracle /
+golden comparisons of test_kernels_gpu.py and test_forward_gpu.py (small sizes, exact values)."""
 import pytest
 import torch
 
@@ -8,7 +10,17 @@ from conftest import rel_fro
 
 pytestmark = pytest.mark.gpu
 
-T, HT, WT, N, TT, D = 13, 30, 45, 17550, 226, 3072
+TT, D = 226, 3072
+
+
+class Geom:
+    def __init__(self, T, HT, WT):
+        self.T, self.HT, self.WT, self.N = T, HT, WT, T * HT * WT
+
+
+@pytest.fixture(scope="module", params=["49x480x720", "49x720x1280"])
+def G(request):
+    return {"49x480x720": Geom(13, 30, 45), "49x720x1280": Geom(13, 45, 80)}[request.param]
 
 
 def rnd(shape, dev, seed, std=1.0):
@@ -22,8 +34,9 @@ def ops():
     return ops
 
 
-def test_patchify_is_a_bijection_on_the_conditioned_latents(ops, dev):
-    """unpatchify(patchify(x)) == x bit for bit for [1, 13, 48, 60, 90] (both are pure index maps with the same 2x2
+def test_patchify_is_a_bijection_on_the_conditioned_latents(ops, dev, G):
+    T, HT, WT, N = G.T, G.HT, G.WT, G.N
+    """unpatchify(patchify(x)) == x bit for bit for [1, 13, 48, 2 HT, 2 WT] (both are pure index maps with the same 2x2
     patch order); and every input element appears exactly once in the patch matrix."""
     x = rnd((1, T, 48, 2 * HT, 2 * WT), dev, 1)
     cols = torch.empty(1, N, 48 * 4, dtype=torch.bfloat16, device=dev)
@@ -34,7 +47,8 @@ def test_patchify_is_a_bijection_on_the_conditioned_latents(ops, dev):
     assert torch.equal(cols.flatten().sort().values, x.flatten().sort().values)
 
 
-def test_forcing_max_is_idempotent_and_monotone(ops, dev):
+def test_forcing_max_is_idempotent_and_monotone(ops, dev, G):
+    T, HT, WT, N = G.T, G.HT, G.WT, G.N
     """max over frames broadcast back over frames: applying it twice changes nothing; the result dominates the input and
     stays inside {0, 1} for hard masks."""
     g = torch.Generator().manual_seed(2)
@@ -46,7 +60,8 @@ def test_forcing_max_is_idempotent_and_monotone(ops, dev):
     assert torch.equal(a[0], a[-1])
 
 
-def test_masked_combine_hard_masks_select_rows(ops, dev):
+def test_masked_combine_hard_masks_select_rows(ops, dev, G):
+    T, HT, WT, N = G.T, G.HT, G.WT, G.N
     """With 0/1 routing weights the face combine is a row selection: tokens routed to nobody keep x bit for bit, tokens
     routed to identity i receive exactly bf16(x + feat_i)."""
     x0 = rnd((1, TT + N, D), dev, 3)
@@ -66,7 +81,8 @@ def test_masked_combine_hard_masks_select_rows(ops, dev):
         assert torch.equal(xv[lab == i], want)
 
 
-def test_audio_combine_swaps_speakers_with_af_matrix(ops, dev):
+def test_audio_combine_swaps_speakers_with_af_matrix(ops, dev, G):
+    T, HT, WT, N = G.T, G.HT, G.WT, G.N
     """G2: w = 1 - (af @ r^T)^T[:, [1, 0]].  Swapping the audio-face assignment (eye <-> 1 - eye) together with the two
     audio feature maps must give the same hidden states: the [1, 0] column swap is what makes that true."""
     x0 = rnd((1, N, D), dev, 6)
@@ -79,7 +95,8 @@ def test_audio_combine_swaps_speakers_with_af_matrix(ops, dev):
     assert torch.equal(a, b)                                              # relabelling the identities changes nothing
 
 
-def test_joint_attention_rows_are_convex_combinations(ops, dev):
+def test_joint_attention_rows_are_convex_combinations(ops, dev, G):
+    T, HT, WT, N = G.T, G.HT, G.WT, G.N
     """Every attention output lies inside the per-dimension [min, max] of V over the keys (softmax weights are a convex
     combination), a constant V comes back unchanged, and permuting the keys (with their values) permutes nothing."""
     H, Dh, S = 48, 64, TT + N
@@ -105,8 +122,9 @@ def test_joint_attention_rows_are_convex_combinations(ops, dev):
     assert float((out.float() - 0.75).abs().max()) < 4e-3
 
 
-def test_gemm_is_linear_in_the_activations_at_full_size(ops, dev):
-    """(a1 + a2) @ W^T == a1 @ W^T + a2 @ W^T up to bf16 rounding on the 17776 x 3072 x 3072 attention-output shape, and
+def test_gemm_is_linear_in_the_activations_at_full_size(ops, dev, G):
+    T, HT, WT, N = G.T, G.HT, G.WT, G.N
+    """(a1 + a2) @ W^T == a1 @ W^T + a2 @ W^T up to bf16 rounding on the (226 + N) x 3072 x 3072 attention-output shape, and
     a zero input returns exactly the bias."""
     a1, a2 = rnd((TT + N, D), dev, 11), rnd((TT + N, D), dev, 12)
     w, b = rnd((D, D), dev, 13, D ** -0.5), rnd((D,), dev, 14)
@@ -120,9 +138,10 @@ def test_gemm_is_linear_in_the_activations_at_full_size(ops, dev):
     assert torch.equal(z, b[None].expand_as(z))
 
 
-def test_router_rowgemm_is_invariant_to_row_shift_under_layernorm(ops, dev):
+def test_router_rowgemm_is_invariant_to_row_shift_under_layernorm(ops, dev, G):
+    T, HT, WT, N = G.T, G.HT, G.WT, G.N
     """LayerNorm removes a per-row offset: rowgemm512 with folded LayerNorm must return (almost) the same q|k|v for x
-    and x + c_row -- exercises the matrix-core row statistics at the full 35100-row router size."""
+    and x + c_row -- exercises the matrix-core row statistics at the full 2 N-row router size."""
     M = 2 * N
     x = rnd((M, 512), dev, 15)
     shift = torch.randn(M, 1, generator=torch.Generator().manual_seed(16)).to(dev) * 2

@@ -31,6 +31,10 @@ SHAPES = {            # name: (M, N, K, epilogue kwargs of the engine's call sit
     "audio_q": (17550, 3072, 3072, dict()),
     "perc_q": (17550, 2048, 3072, dict(nobias=True)),
     "sq8192": (8192, 8192, 8192, dict()),
+    # the Embedding Router's 512-wide Linears (35100 rows = 2 ids x 17550 tokens): today's row-stationary kernel
+    # (bya_rowgemm512) against the persistent tile kernel forced onto the same shape (BYA_GEMM_TILE=4)
+    "router_qkv": (35100, 1536, 512, dict(router=True)),
+    "router_out": (35100, 512, 512, dict(router=True, res=True)),
 }
 
 
@@ -129,7 +133,23 @@ def main():
             M, N, K, a, w, bias, out, kw = make_case(name, data == "zeros")
             fl = 2.0 * M * N * K / 1e12
             arms = {"vendor_plain": lambda: F.linear(a, w, bias)}
-            for v in variants:
+            if SHAPES[name][3].get("router"):
+                res_t = out if SHAPES[name][3].get("res") else None
+                pack = ops.pack_rowgemm512(w, bias)
+
+                def rowgemm():
+                    ops.rowgemm512(a, pack, out, res=res_t)
+
+                def tiled(variant="v4"):
+                    os.environ["BYA_GEMM_TILE"], os.environ["BYA_GEMM_VARIANT"] = "4", variant
+                    try:
+                        ops.gemm(a, w, out, bias=bias, res=res_t)
+                    finally:
+                        os.environ.pop("BYA_GEMM_TILE", None)
+                arms["bya_rowgemm512"] = rowgemm
+                arms["bya_v4_forced_big_tiles"] = tiled
+                kw = None
+            for v in (variants if kw is not None else []):
                 def run(v=v, kw=kw):
                     os.environ["BYA_GEMM_VARIANT"] = v
                     ops.gemm(a, w, out, bias=bias, **kw)

@@ -27,10 +27,18 @@ sys.path.insert(0, ROOT)
 LIB = os.path.join(HERE, "liblds_hog.so")
 
 
+NOSLP = os.path.join(HERE, "libnorm_noslp.so")
+
+
 def build():
     src = os.path.join(HERE, "lds_hog.hip")
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", src, "-o", LIB])
+    # the product's norm.hip once more, compiled WITHOUT the SLP vectoriser: no v_pk_* (packed fp32) instructions at all
+    nsrc = os.path.join(ROOT, "bind_your_avatar_implementation_amd", "csrc", "norm.hip")
+    if not os.path.exists(NOSLP) or os.path.getmtime(NOSLP) < os.path.getmtime(nsrc):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+                               "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1", nsrc, "-o", NOSLP])
     return LIB
 
 
@@ -49,7 +57,7 @@ def load_hog():
 # shows the sentinel proves that bytes crossed from the other process.
 DISTURBERS = ["none", "hog64", "hog96", "hog128", "hog132", "hog136", "hog144", "hog160", "rowgemm_n512_132k",
               "rowgemm_n1536_140k", "gemm256_128k", "attn_32k", "torch_matmul", "rowgemm_sentinel"]
-VICTIMS = ["rmw_inplace", "rmw_out", "qknorm_rope_inplace", "qknorm_rope_dbg1_inplace", "qknorm_rope_dbg2_inplace",
+VICTIMS = ["rmw_inplace", "rmw_out", "qknorm_rope_inplace", "qknorm_rope_noslp_inplace", "qknorm_rope_dbg1_inplace", "qknorm_rope_dbg2_inplace",
            "qknorm_rope_sc1_inplace", "bcast_table", "bcast_table_sc1",
            "qknorm_norope_inplace", "layernorm_out", "layernorm_inplace", "torch_mul_inplace",
            "torch_layernorm_out"]
@@ -130,6 +138,9 @@ def main():
     from bind_your_avatar_implementation_amd import ops
     dev = torch.device("cuda:0")
     hog = load_hog()
+    noslp = ctypes.CDLL(NOSLP)
+    _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    noslp.bya_qknorm_rope.argtypes = [_vp] * 8 + [_i32, _i32, _i32, _i64, _i64, _i32, _f32, _f32, _vp]
     stream = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device=dev).manual_seed(1)
     S, D = 17776, 3072
@@ -161,6 +172,14 @@ def main():
             wq.copy_(pris_q)
             wk.copy_(pris_k)
             ops.qknorm_rope(wq, wk, w64, b64, w64, b64, cos, sin, heads=48, text_rows=226, k_scale=0.18)
+            return (wq, wk)
+        if name == "qknorm_rope_noslp_inplace":          # same source, built without packed-fp32 (v_pk_*) instructions
+            wq.copy_(pris_q)
+            wk.copy_(pris_k)
+            rc = noslp.bya_qknorm_rope(wq.data_ptr(), wk.data_ptr(), w64.data_ptr(), b64.data_ptr(), w64.data_ptr(),
+                                       b64.data_ptr(), cos.data_ptr(), sin.data_ptr(), 1, S, 48, D, 0, 226,
+                                       ctypes.c_float(1e-6), ctypes.c_float(0.18), stream)
+            assert rc == 0, rc
             return (wq, wk)
         if name in ("qknorm_rope_dbg1_inplace", "qknorm_rope_dbg2_inplace"):
             # experiment builds of the kernel: 1 = table loads drained before anything else runs, 2 = 32-bit index maths
