@@ -73,6 +73,31 @@ struct CombArgs {
     float alpha;
 };
 
+// Routing weights of one token.  mode 0 (face): w[id] = r[id].  mode 1 (audio): av = af @ r (bf16 bmm output), then for
+// two streams the reference's  w = 1 - av[[1, 0]]  (models/transformer.py:895-900); for more streams -- the reference
+// hard-codes two -- the build-defined generalisation  w[a] = prod_{b != a} (1 - av[b])  evaluated as a chain of bf16 tensor
+// ops like oracle/model.py::audio_weights ("not any other speaker's region"; identical bits for two streams).
+__device__ __forceinline__ void routing_weights(const CombArgs& p, const bf16_t* r, int b, float (&w)[4]) {
+    if (p.mode == 0) {
+        for (int i = 0; i < p.n_id; ++i) w[i] = bf2f(r[i]);
+        return;
+    }
+    const bf16_t* af = p.af + b * p.n_id * p.n_id;
+    float rv[4], om[4];
+    for (int i = 0; i < p.n_id; ++i) rv[i] = bf2f(r[i]);
+    for (int a = 0; a < p.n_id; ++a) {
+        float av = 0.f;
+        for (int i = 0; i < p.n_id; ++i) av = fmaf(bf2f(af[a * p.n_id + i]), rv[i], av);
+        om[a] = bf2f(f2bf(1.0f - bf2f(f2bf(av))));
+    }
+    for (int a = 0; a < p.n_id; ++a) {
+        float t = 1.0f;
+        for (int bb = 0; bb < p.n_id; ++bb)
+            if (bb != a) t = bf2f(f2bf(t * om[bb]));
+        w[a] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void masked_combine_kernel(CombArgs p) {
     const int vec_per_row = p.D / 8;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -84,16 +109,7 @@ __global__ __launch_bounds__(256) void masked_combine_kernel(CombArgs p) {
     const int b = (int)(bn / p.N);
     const bf16_t* r = p.r + b * p.r_bs + n * p.n_id;
     float w[4];
-    if (p.mode == 0) {
-        for (int i = 0; i < p.n_id; ++i) w[i] = bf2f(r[i]);
-    } else {  // n_id == 2: w[id] = 1 - (af @ r)[1 - id], every intermediate a bf16 tensor in the reference
-        const bf16_t* af = p.af + b * 4;
-        const float r0 = bf2f(r[0]), r1 = bf2f(r[1]);
-        const float av0 = bf2f(f2bf(bf2f(af[0]) * r0 + bf2f(af[1]) * r1));
-        const float av1 = bf2f(f2bf(bf2f(af[2]) * r0 + bf2f(af[3]) * r1));
-        w[0] = bf2f(f2bf(1.0f - av1));
-        w[1] = bf2f(f2bf(1.0f - av0));
-    }
+    routing_weights(p, r, b, w);
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -132,16 +148,7 @@ __global__ __launch_bounds__(256) void routed_mix_kernel(CombArgs p, bf16_t* __r
     const int b = (int)(bn / p.N);
     const bf16_t* r = p.r + b * p.r_bs + n * p.n_id;
     float w[4];
-    if (p.mode == 0) {
-        for (int i = 0; i < p.n_id; ++i) w[i] = bf2f(r[i]);
-    } else {
-        const bf16_t* af = p.af + b * 4;
-        const float r0 = bf2f(r[0]), r1 = bf2f(r[1]);
-        const float av0 = bf2f(f2bf(bf2f(af[0]) * r0 + bf2f(af[1]) * r1));
-        const float av1 = bf2f(f2bf(bf2f(af[2]) * r0 + bf2f(af[3]) * r1));
-        w[0] = bf2f(f2bf(1.0f - av1));
-        w[1] = bf2f(f2bf(1.0f - av0));
-    }
+    routing_weights(p, r, b, w);
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -366,7 +373,7 @@ extern "C" int bya_masked_combine(void* x, const void* feat, const void* r, cons
                                   int64_t x_batch_stride, int64_t r_batch_stride, hipStream_t stream) {
     if (!x || !feat || !r || batch <= 0 || N <= 0 || D <= 0) return BYA_ERR_SHAPE;
     if (mode != 0 && mode != 1) return BYA_ERR_UNSUPPORTED;
-    if (n_id < 1 || n_id > 4 || (mode == 1 && (n_id != 2 || !af))) return BYA_ERR_UNSUPPORTED;
+    if (n_id < 1 || n_id > 4 || (mode == 1 && !af)) return BYA_ERR_UNSUPPORTED;
     if (D % 8 || x_row % 8 || x_batch_stride % 8) return BYA_ERR_ALIGN;
     if (((uintptr_t)x | (uintptr_t)feat) & 15) return BYA_ERR_ALIGN;
     CombArgs a;
@@ -383,7 +390,7 @@ extern "C" int bya_routed_mix(const void* feat, const void* r, const void* af, v
                               hipStream_t stream) {
     if (!feat || !r || !z || batch <= 0 || N <= 0 || D <= 0) return BYA_ERR_SHAPE;
     if (mode != 0 && mode != 1) return BYA_ERR_UNSUPPORTED;
-    if (n_id < 1 || n_id > 4 || (mode == 1 && (n_id != 2 || !af))) return BYA_ERR_UNSUPPORTED;
+    if (n_id < 1 || n_id > 4 || (mode == 1 && !af)) return BYA_ERR_UNSUPPORTED;
     if (D % 8) return BYA_ERR_ALIGN;
     if (((uintptr_t)z | (uintptr_t)feat) & 15) return BYA_ERR_ALIGN;
     CombArgs a;

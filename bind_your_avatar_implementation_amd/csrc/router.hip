@@ -186,18 +186,28 @@ __global__ __launch_bounds__(256) void attn_tiny8_kernel(const bf16_t* __restric
     const long long gseq = wid / hgroups;
     const long long row0 = (gseq / n_inner) * outer_stride + (gseq % n_inner);
     const int col = hgrp * 512 + lane * 8;
-    uint32_t kq[L][4], vq[L][4], qq[L][4];      // plain scalars: bit_cast of an ext_vector element miscompiles
+    constexpr bool Q_IN_REGS = L <= 16;         // L = 25 (97-frame clips): K and V alone are 200 registers
+    uint32_t kq[L][4], vq[L][4], qq[Q_IN_REGS ? L : 1][4];      // plain scalars: bit_cast of an ext_vector element miscompiles
 #pragma unroll
     for (int e = 0; e < L; ++e) {
         const long long off = (row0 + e * seq_stride) * ld_qkv + col;
-        const u32x4 a = *reinterpret_cast<const u32x4*>(q + off);
         const u32x4 b = *reinterpret_cast<const u32x4*>(k + off);
         const u32x4 c = *reinterpret_cast<const u32x4*>(v + off);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { qq[e][w] = a[w]; kq[e][w] = b[w]; vq[e][w] = c[w]; }
+        for (int w = 0; w < 4; ++w) { kq[e][w] = b[w]; vq[e][w] = c[w]; }
+        if (Q_IN_REGS) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(q + off);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) qq[e][w] = a[w];
+        }
     }
 #pragma unroll
     for (int i = 0; i < L; ++i) {
+        if (!Q_IN_REGS) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(q + (row0 + i * seq_stride) * ld_qkv + col);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) qq[0][w] = a[w];
+        }
         float s[L];
         float mx = -INFINITY;
 #pragma unroll
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_tiny8_kernel(const bf16_t* __restric
 #pragma unroll
             for (int w = 0; w < 4; ++w)
             {
-                const uint32_t qa = qq[i][w], kb = kq[j][w];
+                const uint32_t qa = qq[Q_IN_REGS ? i : 0][w], kb = kq[j][w];
                 d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, qa), __builtin_bit_cast(bf16x2, kb), d,
                                                     false);
             }
@@ -264,35 +274,29 @@ extern "C" int bya_router_head(const void* x, const void* w, const void* b, void
 extern "C" int bya_attn_tiny(const void* q, const void* k, const void* v, void* o, int32_t L, int32_t heads,
                              int64_t n_outer, int64_t n_inner, int64_t outer_stride, int64_t seq_stride,
                              int64_t ld_qkv, int64_t ld_o, float scale, hipStream_t stream) {
-    if (!q || !k || !v || !o || L <= 0 || L > 16 || heads <= 0 || n_outer <= 0 || n_inner <= 0) return BYA_ERR_SHAPE;
-    if (heads % 8 == 0 && (L == 2 || L == 13) && ld_qkv % 8 == 0 && ld_o % 8 == 0 &&
+    if (!q || !k || !v || !o || L <= 0 || L > 32 || heads <= 0 || n_outer <= 0 || n_inner <= 0) return BYA_ERR_SHAPE;
+#define TINY_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o
+#define TINY_TAIL (long long)n_outer, (long long)n_inner, (long long)outer_stride, (long long)seq_stride, \
+                  (long long)ld_qkv, (long long)ld_o, scale
+    // fast path: the sequence lengths of the router (frames per clip: 13 at 49 frames, 25 at 97; identities: 2, 3)
+    if (heads % 8 == 0 && (L == 2 || L == 3 || L == 13 || L == 25) && ld_qkv % 8 == 0 && ld_o % 8 == 0 &&
         !(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)) {
         const int hgroups = heads / 8;
         const long long w8 = (long long)n_outer * n_inner * hgroups;
         dim3 g8((unsigned)((w8 + 3) / 4));
-        if (L == 2)
-            BYA_LAUNCH((attn_tiny8_kernel<2>), g8, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (bf16_t*)o, hgroups, (long long)n_outer, (long long)n_inner,
-                       (long long)outer_stride, (long long)seq_stride, (long long)ld_qkv, (long long)ld_o, scale);
-        else
-            BYA_LAUNCH((attn_tiny8_kernel<13>), g8, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (bf16_t*)o, hgroups, (long long)n_outer, (long long)n_inner,
-                       (long long)outer_stride, (long long)seq_stride, (long long)ld_qkv, (long long)ld_o, scale);
+        if (L == 2) BYA_LAUNCH((attn_tiny8_kernel<2>), g8, dim3(256), 0, stream, TINY_ARGS, hgroups, TINY_TAIL);
+        else if (L == 3) BYA_LAUNCH((attn_tiny8_kernel<3>), g8, dim3(256), 0, stream, TINY_ARGS, hgroups, TINY_TAIL);
+        else if (L == 13) BYA_LAUNCH((attn_tiny8_kernel<13>), g8, dim3(256), 0, stream, TINY_ARGS, hgroups, TINY_TAIL);
+        else BYA_LAUNCH((attn_tiny8_kernel<25>), g8, dim3(256), 0, stream, TINY_ARGS, hgroups, TINY_TAIL);
         return ok();
     }
     const long long waves = (long long)n_outer * n_inner * heads;
     dim3 grid((unsigned)((waves + 3) / 4));
-    if (L <= 2)
-        BYA_LAUNCH((attn_tiny_kernel<2>), grid, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                           (const bf16_t*)v, (bf16_t*)o, L, heads, (long long)n_outer, (long long)n_inner,
-                           (long long)outer_stride, (long long)seq_stride, (long long)ld_qkv, (long long)ld_o, scale);
-    else if (L <= 4)
-        BYA_LAUNCH((attn_tiny_kernel<4>), grid, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                           (const bf16_t*)v, (bf16_t*)o, L, heads, (long long)n_outer, (long long)n_inner,
-                           (long long)outer_stride, (long long)seq_stride, (long long)ld_qkv, (long long)ld_o, scale);
-    else
-        BYA_LAUNCH((attn_tiny_kernel<16>), grid, dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)k,
-                           (const bf16_t*)v, (bf16_t*)o, L, heads, (long long)n_outer, (long long)n_inner,
-                           (long long)outer_stride, (long long)seq_stride, (long long)ld_qkv, (long long)ld_o, scale);
+    if (L <= 2) BYA_LAUNCH((attn_tiny_kernel<2>), grid, dim3(256), 0, stream, TINY_ARGS, L, heads, TINY_TAIL);
+    else if (L <= 4) BYA_LAUNCH((attn_tiny_kernel<4>), grid, dim3(256), 0, stream, TINY_ARGS, L, heads, TINY_TAIL);
+    else if (L <= 16) BYA_LAUNCH((attn_tiny_kernel<16>), grid, dim3(256), 0, stream, TINY_ARGS, L, heads, TINY_TAIL);
+    else BYA_LAUNCH((attn_tiny_kernel<32>), grid, dim3(256), 0, stream, TINY_ARGS, L, heads, TINY_TAIL);
+#undef TINY_ARGS
+#undef TINY_TAIL
     return ok();
 }

@@ -61,6 +61,15 @@ __device__ __forceinline__ void read_kstep(bf16x8 (&wf)[4], const uint32_t (&wa)
     }
 }
 
+// A lane constant the compiler may not hoist out of the chunk loop: hoisted address registers do not fit beside the 128
+// X-fragment registers, get spilled, and every scratch reload comes with an s_waitcnt vmcnt(0) -- in front of each LDS-DMA
+// instruction that serialised eight memory round trips per chunk.  Recomputing an address costs one or two VALU ops.
+__device__ __forceinline__ uint32_t lane_now() {      // the lane id, recomputed where it is used (volatile: never hoisted)
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // GELU(erf) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output step): one rcp,
 // one exp2 and six FMAs instead of libm's two-regime erff -- the MLP epilogue evaluates it 18 M times per launch.
 __device__ __forceinline__ float gelu_erf_f(float v) {
@@ -84,7 +93,6 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t = lane & 15, g = lane >> 4;
 
     const int nrb = (p.M + 32 * NW - 1) / (32 * NW), ncc = p.N / CH;
     const long long total = (long long)nrb * ncc;
@@ -112,59 +120,43 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
     // ---- W chunk staging (8 one-KiB rows per wave): LDS row R = j*16 + i holds output column
     // chunk0 + 16*(i>>2) + 4*j + (i&3), so that lane group g ends up with the 16 consecutive columns chunk0 + 16g ..;
     // its 64 16-byte pieces are XOR-swizzled with i: the 16 rows read by one fragment instruction hit 16 bank groups.
-    const uint32_t lane16 = (uint32_t)lane << 4;
     auto stage_chunk = [&](int q, int stg) {
         char* dst = ring + stg * STAGE_BYTES + wave * 8 * 1024;
         const int col0 = (q % ncc) * CH;
+        const uint32_t l16 = lane_now() << 4;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int R = wave * 8 + r, i = R & 15, j = R >> 4;        // wave-uniform
-            const uint32_t vo = (lane16 ^ (uint32_t)(i << 4)) + (uint32_t)(16 * (i >> 2) + 4 * j + (i & 3)) * (RK * 2);
+            const uint32_t vo = (l16 ^ (uint32_t)(i << 4)) + (uint32_t)(16 * (i >> 2) + 4 * j + (i & 3)) * (RK * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dst + r * 1024), 16, vo, col0 * (RK * 2), 0, 0);
         }
     };
 
     // lane-constant fragment read addresses: LDS row t of a column block, 16-byte piece (4*ks + g) ^ t
-    uint32_t wa0[4];
     const uint32_t ring_base = (uint32_t)(uintptr_t)LDS_PTR(ring);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-        wa0[m] = ring_base + t * 1024 + (((g ^ (t & 3)) | ((m ^ (t >> 2)) << 2)) << 4);
-    const uint32_t sc_base = (uint32_t)(uintptr_t)LDS_PTR(smem) + g * 64;      // 16 floats per lane group per chunk
+    const uint32_t smem_base = (uint32_t)(uintptr_t)LDS_PTR(smem);
 
+    // Outer loop: the row blocks this workgroup's range touches (two or three); inner loop: their chunks.  The X fragments
+    // are read-only inside the inner loop, which has no row-block branch -- with the branch inside, hipcc shuffled and
+    // spilled fragments around the MFMA section (every scratch reload drags an s_waitcnt vmcnt(0) with it).
     bf16x8 xf[2][16];
-    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
-    int cur_rb = -1;
     stage_chunk(q0, 0);
-    for (int q = q0; q < q1; ++q) {
-        const int rb = q / ncc, cc = q - rb * ncc, stg = (q - q0) & 1;
+    int q = q0, it = 0;
+    while (q < q1) {
+        const int rb = q / ncc;
+        const int qe = (rb + 1) * ncc < q1 ? (rb + 1) * ncc : q1;
         const int r0 = rb * (32 * NW) + wave * 32;
-        const bool new_rows = rb != cur_rb;
-        if (new_rows) {
+        float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
+        {
             // X fragments: rows r0 + h*16 + t, k = ks*32 + g*8 .. +8 (rows >= M read as zeros through the descriptor)
+            const uint32_t ln = lane_now(), to = ln & 15u, go = ln >> 4;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint32_t vo = (uint32_t)(r0 + h * 16 + t) * (uint32_t)(p.ldx * 2) + g * 16;
+                const uint32_t vo = ((uint32_t)(r0 + h * 16) + to) * (uint32_t)(p.ldx * 2) + go * 16;
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks)
                     xf[h][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, vo + ks * 64, 0, 0));
             }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk q has landed (issued one chunk period ago)
-        __builtin_amdgcn_s_barrier();                          // ... for every wave; stage stg^1 is free
-        u32x4 rv[2][2];
-        if (RES) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    rv[h][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        rsR, (uint32_t)(r0 + h * 16 + t) * (uint32_t)(p.ldres * 2) +
-                                 (uint32_t)(cc * CH + 16 * g + 8 * u) * 2, 0, 0));
-        }
-        if (q + 1 < q1) stage_chunk(q + 1, stg ^ 1);
-        if (new_rows) {
-            cur_rb = rb;
             if (LN) {
                 // row statistics on the matrix core: sum(x) = ones . x^T, sum(x^2) = diag(x . x^T)
                 bf16x8 ones;
@@ -179,9 +171,9 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
                         gr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[h][ks], xf[h][ks], gr, 0, 0, 0);
                     }
                     // lane (g, t) holds <x_{4g+e}, x_t>; the diagonal of token t sits in lane (t>>2, t), register t&3
-                    const int e = t & 3;
+                    const int e = to & 3;
                     const float d = e == 0 ? gr[0] : e == 1 ? gr[1] : e == 2 ? gr[2] : gr[3];
-                    const float sq = __shfl(d, t + 16 * (t >> 2));
+                    const float sq = __shfl(d, (int)(to + 16 * (to >> 2)));
                     const float mu = sm[0] * (1.0f / RK);
                     const float var = fmaxf(sq * (1.0f / RK) - mu * mu, 0.0f);
                     mean[h] = mu;
@@ -189,62 +181,94 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
                 }
             }
         }
-
-        // ---- 16 k-steps x (4 W fragments) x (2 row halves) = 128 MFMAs; fragment reads one k-step ahead
-        uint32_t wa[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) wa[m] = wa0[m] + stg * STAGE_BYTES;
-        f32x4 acc[2][4];
+        // the X fragments (and with them the first chunk's W, requested earlier) have landed.  Passing every fragment
+        // through an empty asm makes that visible to hipcc's wait-count bookkeeping: without it the chunk loop carried a
+        // descending ladder of s_waitcnt vmcnt(19 .. 3) for "X loads that may still be in flight", which made the NEXT
+        // chunk's LDS-DMA land in the middle of this chunk's MFMAs instead of by the next barrier.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 wf[2][4];
-        read_kstep(wf[0], wa, 0);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const int cur = ks & 1;
-            if (ks + 1 < 16) {
-                read_kstep(wf[cur ^ 1], wa, ks + 1);
-                lgkm_wait<4>(wf[cur]);
-            } else {
-                lgkm_wait<0>(wf[cur]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(xf[h][ks]));
+
+        for (; q < qe; ++q, ++it) {
+            const int cc = q - rb * ncc, stg = it & 1;
+            const uint32_t ln = lane_now(), to = ln & 15u, go = ln >> 4;           // for the addresses of this chunk
+            // chunk q has landed (requested one chunk period ago).  vmcnt counts stores too and retires in order: the only
+            // operations younger than chunk q's LDS-DMA are the previous chunk's four output stores, so a counted wait lets
+            // them drain under this chunk's MFMAs (vmcnt(0) here exposed one store round trip per chunk).
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // ... for every wave; stage stg^1 is free
+            u32x4 rv[2][2];
+            if (RES) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    acc[h][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][j], xf[h][ks], acc[h][j], 0, 0, 0);
-        }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        rv[h][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            rsR, ((uint32_t)(r0 + h * 16) + to) * (uint32_t)(p.ldres * 2) +
+                                     ((uint32_t)(cc * CH + 8 * u) + 16 * go) * 2, 0, 0));
+            }
+            if (q + 1 < q1) stage_chunk(q + 1, stg ^ 1);
 
-        // ---- epilogue: lane (g, t) holds token t's columns chunk0 + 16g + 4j + e
+            // ---- 16 k-steps x (4 W fragments) x (2 row halves) = 128 MFMAs; fragment reads one k-step ahead
+            uint32_t wa[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {                        // 8 columns at a time: j = 2u, 2u+1
-            f32x4 s0, s1, c0, c1;
-            const uint32_t a = sc_base + (uint32_t)(cc * CH + 8 * u) * 4, ac = a + (uint32_t)p.N * 4;
-            lds_read_f<0>(s0, a);
-            lds_read_f<16>(s1, a);
-            lds_read_f<0>(c0, ac);
-            lds_read_f<16>(c1, ac);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0), "+v"(s1), "+v"(c0), "+v"(c1));
+            for (int m = 0; m < 4; ++m)
+                wa[m] = ring_base + stg * STAGE_BYTES + to * 1024 + (((go ^ (to & 3)) | ((m ^ (to >> 2)) << 2)) << 4);
+            const uint32_t sc_base = smem_base + go * 64;                      // 16 floats per lane group per chunk
+            f32x4 acc[2][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float v[8];
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float a0 = acc[h][2 * u + (e >> 2)][e & 3];
-                    const float sv = (e >> 2) ? s1[e & 3] : s0[e & 3];
-                    const float cv = (e >> 2) ? c1[e & 3] : c0[e & 3];
-                    float o = LN ? rstd[h] * (a0 - mean[h] * sv) + cv : a0 + cv;
-                    if (ACT == BYA_ACT_GELU_ERF) o = gelu_erf_f(o);
-                    if (RES) o += (e & 1) ? bfhi(rv[h][u][e >> 1]) : bflo(rv[h][u][e >> 1]);
-                    v[e] = o;
+                for (int j = 0; j < 4; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 wf[2][4];
+            read_kstep(wf[0], wa, 0);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int cur = ks & 1;
+                if (ks + 1 < 16) {
+                    read_kstep(wf[cur ^ 1], wa, ks + 1);
+                    lgkm_wait<4>(wf[cur]);
+                } else {
+                    lgkm_wait<0>(wf[cur]);
                 }
-                u32x4 ov;
 #pragma unroll
-                for (int w2 = 0; w2 < 4; ++w2) ov[w2] = pack2bf(v[2 * w2], v[2 * w2 + 1]);
-                __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, (uint32_t)(r0 + h * 16 + t) * (uint32_t)(p.ldc * 2) +
-                                                                    (uint32_t)(cc * CH + 16 * g + 8 * u) * 2, 0, 0);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        acc[h][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][j], xf[h][ks], acc[h][j], 0, 0, 0);
+            }
+
+            // ---- epilogue: lane (g, t) holds token t's columns chunk0 + 16g + 4j + e
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {                        // 8 columns at a time: j = 2u, 2u+1
+                f32x4 s0, s1, c0, c1;
+                const uint32_t a = sc_base + (uint32_t)(cc * CH + 8 * u) * 4, ac = a + (uint32_t)p.N * 4;
+                lds_read_f<0>(s0, a);
+                lds_read_f<16>(s1, a);
+                lds_read_f<0>(c0, ac);
+                lds_read_f<16>(c1, ac);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0), "+v"(s1), "+v"(c0), "+v"(c1));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float a0 = acc[h][2 * u + (e >> 2)][e & 3];
+                        const float sv = (e >> 2) ? s1[e & 3] : s0[e & 3];
+                        const float cv = (e >> 2) ? c1[e & 3] : c0[e & 3];
+                        float o = LN ? fmaf(rstd[h], fmaf(-mean[h], sv, a0), cv) : a0 + cv;     // pinned contraction
+                        if (ACT == BYA_ACT_GELU_ERF) o = gelu_erf_f(o);
+                        if (RES) o += (e & 1) ? bfhi(rv[h][u][e >> 1]) : bflo(rv[h][u][e >> 1]);
+                        v[e] = o;
+                    }
+                    u32x4 ov;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) ov[w2] = pack2bf(v[2 * w2], v[2 * w2 + 1]);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, ((uint32_t)(r0 + h * 16) + to) * (uint32_t)(p.ldc * 2) +
+                                                                        ((uint32_t)(cc * CH + 8 * u) + 16 * go) * 2, 0, 0);
+                }
             }
         }
     }

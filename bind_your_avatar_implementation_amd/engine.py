@@ -31,7 +31,24 @@ def _key(tensors):
 
 
 class DenoiseEngine:
-    N_ID = 2          # the reference forward dereferences exactly id_cond[0], id_cond[1] (models/transformer.py:638-639)
+    # Identities / audio streams per sample.  The reference forward dereferences exactly id_cond[0], id_cond[1]
+    # (models/transformer.py:638-639) and repeats the video twice (:784, :881); everything else in it (router, perceiver,
+    # masked bmm) already runs over a leading identity axis.  Here the count follows the inputs (2..4, BASELINE
+    # configs[4] uses 3); the one place with no n-identity form in the reference, the audio weights' [1, 0] swap, is
+    # generalised as w[a] = prod_{b != a} (1 - av[b]) (include/bya.h, bya_masked_combine).
+    N_ID = 2
+    MAX_ID = 4
+
+    def _count_ids(self, id_cond, audio_embeds):
+        if self.m.is_train_face and id_cond is not None:
+            n = len(id_cond)
+        elif audio_embeds is not None and audio_embeds.ndim == 5:
+            n = audio_embeds.shape[1]
+        else:
+            n = 2
+        if not 2 <= n <= self.MAX_ID:
+            raise ValueError(f"{n} identities: the engine runs 2..{self.MAX_ID} (the reference itself exactly 2)")
+        return n
 
     def __init__(self, model):
         p = model.proj_out.weight
@@ -321,6 +338,7 @@ class DenoiseEngine:
         launches produce them).  ``release()`` drops the cache and returns to the reference's recompute-every-step."""
         self.cache_invariants = True
         self._inv_cache = {}
+        self.N_ID = self._count_ids(id_cond, audio_embeds)
         if self.m.is_train_face and id_cond is not None:
             B = id_cond[0].shape[0]
             flat = list(id_cond[:self.N_ID]) + [t for i in range(self.N_ID) for t in id_vit_hidden[i]]
@@ -344,6 +362,7 @@ class DenoiseEngine:
 
     def _step(self, hidden_states, encoder_hidden_states, timestep, image_rotary_emb, id_cond, id_vit_hidden,
               audio_embeds, af_matrix, routing_logits_forcing, taps=None):
+        self.N_ID = self._count_ids(id_cond, audio_embeds)
         m, cfg, D, H, n_id = self.m, self.cfg, self.D, self.H, self.N_ID
         B, T, C, Hh, Ww = hidden_states.shape
         ht, wt = Hh // 2, Ww // 2
@@ -354,7 +373,7 @@ class DenoiseEngine:
         if sh.world > 1 and B != 1:
             raise NotImplementedError("sequence-parallel execution shards ONE sample; split a CFG batch over rank groups")
         S_loc, Tt_loc, N_loc, v0, v1 = sh.S_loc, sh.Tt_loc, sh.N_loc, sh.v0, sh.v1
-        key = (B, T, C, Hh, Ww, Tt, sh.rank, sh.world)
+        key = (B, T, C, Hh, Ww, Tt, sh.rank, sh.world, n_id)
         if self._ws_key != key:
             self._ws_key, self._ws = key, {}
         buf = self._buf

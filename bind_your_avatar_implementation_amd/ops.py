@@ -47,9 +47,14 @@ _TIMERS = None
 _FLOPS = {}
 
 
-def enable_kernel_timers():
-    global _TIMERS, _FLOPS
-    _TIMERS, _FLOPS = {}, {}
+_SHAPE_LABELS = False
+
+
+def enable_kernel_timers(by_shape=False):
+    """``by_shape``: GEMM launches are keyed ``bya_gemm_bf16:BxMxNxK:epilogue`` instead of by entry point alone
+    (tools/gemm_breakdown.py)."""
+    global _TIMERS, _FLOPS, _SHAPE_LABELS
+    _TIMERS, _FLOPS, _SHAPE_LABELS = {}, {}, bool(by_shape)
     return _TIMERS
 
 
@@ -131,7 +136,10 @@ def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, g
     d.bias_rowscale, d.alpha = _p(bias_rowscale), float(alpha)
     if bias_rowscale is not None:
         assert bias_rowscale.dtype == torch.float32 and bias_rowscale.is_contiguous() and bias_rowscale.numel() == ab * M
-    tok = _begin("bya_gemm_bf16", 2.0 * ab * M * N * K)
+    name = "bya_gemm_bf16"
+    if _SHAPE_LABELS:
+        name += f":{ab}x{M}x{N}x{K}:{act or 'none'}{'+gate' if gate0 is not None else ''}{'+res' if res is not None else ''}"
+    tok = _begin(name, 2.0 * ab * M * N * K)
     check(lib.bya_gemm_bf16(_p(a), _p(w), _p(bias), _p(out), _p(res), _p(gate0), _p(gate1), ctypes.byref(d),
                             _stream()), "bya_gemm_bf16")
     _end(tok)

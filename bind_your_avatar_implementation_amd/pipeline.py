@@ -196,9 +196,10 @@ class BindyouravatarPipeline:
                  id_vit_hidden=None, id_cond=None, kps_cond=None, audio_embs=None, af_matrix=None,
                  zero2cond_cfg_flag: bool = False, routing_logits_zeros_flag: bool = False,
                  routing_logits_forcing=None, image_bg=None, image_latents=None, image_bg_latents=None):
-        if num_frames > 49:
-            raise ValueError("The number of frames must be less than 49 for now due to static positional embeddings. "
-                             "This will be updated in the future to remove this limitation.")       # reference :739-742
+        max_frames = int(getattr(self.transformer.config, "sample_frames", 49))
+        if num_frames > max_frames:     # reference :739-742 with its constant 49 = the stock config's sample_frames
+            raise ValueError(f"The number of frames must be less than {max_frames} for now due to static positional "
+                             "embeddings. This will be updated in the future to remove this limitation.")
         if prompt is not None or negative_prompt is not None or image is not None or image_bg is not None:
             raise NotImplementedError("T5 / VAE are outside the hot path: pass prompt_embeds, negative_prompt_embeds, "
                                       "image_latents (and image_bg_latents) as tensors")

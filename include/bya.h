@@ -168,6 +168,8 @@ int bya_forcing_max_over_frames(const void* forcing, void* out, int32_t frames, 
  *  mode 0 (face):  x[b,n,:] += alpha * sum_id r[b][n,id] * feat[b,id,n,:]
  *  mode 1 (audio): av[n,i] = bf16(sum_j af[b,i,j]*r[b][n,j]); w[n,id] = bf16(1 - av[n,1-id]);
  *                  x[b,n,:] += sum_id w[n,id] * feat[b,id,n,:]
+ *                  n_id in 3..4 (the reference hard-codes two streams; build-defined): af is [batch, n_id, n_id] and
+ *                  w[n,a] = prod_{b != a} bf16(1 - av[n,b]), every product rounded to bf16 (two streams: same bits)
  * r: [batch or 1, N, n_id] (r_batch_stride 0 = shared forcing mask); feat [batch, n_id, N, D]. In place.
  * --------------------------------------------------------------------------------------------- */
 int bya_masked_combine(void* x, const void* feat, const void* r, const void* af, int32_t mode, float alpha,

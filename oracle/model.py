@@ -316,6 +316,29 @@ def masked_combine(weights, feats):
     return (weights.transpose(1, 0) @ feats.transpose(1, 0)).transpose(1, 0)
 
 
+def audio_weights(av):
+    """Per-token weight of every audio stream's feature from ``av = af_matrix @ routing`` ([1, N, n]).
+
+    Two streams -- the reference (models/transformer.py:895-900): swap the last axis and complement,
+    ``w = 1 - av[:, :, [1, 0]]``: a stream is heard everywhere except where the OTHER speaker's face is.
+    More than two streams have no form in the reference (it hard-codes the pair).  BUILD-DEFINED generalisation, the
+    one that keeps that sentence true: ``w[a] = prod_{b != a} (1 - av[b])`` ("nowhere any other speaker's face is"),
+    evaluated as a chain of tensor ops in the activation dtype like the reference would write it; for two streams the
+    product has one factor and the bits are the reference's."""
+    n = av.shape[-1]
+    if n == 2:
+        return 1 - av[:, :, [1, 0]]
+    comp = 1 - av
+    cols = []
+    for a in range(n):
+        w = torch.ones_like(comp[..., 0])
+        for b in range(n):
+            if b != a:
+                w = w * comp[..., b]
+        cols.append(w)
+    return torch.stack(cols, dim=-1)
+
+
 class OracleTransformer(nn.Module):
     """Inference branch of ``BindyouravatarTransformer3DModel`` (models/transformer.py:265-964).
 
@@ -383,7 +406,9 @@ class OracleTransformer(nn.Module):
                 routing_logits_zeros_flag=False, routing_logits_forcing=None, taps=None):
         assert index_mask is None, "the oracle restates the inference branch only"
         taps = {} if taps is None else taps
-        n_id = 2
+        # the reference dereferences id_cond[0], id_cond[1] and repeats the video twice (models/transformer.py:638-639,
+        # 784, 881); every other op already carries an identity axis, so the count simply follows the inputs here
+        n_id = len(id_cond) if (self.is_train_face and id_cond is not None) else 2
         if self.is_train_face:
             assert id_cond is not None and id_vit_hidden is not None
             embs = [self.local_facial_extractor(id_cond[i], id_vit_hidden[i]) for i in range(n_id)]
@@ -439,7 +464,7 @@ class OracleTransformer(nn.Module):
                 for j in range(b):
                     sub = hid[j].repeat(n_id, 1, 1)
                     af = self.audio_model(ctx[j], sub, t, i // self.audio_attn_interval)
-                    wgt = 1 - av[j].unsqueeze(0)[:, :, [1, 0]]
+                    wgt = audio_weights(av[j].unsqueeze(0))
                     feats.append(masked_combine(wgt, af))
                 hid = hid + torch.cat(feats)
                 taps[f"audio{i}"] = hid

@@ -296,7 +296,7 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def bf16_oracle_pass(layers, seed, inp, step, **over):
+def bf16_oracle_pass(layers, seed, inp, step, router_tap=None, **over):
     """The restatement with bf16 parameters and activations (what the reference's own bf16 inference path computes,
     infer.py:477) on the same synthetic weights: its distance from the fp32 result is the tolerance bar."""
     with torch.device("meta"):
@@ -305,6 +305,8 @@ def bf16_oracle_pass(layers, seed, inp, step, **over):
     fill(orc, seed)
     orc.eval()
     taps = StridedTaps(step)
+    if router_tap is not None:
+        orc.router.register_forward_hook(lambda m, a, o: router_tap.append(o.detach().float().clone()))
     t0 = time.time()
     with torch.no_grad():
         out = orc(taps=taps, **to_bf16_inputs(inp))[0]
@@ -375,9 +377,14 @@ def run_bars(seed):
         if case == "cfg_forcing":
             inp["af_matrix"] = (1 - torch.eye(2))[None].repeat(batch, 1, 1)
             inp["routing_logits_forcing"] = torch.from_numpy(fx["forcing_u8"].astype(np.float32))
-        out16, _ = bf16_oracle_pass(2, seed, inp, 970)
+        rt = []
+        out16, _ = bf16_oracle_pass(2, seed, inp, 970, router_tap=rt)
         bars[case] = rel(out16, torch.from_numpy(fx["output_f16"].astype(np.float32)))
         print(f"{case}: bf16 oracle vs stored fp32 reference output = {bars[case]:.3e}", flush=True)
+        if case == "base":       # the first router call's sigmoid outputs: bf16 path vs the reference's fp32 values
+            d = (rt[0].reshape(-1) - torch.from_numpy(fx["router.0.call0"]).float().reshape(-1)).abs()
+            bars["base_router_logits_max_abs"], bars["base_router_logits_mean_abs"] = float(d.max()), float(d.mean())
+            print(f"{case}: router logits bf16 vs fp32: max-abs {d.max():.3e} mean {d.mean():.3e}", flush=True)
     with open(os.path.join(HERE, "bf16_bars.json"), "w") as f:
         json.dump(bars, f, indent=1)
 

@@ -180,6 +180,34 @@ def test_rowgemm512(ops, dev, M, N, ln, res, act, nsplit):
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.mark.parametrize("N,ln,res", [(1536, True, False), (512, False, True), (512, True, False)])
+def test_rowgemm512_repeatable_at_router_shape(ops, dev, N, ln, res):
+    """The W-chunk ring is synchronised with COUNTED waits (the previous chunk's output stores stay in flight across the
+    barrier): a wait that is one short would read a chunk before it has landed -- rare wrong tiles that depend on memory
+    load.  35100 rows x the router's widths, 25 launches on a busy GPU (a large GEMM queued on a second stream), every
+    result bit-identical to the first and to a launch on an idle GPU."""
+    M = 35100
+    x = rnd((M, 512), dev, 80)
+    w, b = rnd((N, 512), dev, 81, 512 ** -0.5), rnd((N,), dev, 82, 0.2)
+    gam, bet = rnd((512,), dev, 83, 0.3) + 1, rnd((512,), dev, 84, 0.2)
+    pack = ops.pack_rowgemm512(w, b, gam if ln else None, bet if ln else None)
+    r = rnd((M, N), dev, 85) if res else None
+    def run():
+        out = r.clone() if res else torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.rowgemm512(x, pack, out, res=out if res else None)
+        return out
+    first = run()
+    torch.cuda.synchronize()
+    a, bb = rnd((8192, 8192), dev, 86), rnd((8192, 8192), dev, 87)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            a @ bb
+    outs = [run() for _ in range(25)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(first, o) for o in outs)
+
+
 @pytest.mark.parametrize("variant", ["v4", "w8", "w4", "v3"])
 def test_gemm_big_tile_kernels_whole_suite(dev, variant):
     """Every GEMM parity test again with the 256x256 pipelined kernels FORCED for all shapes (BYA_GEMM_TILE=4: ragged M / N,

@@ -124,3 +124,26 @@ def test_mask_path_oracle_matches_reference_golden():
         assert got.shape == (1, 17550, 2)
         assert np.array_equal(got[0].numpy().astype(np.uint8), want)
         assert want.sum(1).max() == 1 and 1000 < want.sum() < 6000          # one-hot rows, both people present
+
+
+def test_audio_weights_two_streams_is_the_reference_swap_and_three_streams_generalise():
+    """oracle/model.py::audio_weights: for two streams the reference's ``1 - av[:, :, [1, 0]]`` bit for bit (fp32 and
+    bf16); for three the build-defined product form -- with one-hot face masks and a permutation audio-to-face matrix a
+    stream is heard on its own face and on the background and nowhere on another face."""
+    from oracle.model import audio_weights
+    g = torch.Generator().manual_seed(0)
+    for dt in (torch.float32, torch.bfloat16):
+        av = torch.rand(1, 50, 2, generator=g).to(dt)
+        assert torch.equal(audio_weights(av), 1 - av[:, :, [1, 0]])
+    r = torch.zeros(1, 6, 3)
+    r[0, 0, 0] = r[0, 1, 1] = r[0, 2, 2] = 1                     # tokens 0..2: faces 0..2; tokens 3..5: background
+    af = torch.roll(torch.eye(3), 1, dims=1)[None]               # audio stream a speaks through face a + 1
+    av = (af @ r.transpose(-2, -1)).transpose(-2, -1)
+    w = audio_weights(av)
+    own = torch.tensor([1, 2, 0])
+    for a in range(3):
+        for tok in range(3):
+            assert w[0, tok, a] == (1.0 if tok == own[a] else 0.0)
+        assert (w[0, 3:, a] == 1).all()
+    soft = audio_weights(torch.full((1, 4, 3), 0.25))
+    assert torch.allclose(soft, torch.full((1, 4, 3), 0.75 ** 2))
