@@ -300,6 +300,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     dispatch_act_big(p.act, run);
 }
 
+// the persistent kernel's 16-byte epilogue accesses must be aligned and K must have at least three K-tiles
+inline bool v4_eligible(const GemmArgs& a) {
+    return a.K >= 3 * BK && a.N % 8 == 0 && a.n_split % 8 == 0 && a.ldc % 8 == 0 && (!a.res || a.ldres % 8 == 0) &&
+        !(((uintptr_t)a.C | (uintptr_t)a.res | (uintptr_t)a.bias | (uintptr_t)a.gate0 | (uintptr_t)a.gate1) & 15) &&
+        a.c_bs % 8 == 0 && a.res_bs % 8 == 0 && a.gate_bs % 8 == 0 && a.c_split_stride % 8 == 0;
+}
+
 int launch256(const GemmArgs& a, int batch, hipStream_t s) {
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
     dim3 grid(tiles_m * tiles_n, 1, batch);
@@ -311,9 +318,7 @@ int launch256(const GemmArgs& a, int batch, hipStream_t s) {
     // BYA_GEMM_VARIANT (read per call so one process can A/B them, tools/gemm_probe.py): "w8" = this file's 8-wave
     // kernel, "w4" = gemm_w4.hip, "v3" = gemm_v3.hip, "v4" = gemm_v4.hip.
     const char* variant = getenv("BYA_GEMM_VARIANT");
-    const bool v4_ok = a.K >= 3 * BK && a.N % 8 == 0 && a.n_split % 8 == 0 && a.ldc % 8 == 0 && (!a.res || a.ldres % 8 == 0) &&
-        !(((uintptr_t)a.C | (uintptr_t)a.res | (uintptr_t)a.bias | (uintptr_t)a.gate0 | (uintptr_t)a.gate1) & 15) &&
-        a.c_bs % 8 == 0 && a.res_bs % 8 == 0 && a.gate_bs % 8 == 0 && a.c_split_stride % 8 == 0;
+    const bool v4_ok = v4_eligible(a);
     if (variant && variant[0] == 'w' && variant[1] == '4') return bya_launch_gemm256w4(&a, batch, s);
     if (variant && variant[0] == 'v' && variant[1] == '3') return bya_launch_gemm256v3(&a, batch, s);
     if (v4_ok && !(variant && variant[0] == 'w' && variant[1] == '8')) return bya_launch_gemm256p(&a, batch, s);
@@ -334,7 +339,7 @@ int launch(const GemmArgs& a, int batch, hipStream_t s) {
 }
 
 // Tile choice: fewest "CU rounds" (wave quantisation on 256 CUs) weighted by the tile's relative efficiency.
-inline int pick_tile(int M, int N, int K, int batch, int forced, int act) {
+inline int pick_tile(int M, int N, int K, int batch, int forced, int act, bool splitk) {
     if (forced >= 0) return (forced >= 4 && !act_on_big_tiles(act)) ? 1 : forced;
     if (N <= 64) return 0;
     auto rounds = [&](int bm, int bn, int per_cu) {
@@ -344,7 +349,9 @@ inline int pick_tile(int M, int N, int K, int batch, int forced, int act) {
     };
     const double t128 = rounds(128, 128, 2) / 0.80;     // measured relative speeds of the three structures
     const double t256x128 = rounds(256, 128, 1) / 0.95;
-    const double t256 = rounds(256, 256, 1) / 1.00;
+    // with the split-K workspace the persistent kernel's last round costs its fill fraction (plus the slab exchange)
+    const double frac_rounds = (double)((M + 255) / 256) * ((N + 255) / 256) * batch / 256.0;
+    const double t256 = splitk ? (frac_rounds + 0.12) * 65536.0 : rounds(256, 256, 1) / 1.00;
     (void)t256x128;
     if (M < 1024 || N < 512 || K < 1024 || !act_on_big_tiles(act)) return 1;     // short K loops: the pipelined kernel's prologue/epilogue dominate
     // the pipelined 256x256 kernel is ~1.2x the 128x128 one per unit of tile area when its grid fills the CUs
@@ -352,6 +359,22 @@ inline int pick_tile(int M, int N, int K, int batch, int forced, int act) {
 }
 
 }  // namespace
+
+namespace {
+std::atomic<void*> g_gemm_ws{nullptr};          // split-K workspace of the persistent kernel (gemm_v4.hip), caller-owned
+}  // namespace
+
+extern "C" int bya_set_gemm_workspace(void* ws, int64_t bytes) {
+    if (ws && (bytes < (int64_t)GEMM_WS_BYTES || ((uintptr_t)ws & 255))) return BYA_ERR_SHAPE;
+    g_gemm_ws.store(ws);
+    return BYA_OK;
+}
+
+extern "C" int bya_gemm_workspace_bytes(int64_t* bytes) {
+    if (!bytes) return BYA_ERR_SHAPE;
+    *bytes = (int64_t)GEMM_WS_BYTES;
+    return BYA_OK;
+}
 
 extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, void* C, const void* res,
                              const void* gate0, const void* gate1, const bya_gemm_desc* d, hipStream_t stream) {
@@ -371,10 +394,17 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
     a.gate_bs = d->gate_batch_stride; a.gate_split = d->gate_split; a.act = d->act; a.leaky = 0.01f;
     a.n_split = d->n_split; a.c_split_stride = d->c_split_stride;
     a.bias_rowscale = d->bias_rowscale; a.alpha = d->alpha == 0.0f ? 1.0f : d->alpha;
+    char* const ws = static_cast<char*>(g_gemm_ws.load());
+    a.ws_counters = reinterpret_cast<unsigned*>(ws);
+    a.ws_slabs = ws ? reinterpret_cast<float*>(ws + GEMM_WS_COUNTER_BYTES) : nullptr;
     if (d->n_split < 0 || (d->n_split > 0 && (d->n_split % 4 || d->c_split_stride % 4 || res))) return BYA_ERR_SHAPE;
     const char* tile_env = getenv("BYA_GEMM_TILE");            // tuning / test switch, read per call
     const int forced = tile_env ? atoi(tile_env) : -1;
-    switch (pick_tile(d->M, d->N, d->K, d->batch, forced, d->act)) {
+    const char* sk_env = getenv("BYA_GEMM_SPLITK");
+    const char* var_env = getenv("BYA_GEMM_VARIANT");
+    const bool splitk = ws && !(sk_env && sk_env[0] == '0') && a.K / BK >= 2 * bya_gemm_split_min_ktiles() && v4_eligible(a) &&
+        (!var_env || (var_env[0] == 'v' && var_env[1] == '4'));
+    switch (pick_tile(d->M, d->N, d->K, d->batch, forced, d->act, splitk)) {
         case 0: return launch<128, 64, 2, 2>(a, d->batch, stream);
         case 1: return launch<128, 128, 2, 2>(a, d->batch, stream);
         case 2: return launch<256, 128, 4, 2>(a, d->batch, stream);
@@ -388,7 +418,8 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
     const int tn = (a.N + 255) / 256, tm = (a.M + 255) / 256;
     const long long tiles = (long long)tm * tn;
     const long long full = tiles / 256;
-    if (!no_tail && d->batch == 1 && full >= 1 && tiles % 256 != 0) {
+    // (with a split-K workspace the persistent kernel cuts that last round along K itself: no row split)
+    if (!no_tail && !splitk && d->batch == 1 && full >= 1 && tiles % 256 != 0) {
         const int main_tm = (int)(full * 256 / tn);
         const int m0 = main_tm * 256;
         if (m0 > 0 && m0 < a.M) {

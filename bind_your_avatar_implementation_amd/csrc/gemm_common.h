@@ -18,7 +18,14 @@ struct GemmArgs {
     long long c_split_stride;
     const float* bias_rowscale;   // optional fp32 [batch*M]: bias is multiplied by bias_rowscale[z*M + m]
     float alpha;                  // scales (acc + bias) after the activation (local_face_scale)
+    // split-K workspace of the persistent kernel (gemm_v4.hip; bya_set_gemm_workspace): 256 slabs of 256 x 256 fp32 behind
+    // 1024 counters; null = the last, partial round of tiles is not split
+    float* ws_slabs;
+    unsigned* ws_counters;
 };
+
+constexpr size_t GEMM_WS_COUNTER_BYTES = 4096, GEMM_WS_SLAB_BYTES = 256 * 256 * 4, GEMM_WS_SLABS = 256;
+constexpr size_t GEMM_WS_BYTES = GEMM_WS_COUNTER_BYTES + GEMM_WS_SLABS * GEMM_WS_SLAB_BYTES;
 
 constexpr int BK = 64;  // bf16 elements per K tile = 128-byte LDS rows
 
@@ -165,3 +172,4 @@ int bya_launch_gemm256w4(const void* args, int batch, hipStream_t stream);
 int bya_launch_gemm256v3(const void* args, int batch, hipStream_t stream);
 // defined in gemm_v4.hip (same flags): persistent form of v3 with cross-tile prefetch and 16-byte epilogue accesses
 int bya_launch_gemm256p(const void* args, int batch, hipStream_t stream);
+int bya_gemm_split_min_ktiles();     // K-tiles per K-range below which the persistent kernel does not split a tile

@@ -17,6 +17,16 @@
 //    bytes per row and instruction -- half the memory instructions of the 8-byte epilogue, all requested in bursts
 //    (gemm_common.h explains why that matters: one serialized round trip per access otherwise).
 //
+//  * THE LAST, PARTIAL ROUND IS SPLIT ALONG K (when the caller registered a workspace, bya_set_gemm_workspace): an XCD
+//    whose tile count is not a multiple of its 32 workgroups has R < 32 tiles left after the full rounds; each of them is
+//    cut into p = min(32 / R, K-tiles / 40) K-ranges that p workgroups compute at the same time (shorter ranges do not
+//    pay for the slab exchange: K = 12288 splits, K = 3072 does not).  p - 1 of them write
+//    their 256 x 256 fp32 partial sums to a slab (write-through stores, drained, then one agent-scope counter increment);
+//    the workgroup with the highest index of the p -- dispatched last, so it never waits for a workgroup that has no
+//    CU yet -- polls the counter, adds the slabs inside its epilogue bursts and resets the counter.  17776 x 3072
+//    outputs are 3.28 rounds of tiles: the 0.28 used to cost a whole round (or a row split onto the slower 128 x 128
+//    kernel); per-rank shapes of the sharded step (2222 rows: 108 tiles on 256 CUs) use every CU this way.
+//
 // K-tile variants (tools/gen_gemm_v4_schedule.py holds the placement tables and rewrites the GENERATED block):
 //   A first (C = 0), B steady, C last-but-one (+ next tile's K-tile 0), D last (+ next tile's K-tile 1).  K >= 192.
 //
@@ -49,14 +59,26 @@ __device__ __forceinline__ void dma_piece(uint32_t lds_base, uint32_t voff, cons
                  : "memory");
 }
 
-struct TileCoord { int z, m0, n0; bool valid; };
+// One unit of work: K-tiles [k0, k0 + nkk) of output tile (z, m0, n0).  role 0: the whole tile (ordinary epilogue);
+// 1: a partial sum, written to slab `slab`; 2: the finisher of a tile split into `parts` K-ranges (adds slabs
+// slab, slab + slab_step, ... then the ordinary epilogue; counter `ctr` says when they are complete).
+struct TileCoord { int z, m0, n0; bool valid; int k0, nkk, role, parts, slab, slab_step, ctr; };
+// K-tiles per K-range below which a split does not pay (the slab exchange costs ~20 us: measured break-even ~30 K-tiles)
+constexpr int DEFAULT_MIN_SPLIT_KTILES = 40;
 
 // Wide epilogue of one wave.  The lane (fr = lane & 15, fq = lane >> 4) holds, for row block j and accumulator register e,
 // the EIGHT consecutive columns  n8 = n_wave + (4 e + fq) * 8 + i,  i = 0..7  in acc[i][j][e]  (W rows are staged in the
 // permuted order described at the top), of row  m = m_wave + 16 j + fr.
+// Split tiles (see the top).  A slab holds a tile's partial sums in the order this epilogue walks the accumulators:
+// unit (wave, j, e, half) = the lane's values i = 4 half .. 4 half + 3 of row block j, register e: 16 bytes per lane at
+// ((wave * 64 + (j * 4 + e) * 2 + half) * 64 + lane) * 16, so that one store instruction writes eight whole 128-byte lines.
+// raw_out != null: this workgroup is a WRITER -- its accumulators go to that slab with write-through (sc1) stores and
+// nothing else happens.  Same call site as the ordinary epilogue and through one VALU multiply: a second kind of consumer
+// of the asm-owned accumulators (a plain store of them) made hipcc put the store's data tuples into AGPRs too and evict
+// accumulators to scratch right behind their last MFMA, inside the K-loop -- 250 registers of scratch traffic per tile.
 template <int ACT, int JB>
 __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wave, int n_wave, int fr, int fq,
-                                              const f32x4 (&acc)[8][8]) {
+                                              const f32x4 (&acc)[8][8], int wave, int lane, float* raw_out = nullptr) {
     const bool has_res = p.res != nullptr, has_gate = p.gate0 != nullptr, has_bias = p.bias != nullptr;
     const bool has_rs = p.bias_rowscale != nullptr;
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
@@ -108,10 +130,26 @@ __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wa
             const int m = m_wave + 16 * j + fr;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float b8[8], v[8];
+                float b8[8], v[8], a0[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a0[i] = acc[i][j][e];
+                if (raw_out) {
+                    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)raw_out, 0, (int)GEMM_WS_SLAB_BYTES, 0x00020000);
+                    const uint32_t so = (uint32_t)(((wave * 64 + (j * 4 + e) * 2) * 64 + lane) * 16);
+                    // the values pass through one VALU multiply by an opaque 1.0: stored as they are, hipcc put the store's
+                    // data tuples into AGPRs too and evicted accumulators to scratch inside the K-loop to make room
+                    float one = 1.0f;
+                    asm volatile("" : "+s"(one));
+                    const f32x4 lof = {a0[0] * one, a0[1] * one, a0[2] * one, a0[3] * one};
+                    const f32x4 hif = {a0[4] * one, a0[5] * one, a0[6] * one, a0[7] * one};
+                    const u32x4 lo = __builtin_bit_cast(u32x4, lof), hi = __builtin_bit_cast(u32x4, hif);
+                    __builtin_amdgcn_raw_buffer_store_b128(lo, rsS, so, 0, 16 /* sc1 */);
+                    __builtin_amdgcn_raw_buffer_store_b128(hi, rsS, so + 1024, 0, 16 /* sc1 */);
+                    continue;
+                }
                 unpack8(bv[e], b8);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = p.alpha * apply_act<ACT>(fmaf(rs[jj], b8[i], acc[i][j][e]), p.leaky);
+                for (int i = 0; i < 8; ++i) v[i] = p.alpha * apply_act<ACT>(fmaf(rs[jj], b8[i], a0[i]), p.leaky);
                 if (has_gate) {
                     float g8[8];
                     unpack8(m < p.gate_split ? g0[e] : g1[e], g8);
@@ -130,7 +168,8 @@ __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wa
     }
 }
 
-__global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_m, int tiles_n, int batch) {
+__global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_m, int tiles_n, int batch, int split,
+                                                          int min_seg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 256, BN = 256, STAGE = (BM + BN) * BK * 2, TILE_A = BM * BK * 2;
     static_assert(STAGE == 65536, "stage flip uses one address bit");
@@ -147,9 +186,41 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
     const int cq = total >> 3, cr = total & 7;
     const int base = (xcd < cr) ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
     const int end = base + cq + (xcd < cr ? 1 : 0);
-    auto coord = [&](int id) {
+    // unit `seq` of this workgroup: full rounds first (tile base + slot + seq * slots), then -- with a workspace -- its
+    // K-range of one of the R tiles the full rounds leave over (see the top)
+    const int n_x = end - base;
+    const int full = split ? n_x / slots : 0x7fffffff;
+    const int R = split ? n_x - full * slots : 0;
+    int parts = 1;
+    if (split && R > 0) {
+        parts = slots / R;
+        if (parts > nk / min_seg) parts = nk / min_seg;
+        if (parts < 1) parts = 1;
+    }
+    auto coord = [&](int seq) {
         TileCoord c;
-        c.valid = id < end;
+        c.k0 = 0; c.nkk = nk; c.role = 0; c.parts = 1; c.slab = 0; c.slab_step = 0; c.ctr = 0;
+        int id;
+        if (seq < full) {
+            id = base + slot + seq * slots;
+            c.valid = id < end;
+        } else if (seq == full && R > 0 && slot < R * parts) {
+            const int j = slot / R, r = slot - j * R;
+            id = base + full * slots + r;
+            c.valid = true;
+            if (parts > 1) {
+                c.k0 = j * nk / parts;
+                c.nkk = (j + 1) * nk / parts - c.k0;
+                c.parts = parts;
+                c.role = j == parts - 1 ? 2 : 1;
+                c.slab = c.role == 1 ? xcd * 32 + j * R + r : xcd * 32 + r;
+                c.slab_step = R;
+                c.ctr = xcd * 32 + r;
+            }
+        } else {
+            id = base;
+            c.valid = false;
+        }
         const int idz = c.valid ? id : base;
         c.z = idz / per_z;
         const int idt = idz - c.z * per_z;
@@ -162,8 +233,8 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         c.n0 = (in_g / gsz) * BN;
         return c;
     };
-    int id = base + slot;
-    TileCoord cur = coord(id);
+    int seq = 0;
+    TileCoord cur = coord(seq);
     if (!cur.valid) return;
 
     // fragment read addresses (XOR swizzle on (row >> 1) & 7; row blocks are 16 rows = 2048 bytes apart)
@@ -192,12 +263,13 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         voW[q] = (uint32_t)wcol * (uint32_t)(p.ldw * 2) + chunk16;
     }
     auto a_rsrc = [&](const TileCoord& c) {
-        const long long left = ((long long)(p.M - 1 - c.m0) * p.lda + p.K) * 2;
-        return raw_rsrc(p.A + (long long)c.z * p.a_bs + (long long)c.m0 * p.lda, c.valid && left > 0 ? (uint32_t)left : 0u);
+        const long long left = ((long long)(p.M - 1 - c.m0) * p.lda + p.K - c.k0 * BK) * 2;
+        return raw_rsrc(p.A + (long long)c.z * p.a_bs + (long long)c.m0 * p.lda + c.k0 * BK,
+                        c.valid && left > 0 ? (uint32_t)left : 0u);
     };
     auto w_rsrc = [&](const TileCoord& c) {
-        const long long left = ((long long)(p.N - 1 - c.n0) * p.ldw + p.K) * 2;
-        return raw_rsrc(p.W + (long long)c.n0 * p.ldw, c.valid && left > 0 ? (uint32_t)left : 0u);
+        const long long left = ((long long)(p.N - 1 - c.n0) * p.ldw + p.K - c.k0 * BK) * 2;
+        return raw_rsrc(p.W + (long long)c.n0 * p.ldw + c.k0 * BK, c.valid && left > 0 ? (uint32_t)left : 0u);
     };
     i32x4 rsA = a_rsrc(cur), rsW = w_rsrc(cur);
 
@@ -225,8 +297,9 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         RW(0, 0); RW(0, 1); RW(0, 2); RW(0, 3); RW(0, 4); RW(0, 5); RW(0, 6); RW(0, 7);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-        const TileCoord nxt = coord(id + slots);
+        const TileCoord nxt = coord(seq + 1);
         const i32x4 rsAn = a_rsrc(nxt), rsWn = w_rsrc(nxt);
+        const int unk = cur.nkk;                              // K-tiles of this unit (>= 3)
 
         // One K-tile, variant V (see the top); t = its index inside the output tile.
         auto ktile = [&](int t, auto v_c) {
@@ -785,22 +858,101 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
 #undef FLIP1
         };
         ktile(0, IntTag<'A'>{});
-        for (int t = 1; t + 2 < nk; ++t) ktile(t, IntTag<'B'>{});
-        ktile(nk - 2, IntTag<'C'>{});
-        ktile(nk - 1, IntTag<'D'>{});
+        for (int t = 1; t + 2 < unk; ++t) ktile(t, IntTag<'B'>{});
+        ktile(unk - 2, IntTag<'C'>{});
+        ktile(unk - 1, IntTag<'D'>{});
 #undef RA
 #undef RW
         // K-tile 0 of the next output tile (16 pieces, requested during variant C) has landed once all but the 16 younger
         // pieces of its K-tile 1 have; the MFMAs are inline asm, so pad their last results before the epilogue reads them
         asm volatile("s_waitcnt vmcnt(16)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-        auto run = [&](auto act_tag) {
-            epilogue_wide<decltype(act_tag)::value, 2>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc);
-        };
-        dispatch_act_big(p.act, run);
+        if (cur.role == 2) {
+            // ---- finisher of a split tile: the other K-ranges were started together with this one; wait for their slabs
+            if (tid == 0) {
+                while (__hip_atomic_load(p.ws_counters + cur.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+                       (unsigned)(cur.parts - 1))
+                    __builtin_amdgcn_s_sleep(8);
+                if (split == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            // add the slabs into the accumulators (back into the AGPRs: the epilogue below is the ordinary one).  (row block,
+            // slab) pairs in order, the loads of pair it + 1 in flight while pair it is summed: a slab read is an
+            // agent-scope (sc1) load, a memory round trip past the L2s -- other workgroups, maybe on another XCD, wrote it
+            {
+                const float* const part0 = p.ws_slabs + (size_t)cur.slab * (GEMM_WS_SLAB_BYTES / 4);
+                const int nparts = cur.parts - 1, part_step = cur.slab_step;
+                u32x4 pf[4][2];
+                auto issue = [&](int it) {
+                    const int jn = it / nparts, s2 = it - jn * nparts;
+                    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(part0 + (size_t)s2 * part_step * (GEMM_WS_SLAB_BYTES / 4)), 0, (int)GEMM_WS_SLAB_BYTES, 0x00020000);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int hlf = 0; hlf < 2; ++hlf)
+                            pf[e][hlf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                rsP, (uint32_t)(((wave * 64 + (jn * 4 + e) * 2 + hlf) * 64 + lane) * 16), 0, 16 /* sc1 */));
+                };
+                issue(0);
+#pragma unroll
+                for (int jn = 0; jn < 8; ++jn) {
+                    float ps[4][8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) ps[e][i] = 0.f;
+                    for (int s2 = 0; s2 < nparts; ++s2) {
+                        f32x4 c[4][2];
+                        // whole-vector casts: bit_cast of ONE element of an ext_vector miscompiles (hipcc 7.2 returns element 0)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { c[e][0] = __builtin_bit_cast(f32x4, pf[e][0]); c[e][1] = __builtin_bit_cast(f32x4, pf[e][1]); }
+                        const int it = jn * nparts + s2 + 1;
+                        if (it < 8 * nparts) issue(it);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) ps[e][i] += c[e][i >> 2][i & 3];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        f32x4 t = acc[i][jn];
+                        t[0] += ps[0][i]; t[1] += ps[1][i]; t[2] += ps[2][i]; t[3] += ps[3][i];
+                        asm volatile("" : "+a"(t));          // back into accumulator registers, 4 at a time
+                        acc[i][jn] = t;
+                    }
+                }
+            }
+            auto run = [&](auto act_tag) {
+                epilogue_wide<decltype(act_tag)::value, 2>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc, wave, lane);
+            };
+            dispatch_act_big(p.act, run);
+            asm volatile("s_barrier" ::: "memory");          // every wave has read the slabs: the counter can go back to 0
+            if (tid == 0) __hip_atomic_store(p.ws_counters + cur.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // ---- whole tile (ordinary epilogue), or (role 1) a split tile's partial sums -> slab, then drained and counted
+            float* const raw_out = cur.role == 1 ? p.ws_slabs + (size_t)cur.slab * (GEMM_WS_SLAB_BYTES / 4) : nullptr;
+            auto run = [&](auto act_tag) {
+                epilogue_wide<decltype(act_tag)::value, 2>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc, wave, lane,
+                                                           raw_out);
+            };
+            dispatch_act_big(p.act, run);
+            if (cur.role == 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                if (tid == 0) {
+                    if (split == 2) {                    // debugging aid: full agent-scope release instead of relying on sc1
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __hip_atomic_fetch_add(p.ws_counters + cur.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
 
         if (!nxt.valid) break;
-        id += slots;
+        ++seq;
         cur = nxt;
         rsA = rsAn;
         rsW = rsWn;
@@ -810,14 +962,24 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
 
 }  // namespace
 
+int bya_gemm_split_min_ktiles() {
+    const char* e = getenv("BYA_GEMM_SPLITK_MIN");           // test / tuning switch, read per call
+    const int v = e ? atoi(e) : DEFAULT_MIN_SPLIT_KTILES;
+    return v < 3 ? 3 : v;
+}
+
 int bya_launch_gemm256p(const void* args, int batch, hipStream_t s) {
     const GemmArgs& a = *static_cast<const GemmArgs*>(args);
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
     const long long total = (long long)tiles_m * tiles_n * batch;
-    int blocks = (int)(total < 256 ? (total + 7) / 8 * 8 : 256);
+    // split the last partial round along K when a workspace is registered (BYA_GEMM_SPLITK=0 switches it off, read per call)
+    const char* sk = getenv("BYA_GEMM_SPLITK");
+    const int min_seg = bya_gemm_split_min_ktiles();
+    const int split = (a.ws_slabs && a.ws_counters && !(sk && sk[0] == '0') && a.K / BK >= 2 * min_seg) ? (sk && sk[0] == '2' ? 2 : 1) : 0;
+    int blocks = (int)(total < 256 && !split ? (total + 7) / 8 * 8 : 256);
     const size_t lds = 2 * 512 * BK * 2;
     static std::atomic<unsigned long long> attr_done{0};
     if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256p_kernel), (int)lds, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
-    BYA_LAUNCH(gemm256p_kernel, dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, batch);
+    BYA_LAUNCH(gemm256p_kernel, dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, batch, split, min_seg);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

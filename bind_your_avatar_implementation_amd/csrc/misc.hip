@@ -77,24 +77,40 @@ struct CombArgs {
 // two streams the reference's  w = 1 - av[[1, 0]]  (models/transformer.py:895-900); for more streams -- the reference
 // hard-codes two -- the build-defined generalisation  w[a] = prod_{b != a} (1 - av[b])  evaluated as a chain of bf16 tensor
 // ops like oracle/model.py::audio_weights ("not any other speaker's region"; identical bits for two streams).
+template <int NID>
+__device__ __forceinline__ void audio_weights_n(const bf16_t* __restrict__ af, const bf16_t* __restrict__ r, float (&w)[4]) {
+    float rv[NID], om[NID];
+#pragma unroll
+    for (int i = 0; i < NID; ++i) rv[i] = bf2f(r[i]);
+#pragma unroll
+    for (int a = 0; a < NID; ++a) {
+        float av = 0.f;
+#pragma unroll
+        for (int i = 0; i < NID; ++i) av = fmaf(bf2f(af[a * NID + i]), rv[i], av);
+        om[a] = bf2f(f2bf(1.0f - bf2f(f2bf(av))));
+    }
+#pragma unroll
+    for (int a = 0; a < NID; ++a) {
+        float t = 1.0f;
+#pragma unroll
+        for (int bb = 0; bb < NID; ++bb)
+            if (bb != a) t = bf2f(f2bf(t * om[bb]));
+        w[a] = t;
+    }
+}
+
 __device__ __forceinline__ void routing_weights(const CombArgs& p, const bf16_t* r, int b, float (&w)[4]) {
     if (p.mode == 0) {
-        for (int i = 0; i < p.n_id; ++i) w[i] = bf2f(r[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = i < p.n_id ? bf2f(r[i]) : 0.f;
         return;
     }
     const bf16_t* af = p.af + b * p.n_id * p.n_id;
-    float rv[4], om[4];
-    for (int i = 0; i < p.n_id; ++i) rv[i] = bf2f(r[i]);
-    for (int a = 0; a < p.n_id; ++a) {
-        float av = 0.f;
-        for (int i = 0; i < p.n_id; ++i) av = fmaf(bf2f(af[a * p.n_id + i]), rv[i], av);
-        om[a] = bf2f(f2bf(1.0f - bf2f(f2bf(av))));
-    }
-    for (int a = 0; a < p.n_id; ++a) {
-        float t = 1.0f;
-        for (int bb = 0; bb < p.n_id; ++bb)
-            if (bb != a) t = bf2f(f2bf(t * om[bb]));
-        w[a] = t;
+    w[2] = w[3] = 0.f;
+    switch (p.n_id) {          // unrolled per count: everything stays in registers (the two-stream form is the hot one)
+        case 2: audio_weights_n<2>(af, r, w); break;
+        case 3: audio_weights_n<3>(af, r, w); break;
+        default: audio_weights_n<4>(af, r, w); break;
     }
 }
 
@@ -113,11 +129,14 @@ __global__ __launch_bounds__(256) void masked_combine_kernel(CombArgs p) {
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int i = 0; i < p.n_id; ++i) {
-        float f[8];
-        unpack8(*reinterpret_cast<const u32x4*>(p.feat + (((long long)b * p.n_id + i) * p.N + n) * p.D + c8 * 8), f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(w[i], f[e], acc[e]);
+    for (int i = 0; i < 4; ++i) {
+        if (i < p.n_id) {
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4*>(p.feat + (((long long)b * p.n_id + i) * p.N + n) * p.D + c8 * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(w[i], f[e], acc[e]);
+        }
     }
     bf16_t* xp = p.x + b * p.x_bs + n * p.x_row + c8 * 8;
     float xv[8];
@@ -153,12 +172,15 @@ __global__ __launch_bounds__(256) void routed_mix_kernel(CombArgs p, bf16_t* __r
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     float ws = 0.f;
-    for (int i = 0; i < p.n_id; ++i) {
-        float f[8];
-        unpack8(*reinterpret_cast<const u32x4*>(p.feat + (((long long)b * p.n_id + i) * p.N + n) * p.D + c8 * 8), f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(w[i], f[e], acc[e]);
-        ws += w[i];
+    for (int i = 0; i < 4; ++i) {
+        if (i < p.n_id) {
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4*>(p.feat + (((long long)b * p.n_id + i) * p.N + n) * p.D + c8 * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(w[i], f[e], acc[e]);
+            ws += w[i];
+        }
     }
     *reinterpret_cast<u32x4*>(z + ((long long)b * p.N + n) * p.D + c8 * 8) = pack8(acc);
     if (c8 == 0 && wsum) wsum[(long long)b * p.N + n] = ws;

@@ -58,6 +58,7 @@ class DenoiseEngine:
         if p.dtype != torch.bfloat16:
             raise RuntimeError(f"engine computes in bf16 (MFMA, fp32 accumulate); parameters are {p.dtype}")
         ops._hip.load()      # fail loudly right here if libbya_hip.so is missing
+        ops.ensure_gemm_workspace(p.device)      # split-K slabs of the persistent GEMM kernel (one per process)
         self.m = model
         self.cfg = model.config
         self.dev = p.device

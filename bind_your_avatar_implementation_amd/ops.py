@@ -106,6 +106,27 @@ def _mat(t, name):
     raise ValueError(f"{name}: expected 2-D or 3-D, got {t.dim()}-D")
 
 
+_GEMM_WS = None
+
+
+def ensure_gemm_workspace(device):
+    """Register the split-K workspace of the persistent GEMM kernel (bya_set_gemm_workspace) once per process: 64 MiB of
+    zero-filled device memory that lives as long as the process.  Without it the kernels still run (no K split)."""
+    global _GEMM_WS
+    if _GEMM_WS is not None:
+        if _GEMM_WS.device != torch.device(device):
+            raise RuntimeError("the GEMM split-K workspace is per process: one GPU per process (DESIGN.md section 5)")
+        return _GEMM_WS
+    lib = _hip.load()
+    n = ctypes.c_int64(0)
+    check(lib.bya_gemm_workspace_bytes(ctypes.byref(n)), "bya_gemm_workspace_bytes")
+    ws = torch.zeros(n.value, dtype=torch.uint8, device=device)
+    torch.cuda.synchronize(device)
+    check(lib.bya_set_gemm_workspace(ws.data_ptr(), n.value), "bya_set_gemm_workspace")
+    _GEMM_WS = ws
+    return ws
+
+
 def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, gate_batch_stride=0, act=None,
          split=None, bias_rowscale=None, alpha=1.0):
     """out = res + gate * act(a @ w.T + bias).  a: [(B,) M, K], w: [N, K], out/res: [(B,) M, N].
@@ -115,6 +136,8 @@ def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, g
     lib = _hip.load()
     ab, M, K, a_bs, lda = _mat(a, "a")
     ob, Mo, N, c_bs, ldc = _mat(out, "out")
+    if _GEMM_WS is None:
+        ensure_gemm_workspace(a.device)
     if split is not None:
         N = w.shape[0]
     if w.dim() != 2 or w.shape[1] != K or w.shape[0] != N or w.stride(1) != 1 or w.dtype != torch.bfloat16:

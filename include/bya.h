@@ -63,6 +63,14 @@ typedef struct bya_gemm_desc {
 int bya_gemm_bf16(const void* A, const void* W, const void* bias, void* C, const void* res,
                   const void* gate0, const void* gate1, const bya_gemm_desc* desc, hipStream_t stream);
 
+/* Optional split-K workspace of the persistent GEMM kernel (device memory owned by the caller, 256-byte aligned, at
+ * least the size bya_gemm_workspace_bytes reports, ZERO-FILLED once): with it, the last partial round of 256 x 256 output tiles
+ * of a bya_gemm_bf16 launch is cut along K over the idle CUs (partial sums and completion counters live here).  One
+ * workspace per process: launches that use it must be ordered on one stream.  NULL unregisters.  Results do not depend
+ * on it beyond fp32 summation order.  (No reference counterpart: scheduling detail of the Linear layers.) */
+int bya_set_gemm_workspace(void* ws, int64_t bytes);
+int bya_gemm_workspace_bytes(int64_t* bytes);
+
 /* ---------------------------------------------------------------------------------------------
  * Small-M linear (M <= 8 rows):  out[m,n] = sum_k f(x[m,k]) * W[n,k] + bias[n],  f = identity or SiLU.
  * HBM-bound weight stream.  Replaces TimestepEmbedding.linear_1/2, CogVideoXLayerNormZero.linear

@@ -6,6 +6,7 @@ comparison target is the fp32 reference result ROUNDED to bf16 (an exact kernel 
 ``relative Frobenius error <= 1e-3`` unless a test states otherwise.  Index-only kernels are bit-exact.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -52,6 +53,67 @@ def test_gemm_plain(ops, dev, M, N, K):
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     ops.gemm(a, w, out)
     check(out, a.float() @ w.float().T, what=f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K,epi", [
+    (17776, 3072, 3072, "gate_res"),      # attention out-projection: 840 tiles = 3.28 rounds -> 9 leftover tiles per XCD x 3
+    (17550, 3072, 3072, "res"),           # audio out-projection: 828 tiles, XCDs with 7 and with 8 leftover tiles (x 4)
+    (17776, 3072, 12288, "gate_res"),     # FF2
+    (2222, 3072, 3072, "res"),            # one rank's rows of an 8-GPU step: 108 tiles on 256 CUs, every tile split in 2
+    (2222, 9216, 3072, "split3"),         # its packed q|k|v projection: one full round + leftovers
+    (1024, 1024, 2048, "gelu"),           # 16 tiles: 2 per XCD, 4 K-ranges each
+    (4000, 1536, 1024, "plain"),          # ragged M (4000 = 15.6 tiles), 16 K-tiles: exactly 2 ranges of 8
+    (2222, 3072, 12288, "gate_res"),      # one rank's FF2
+])
+def test_gemm_split_k_last_round(ops, dev, M, N, K, epi, monkeypatch):
+    """The persistent kernel cuts the last, partial round of 256 x 256 tiles along K when the split-K workspace is
+    registered (ops.gemm registers it): partial sums travel through fp32 slabs between workgroups (write-through stores,
+    agent-scope counter).  Against the fp32 product with the usual bar, against the unsplit kernel (BYA_GEMM_SPLITK=0:
+    same products, only the fp32 summation order of a split tile differs) and 12 repeats bit-identical on a busy GPU
+    (a wrong wait, a stale slab or a counter that is not reset shows as rare wrong tiles).  By default only K-ranges of
+    40+ K-tiles are split (K = 12288: the exchange costs ~20 us); BYA_GEMM_SPLITK_MIN=8 makes every shape here split."""
+    monkeypatch.setenv("BYA_GEMM_SPLITK_MIN", "8")
+    a, w, b = rnd((M, K), dev, 31), rnd((N, K), dev, 32, K ** -0.5), rnd((N,), dev, 33, 0.5)
+    kw, ref = {}, a.float() @ w.float().T + b.float()
+    res = rnd((M, N), dev, 34)
+    gate = rnd((2, N), dev, 35)
+    n_out = N
+    if epi == "gelu":
+        kw, ref = dict(act="gelu_tanh"), F.gelu(ref, approximate="tanh")
+    elif epi == "res":
+        kw, ref = dict(res=res), ref + res.float()
+    elif epi == "gate_res":
+        kw = dict(res=res, gate0=gate[0], gate1=gate[1], gate_split=226)
+        g = torch.where((torch.arange(M, device=dev) < 226)[:, None], gate[0].float()[None], gate[1].float()[None])
+        ref = ref * g + res.float()
+    def run():
+        if epi == "split3":
+            out = torch.empty(3, M, N // 3, dtype=torch.bfloat16, device=dev)
+            ops.gemm(a, w, out[0], bias=b, split=(N // 3, M * (N // 3)))
+            return out.permute(1, 0, 2).reshape(M, N)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(a, w, out, bias=b, **kw)
+        return out
+    first = run()
+    check(first, ref, what=f"split-K gemm {M}x{N}x{K} {epi}")
+    os.environ["BYA_GEMM_SPLITK"] = "0"
+    try:
+        unsplit = run()
+    finally:
+        del os.environ["BYA_GEMM_SPLITK"]
+    d = (first.float() - unsplit.float()).abs()
+    frac = (d > 0).float().mean().item()
+    print(f"split vs unsplit: {frac * 100:.2f} % of the outputs differ, max {d.max().item():.3e} (one bf16 step of the value)")
+    assert rel_fro(first.float(), unsplit.float()) < 2e-3
+    x, y = rnd((8192, 8192), dev, 36), rnd((8192, 8192), dev, 37)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(4):
+            x @ y
+    outs = [run() for _ in range(12)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(first, o) for o in outs)
+    assert torch.equal(run(), first)
 
 
 def test_gemm_mfma_layout_asymmetric(ops, dev):
