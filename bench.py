@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--latent-hw", type=int, nargs=2, default=[60, 90], metavar=("H", "W"),
                     help="latent height / width; anything but 60 90 (= 480x720) is not the headline config")
     ap.add_argument("--batch", type=int, default=1, help="2 = the CFG pair of BASELINE config 3 (not the headline)")
+    ap.add_argument("--latent-frames", type=int, default=13, help="25 = the 97-frame clip of BASELINE config 4 (not the headline)")
+    ap.add_argument("--identities", type=int, default=2, help="3 = BASELINE config 4's character count (not the headline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,7 +176,8 @@ def main():
     from bind_your_avatar_implementation_amd.synth import synth_inputs
 
     lh, lw = args.latent_hw
-    kw = dict(MODEL_KW, num_layers=args.layers, sample_height=lh, sample_width=lw)
+    lt, nid = args.latent_frames, args.identities
+    kw = dict(MODEL_KW, num_layers=args.layers, sample_height=lh, sample_width=lw, sample_frames=(lt - 1) * 4 + 1)
     model = BindyouravatarTransformer3DModel(**kw, device=dev).init_synthetic(seed=0, fast=True)
     if world > 1:
         from bind_your_avatar_implementation_amd.parallel import shard_cfg, shard_sequence
@@ -182,7 +185,8 @@ def main():
             shard_cfg(model, dist.group.WORLD)          # [uncond, cond] on two halves of the ranks
         else:
             shard_sequence(model, dist.group.WORLD)
-    inp = synth_inputs(batch=args.batch, height=lh, width=lw, seed=0, device="cpu", uncond_first=args.batch == 2)
+    inp = synth_inputs(batch=args.batch, frames=lt, height=lh, width=lw, n_id=nid, seed=0, device="cpu",
+                       uncond_first=args.batch == 2)
     inp = {k: (v.to(dev, torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else
                (v.to(dev) if torch.is_tensor(v) else v)) for k, v in inp.items()}
     inp["image_rotary_emb"] = tuple(t.to(dev, torch.float32) for t in inp["image_rotary_emb"])
@@ -226,7 +230,7 @@ def main():
         torch.cuda.synchronize()
         ktimes = ops.collect_kernel_timers()
 
-    headline = (lh, lw) == (60, 90) and args.batch == 1
+    headline = (lh, lw, lt, nid) == (60, 90, 13, 2) and args.batch == 1
     if rank == 0:
         sec_per_step = dt / args.steps
         value = 1.0 / sec_per_step
@@ -234,14 +238,15 @@ def main():
             "metric": "denoise-steps/sec", "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "latent_frames_per_sec": 13 * value,
+            "latent_frames_per_sec": lt * value,
             "mfma_roofline_frac_whole_step": (TFLOP_PER_STEP * (args.layers / 42) * value / (world * PEAK_BF16_TFLOPS)
                                               if headline else None),
             "config": {"workload": ("BASELINE.json configs[1]: full transformer.forward, 49x480x720 (13x30x45 latent "
                                     "tokens + 226 text), 2 characters (2 ID + 2 audio), batch 1, random-init 8.6B-param "
                                     "architecture") if headline else
-                                   (f"NOT the headline config: full transformer.forward, 49x{lh * 8}x{lw * 8} "
-                                    f"(13x{lh // 2}x{lw // 2} latent tokens + 226 text), 2 characters, batch {args.batch}"), "layers": args.layers, "tokens": 226 + 13 * (lh // 2) * (lw // 2), "batch": args.batch,
+                                   (f"NOT the headline config: full transformer.forward, {(lt - 1) * 4 + 1}x{lh * 8}x{lw * 8} "
+                                    f"({lt}x{lh // 2}x{lw // 2} latent tokens + 226 text), {nid} characters, batch {args.batch}"),
+                       "layers": args.layers, "tokens": 226 + lt * (lh // 2) * (lw // 2), "batch": args.batch,
                        "launch": "hipGraph replay" if (args.graph and world == 1) else "eager",
                        "parallelism": "single GPU" if world == 1 else
                        (f"CFG batch split x2, each half sequence-parallel x{world // 2}" if args.batch == 2 else
@@ -257,12 +262,12 @@ def main():
             attn_roof = None
             if attn:
                 avg = sum(attn) / len(attn)
-                tokens = 226 + 13 * (lh // 2) * (lw // 2)
+                tokens = 226 + lt * (lh // 2) * (lw // 2)
                 shards = world // 2 if (args.batch == 2 and world > 1) else world       # ranks sharing one sample's attention
                 per_launch = 4 * tokens ** 2 * 3072 / 1e12 * (args.batch if world == 1 else 1)
                 ach = per_launch / max(shards, 1) / avg
                 jv = sorted(v for (tag, v), n in ops.ATTN_VARIANTS.items() if tag == "joint" and n)
-                attn_roof = {"kernel": "joint 17776-token self-attention, softmax variant(s): " + ", ".join(jv),
+                attn_roof = {"kernel": f"joint {tokens}-token self-attention, softmax variant(s): " + ", ".join(jv),
                              "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                              "frac": ach / PEAK_BF16_TFLOPS,
                              "traffic": pmc_traffic(world, "attn_fwd_kernel_d64_bounded", "attn_fwd_kernel_d64_prescaled"),
@@ -272,10 +277,11 @@ def main():
             gemm_roof = None
             if gemm:
                 gflop = ops.kernel_timer_flops().get("bya_gemm_bf16", 0.0)
-                gemm_roof = {"kernel": "bya_gemm_bf16 (every Linear of the step: pipelined 256x256 tiles + 128x128 tiles)",
+                gemm_roof = {"kernel": "bya_gemm_bf16 (every Linear of the step: gemm256p_kernel 256x256 tiles, 87 % of the time, + "
+                                       "128x128 tiles; `traffic` is gemm256p_kernel's, per launch of that kernel)",
                              "bound": "mfma", "achieved": gflop / 1e12 / sum(gemm), "peak": PEAK_BF16_TFLOPS,
                              "unit": "TFLOP/s", "frac": gflop / 1e12 / sum(gemm) / PEAK_BF16_TFLOPS,
-                             "traffic": pmc_traffic(world, "gemm256_kernel"), "launches": len(gemm),
+                             "traffic": pmc_traffic(world, "gemm256p_kernel", "gemm256_kernel"), "launches": len(gemm),
                              "avg_launch_ms": sum(gemm) / len(gemm) * 1e3, "tflop_per_launch_avg": gflop / 1e12 / len(gemm),
                              "ms_per_step": sum(gemm) / args.steps * 1e3}
             # headline = the kernel that dominates the step's time (the GEMM kernel when both were timed)

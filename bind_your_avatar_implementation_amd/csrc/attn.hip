@@ -28,6 +28,21 @@ struct AttnArgs {
     float score_bound; // > 0: |score| <= bound guaranteed by the caller -> static-offset softmax (no running maximum)
 };
 
+// Ablation build (tools/attn_ablate.py; NEVER defined in the product build): a bit mask of work to leave out of the hot
+// loop, results become meaningless, only the time is read.  1: v_exp -> one FMA, 2: K fragments read from LDS once per
+// block instead of per tile, 4: V fragments likewise, 8: no K/V staging after the first tile, 16: no row-sum adds.
+#ifndef BYA_ATTN_ABLATE
+#define BYA_ATTN_ABLATE 0
+#endif
+#ifndef BYA_ATTN_KPREFETCH
+#define BYA_ATTN_KPREFETCH 1      // 0 = the compiler-scheduled K reads of round 1 (kept for tools/attn_ablate.py's A/B)
+#endif
+#ifndef BYA_ATTN_OCC
+#define BYA_ATTN_OCC 4
+#endif
+#ifndef BYA_ATTN_RING
+#define BYA_ATTN_RING 2          // K/V stages in LDS for head_dim 64 (3 = staging two tiles ahead; experiment switch)
+#endif
 constexpr int KV_TILE = 64;
 constexpr int Q_PER_WAVE = 32;
 constexpr int Q_PER_BLOCK = 128;
@@ -69,6 +84,13 @@ __device__ __forceinline__ s16x4 lds_tr_read(uint32_t addr) {
     return v;
 }
 
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+
 template <int N>
 __device__ __forceinline__ void lgkm_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
@@ -83,6 +105,7 @@ struct VFrag {
 template <int D, int KS>
 __device__ __forceinline__ void v_issue(VFrag<D>& f, const uint32_t (&vbase)[D / 32]) {
     constexpr int RB = D * 2;
+    if ((BYA_ATTN_ABLATE & 4) && KS >= 2) return;          // ablation: half of the V reads (k-steps 2, 3 reuse 0, 1)
 #pragma unroll
     for (int d = 0; d < D / 32; ++d) {
         f.lo[d] = lds_tr_read<KS * 16 * RB>(vbase[d]);
@@ -131,6 +154,38 @@ __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase
     const float thr = PRESCALED ? RESCALE_THR : RESCALE_THR / c;
     constexpr int ROW_BYTES = D * 2, DSTEPS = D / 16, DT = D / 32;
     f32x16 sacc[2];
+    if constexpr (D == 64 && BYA_ATTN_KPREFETCH) {
+        // ALL eight K fragments of the tile are requested before the first MFMA and every MFMA waits for its own fragment
+        // only (asm reads, counted lgkmcnt).  Left to hipcc, the 128-register budget of four waves per SIMD made it
+        // reuse one fragment register quad: read, wait lgkmcnt(0), MFMA, read ... -- three exposed LDS round trips per
+        // tile, 250 of the 790 cycles a wave spent per tile (ablation: tools/attn_ablate.py, profiles/r2_attn_ablation.json).
+        const uint32_t kb = (uint32_t)(uintptr_t)LDS_PTR(kt) + r * ROW_BYTES;
+        const int sw = kswz<D>(r);                       // rows r and r + 32 share the swizzle (32 is a multiple of 16)
+        bf16x8 kf[2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t a = kb + (((2 * s + hf) ^ sw) << 4);
+            kf[0][s] = lds_read128<0>(a);
+            kf[1][s] = lds_read128<32 * ROW_BYTES>(a);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[u][i] = 0.f;
+        if (!BOUNDED) {
+            sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mfrag, sacc[0], 0, 0, 0);
+            sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mfrag, sacc[1], 0, 0, 0);
+        }
+        lgkm_wait<6>(); sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][0], qf[0], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][0], qf[0], sacc[1], 0, 0, 0);
+        lgkm_wait<4>(); sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][1], qf[1], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][1], qf[1], sacc[1], 0, 0, 0);
+        lgkm_wait<2>(); sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][2], qf[2], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][2], qf[2], sacc[1], 0, 0, 0);
+        lgkm_wait<0>(); sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][3], qf[3], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][3], qf[3], sacc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -141,13 +196,15 @@ __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase
         for (int s = 0; s < DSTEPS; ++s) {
             const int chunk = 2 * s + hf;
             const int off = krow * ROW_BYTES + ((chunk ^ kswz<D>(krow)) << 4);
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + off);
+            const bf16x8 kf = (BYA_ATTN_ABLATE & 2) ? qf[(s + 1 + u) % DSTEPS] : *reinterpret_cast<const bf16x8*>(kt + off);   // (+ u: no CSE of the two chains)
             sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[u], 0, 0, 0);
         }
+    }
     }
     // first V fragments can fly while the softmax runs
     VFrag<D> fa, fb;
     v_issue<D, 0>(fa, vbase);
+    if constexpr (D == 64 && BYA_ATTN_KPREFETCH) __builtin_amdgcn_sched_barrier(0);      // ... issued HERE, ahead of the softmax
 
     float mx = -INFINITY;
 #pragma unroll
@@ -200,8 +257,9 @@ __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(PRESCALED ? sacc[u][tt * 8 + e] : sacc[u][tt * 8 + e] * c);
-                psum += pv;
+                const float sv = PRESCALED ? sacc[u][tt * 8 + e] : sacc[u][tt * 8 + e] * c;
+                const float pv = (BYA_ATTN_ABLATE & 1) ? fmaf(sv, 0.015625f, 1.0f) : __builtin_amdgcn_exp2f(sv);
+                if (!(BYA_ATTN_ABLATE & 16)) psum += pv;
                 pf[u * 2 + tt][e] = (__bf16)pv;
             }
     l_run += psum;
@@ -226,6 +284,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
     constexpr int TILE_BYTES = KV_TILE * ROW_BYTES;
     constexpr int DSTEPS = D / 16;   // k-steps of the QK^T product
     constexpr int DT = D / 32;       // 32-row tiles of O^T
+    constexpr int RING = D == 64 ? BYA_ATTN_RING : 2;
     // LDS ring: stage b holds K at smem + b*2*TILE_BYTES and V right behind it
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -311,7 +370,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
     }
     const int k_tile_stride = KV_TILE * (int)p.k_row * 2, v_tile_stride = KV_TILE * (int)p.v_row * 2;
     auto stage = [&](int t) {
-        char* st = smem + (t & 1) * 2 * TILE_BYTES + wave * 16 * ROW_BYTES;
+        char* st = smem + (RING == 2 ? (t & 1) : (t % 3)) * 2 * TILE_BYTES + wave * 16 * ROW_BYTES;
 #pragma unroll
         for (int q = 0; q < NPIECE; ++q) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_PTR(st + q * 1024), 16, kvo[q], t * k_tile_stride, 0, 0);
@@ -323,15 +382,27 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
     const int ntiles = (p.Skv + KV_TILE - 1) / KV_TILE;
     const int nfull = p.Skv / KV_TILE;
     stage(0);
+    if (RING == 3 && ntiles > 1) stage(1);
+    int slot = 0;                                         // ring slot of tile t
 
     for (int t = 0; t < nfull; ++t) {                     // full tiles: no masking code in the hot loop
+        if constexpr (RING == 3) {
+            // tile t has landed once all but the 2 NPIECE younger requests (tile t + 1) are done; raw barrier: a
+            // __syncthreads() would drain the LDS-DMA in flight.  Tile t + 2 goes where tile t - 1 was: everybody is past it.
+            if (t + 1 < ntiles) { if constexpr (NPIECE == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (t + 2 < ntiles) stage(t + 2);
+        } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < ntiles) stage(t + 1);
-        const char* kt = smem + (t & 1) * 2 * TILE_BYTES;
+        if (t + 1 < ntiles && (!(BYA_ATTN_ABLATE & 8) || t == 0)) stage(t + 1);
+        }
+        const char* kt = smem + slot * 2 * TILE_BYTES;
         uint32_t vbase[DT];
 #pragma unroll
-        for (int d = 0; d < DT; ++d) vbase[d] = lds0 + (t & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
+        for (int d = 0; d < DT; ++d) vbase[d] = lds0 + slot * 2 * TILE_BYTES + TILE_BYTES + voff[d];
+        slot = (slot + 1 == RING) ? 0 : slot + 1;
         int tz = t;
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+s"(tz));                       // opaque: keeps hipcc from peeling the first iteration
@@ -342,10 +413,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
     if (nfull < ntiles) {                                 // ragged last tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const char* kt = smem + (nfull & 1) * 2 * TILE_BYTES;
+        const char* kt = smem + slot * 2 * TILE_BYTES;
         uint32_t vbase[DT];
 #pragma unroll
-        for (int d = 0; d < DT; ++d) vbase[d] = lds0 + (nfull & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
+        for (int d = 0; d < DT; ++d) vbase[d] = lds0 + slot * 2 * TILE_BYTES + TILE_BYTES + voff[d];
         attn_tile<D, true, PRESCALED, BOUNDED>(kt, vbase, qf, oacc, ones, mfrag, m_run, l_run, nfull == 0,
                                                p.Skv - nfull * KV_TILE, r, hf, BOUNDED ? p.score_bound : p.scale_log2);
     }
@@ -378,7 +449,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel_d64_prescaled(AttnArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_fwd_body<64, true>(p, smem);
 }
-__global__ __launch_bounds__(256, 4) void attn_fwd_kernel_d64_bounded(AttnArgs p) {
+__global__ __launch_bounds__(256, BYA_ATTN_OCC) void attn_fwd_kernel_d64_bounded(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_fwd_body<64, true, true>(p, smem);
 }
@@ -391,7 +462,7 @@ template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     const int nbh = a.nb1 * a.nb2 * a.heads;
     dim3 grid((nbh * a.nqt + 7) / 8 * 8);          // whole groups of 8 (one block per XCD); surplus blocks exit at once
-    const size_t lds = 4 * KV_TILE * D * 2;
+    const size_t lds = (size_t)(D == 64 ? BYA_ATTN_RING : 2) * 2 * KV_TILE * D * 2;
     if (D == 64 && a.prescaled && a.score_bound > 0.f) BYA_LAUNCH(attn_fwd_kernel_d64_bounded, grid, dim3(256), lds, s, a);
     else if (D == 64 && a.prescaled) BYA_LAUNCH(attn_fwd_kernel_d64_prescaled, grid, dim3(256), lds, s, a);
     else if (D == 64) BYA_LAUNCH(attn_fwd_kernel_d64, grid, dim3(256), lds, s, a);
