@@ -281,7 +281,7 @@ def main():
                                        "128x128 tiles; `traffic` is gemm256p_kernel's, per launch of that kernel)",
                              "bound": "mfma", "achieved": gflop / 1e12 / sum(gemm), "peak": PEAK_BF16_TFLOPS,
                              "unit": "TFLOP/s", "frac": gflop / 1e12 / sum(gemm) / PEAK_BF16_TFLOPS,
-                             "traffic": pmc_traffic(world, "gemm256p_kernel", "gemm256_kernel"), "launches": len(gemm),
+                             "traffic": pmc_traffic(world, "gemm256p_kernel<false>", "gemm256p_kernel", "gemm256_kernel"), "launches": len(gemm),
                              "avg_launch_ms": sum(gemm) / len(gemm) * 1e3, "tflop_per_launch_avg": gflop / 1e12 / len(gemm),
                              "ms_per_step": sum(gemm) / args.steps * 1e3}
             # headline = the kernel that dominates the step's time (the GEMM kernel when both were timed)

@@ -5,7 +5,10 @@ Loading fails LOUDLY: there is no CPU / PyTorch fallback for the product path.
 import ctypes
 import os
 
-from .build import LIB_PATH
+from .build import LIB_PATH as _BUILT_LIB
+
+# tools/ A/B runs may point at a side build of the same library (never set in production)
+LIB_PATH = os.environ.get("BYA_HIP_LIB") or _BUILT_LIB
 
 _c = ctypes
 _vp, _i32, _i64, _f32 = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_float

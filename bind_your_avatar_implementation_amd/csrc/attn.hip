@@ -35,7 +35,8 @@ struct AttnArgs {
 #define BYA_ATTN_ABLATE 0
 #endif
 #ifndef BYA_ATTN_KPREFETCH
-#define BYA_ATTN_KPREFETCH 1      // 0 = the compiler-scheduled K reads of round 1 (kept for tools/attn_ablate.py's A/B)
+#define BYA_ATTN_KPREFETCH 0      // 1 = all K fragment reads of a tile up front, counted waits (tools/attn_ablate.py: +-1 % on the
+                                  // static-bound kernel, -30 % on the running-maximum kernel whose registers are tighter: off)
 #endif
 #ifndef BYA_ATTN_OCC
 #define BYA_ATTN_OCC 4

@@ -76,7 +76,7 @@ constexpr int DEFAULT_MIN_SPLIT_KTILES = 40;
 // nothing else happens.  Same call site as the ordinary epilogue and through one VALU multiply: a second kind of consumer
 // of the asm-owned accumulators (a plain store of them) made hipcc put the store's data tuples into AGPRs too and evict
 // accumulators to scratch right behind their last MFMA, inside the K-loop -- 250 registers of scratch traffic per tile.
-template <int ACT, int JB>
+template <int ACT, int JB, bool SPLIT>
 __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wave, int n_wave, int fr, int fq,
                                               const f32x4 (&acc)[8][8], int wave, int lane, float* raw_out = nullptr) {
     const bool has_res = p.res != nullptr, has_gate = p.gate0 != nullptr, has_bias = p.bias != nullptr;
@@ -133,7 +133,7 @@ __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wa
                 float b8[8], v[8], a0[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) a0[i] = acc[i][j][e];
-                if (raw_out) {
+                if (SPLIT && raw_out) {
                     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)raw_out, 0, (int)GEMM_WS_SLAB_BYTES, 0x00020000);
                     const uint32_t so = (uint32_t)(((wave * 64 + (j * 4 + e) * 2) * 64 + lane) * 16);
                     // the values pass through one VALU multiply by an opaque 1.0: stored as they are, hipcc put the store's
@@ -168,8 +168,13 @@ __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wa
     }
 }
 
-__global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_m, int tiles_n, int batch, int split,
+// SPLIT = false: the instance for launches that will not split a tile (no workspace, short K, or nothing left over): its
+// epilogue has no slab branch -- that branch alone costs the ordinary path 1.5-2.5 % on K = 3072 shapes (same-box A/B,
+// gpurun_out/r2c22) because it cuts the unrolled epilogue into blocks.
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_m, int tiles_n, int batch, int split_arg,
                                                           int min_seg) {
+    const int split = SPLIT ? split_arg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 256, BN = 256, STAGE = (BM + BN) * BK * 2, TILE_A = BM * BK * 2;
     static_assert(STAGE == 65536, "stage flip uses one address bit");
@@ -867,7 +872,7 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         // pieces of its K-tile 1 have; the MFMAs are inline asm, so pad their last results before the epilogue reads them
         asm volatile("s_waitcnt vmcnt(16)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-        if (cur.role == 2) {
+        if (SPLIT && cur.role == 2) {
             // ---- finisher of a split tile: the other K-ranges were started together with this one; wait for their slabs
             if (tid == 0) {
                 while (__hip_atomic_load(p.ws_counters + cur.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
@@ -925,20 +930,20 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
                 }
             }
             auto run = [&](auto act_tag) {
-                epilogue_wide<decltype(act_tag)::value, 2>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc, wave, lane);
+                epilogue_wide<decltype(act_tag)::value, 2, SPLIT>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc, wave, lane);
             };
             dispatch_act_big(p.act, run);
             asm volatile("s_barrier" ::: "memory");          // every wave has read the slabs: the counter can go back to 0
             if (tid == 0) __hip_atomic_store(p.ws_counters + cur.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             // ---- whole tile (ordinary epilogue), or (role 1) a split tile's partial sums -> slab, then drained and counted
-            float* const raw_out = cur.role == 1 ? p.ws_slabs + (size_t)cur.slab * (GEMM_WS_SLAB_BYTES / 4) : nullptr;
+            float* const raw_out = (SPLIT && cur.role == 1) ? p.ws_slabs + (size_t)cur.slab * (GEMM_WS_SLAB_BYTES / 4) : nullptr;
             auto run = [&](auto act_tag) {
-                epilogue_wide<decltype(act_tag)::value, 2>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc, wave, lane,
-                                                           raw_out);
+                epilogue_wide<decltype(act_tag)::value, 2, SPLIT>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc, wave,
+                                                                  lane, raw_out);
             };
             dispatch_act_big(p.act, run);
-            if (cur.role == 1) {
+            if (SPLIT && cur.role == 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");
                 if (tid == 0) {
@@ -978,8 +983,16 @@ int bya_launch_gemm256p(const void* args, int batch, hipStream_t s) {
     const int split = (a.ws_slabs && a.ws_counters && !(sk && sk[0] == '0') && a.K / BK >= 2 * min_seg) ? (sk && sk[0] == '2' ? 2 : 1) : 0;
     int blocks = (int)(total < 256 && !split ? (total + 7) / 8 * 8 : 256);
     const size_t lds = 2 * 512 * BK * 2;
-    static std::atomic<unsigned long long> attr_done{0};
-    if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256p_kernel), (int)lds, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
-    BYA_LAUNCH(gemm256p_kernel, dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, batch, split, min_seg);
+    static std::atomic<unsigned long long> attr_done{0}, attr_done_s{0};
+    // would any XCD have tiles left over after its full rounds?  (only then the split instance is worth its epilogue branch)
+    const bool leftover = split && (total % 256 != 0);
+    if (leftover) {
+        if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256p_kernel<true>), (int)lds, attr_done_s) != BYA_OK) return BYA_ERR_LAUNCH;
+        BYA_LAUNCH(gemm256p_kernel<true>, dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, batch, split, min_seg);
+    } else {
+        if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256p_kernel<false>), (int)lds, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
+        if (total < 256) blocks = (int)((total + 7) / 8 * 8);
+        BYA_LAUNCH(gemm256p_kernel<false>, dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, batch, 0, min_seg);
+    }
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
