@@ -116,6 +116,42 @@ def test_gemm_split_k_last_round(ops, dev, M, N, K, epi, monkeypatch):
     assert torch.equal(run(), first)
 
 
+def test_gemm_split_k_inside_a_replayed_hip_graph(ops, dev):
+    """The split-K hand-off keeps state in the workspace (slabs, counters the finisher puts back to zero): a captured
+    hipGraph that contains a split launch must replay bit-identically, on new input values too, and interleaved with eager
+    launches of another split shape."""
+    M, N, K = 17776, 3072, 12288
+    a, w = rnd((M, K), dev, 41), rnd((N, K), dev, 42, K ** -0.5)
+    a2 = rnd((M, K), dev, 43)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a, w, out)
+    eager1 = out.clone()
+    static_a = a.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.gemm(static_a, w, out)                      # warm-up on a side stream, as torch's capture recipe prescribes
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        ops.gemm(static_a, w, out)
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        assert torch.equal(out, eager1)
+    small_a, small_w = rnd((2222, K), dev, 44), rnd((N, K), dev, 45, K ** -0.5)
+    small_out = torch.empty(2222, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(small_a, small_w, small_out)               # another split shape in between (same counters / slabs)
+    small_ref = small_out.clone()
+    static_a.copy_(a2)
+    g.replay()
+    replay2 = out.clone()
+    ops.gemm(a2, w, out)
+    assert torch.equal(replay2, out)
+    ops.gemm(small_a, small_w, small_out)
+    assert torch.equal(small_out, small_ref)
+
+
 def test_gemm_mfma_layout_asymmetric(ops, dev):
     """A = I against an asymmetric integer-valued W catches swapped row/col maps exactly."""
     K = N = 128
