@@ -170,7 +170,7 @@ __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wa
 
 // SPLIT = false: the instance for launches that will not split a tile (no workspace, short K, or nothing left over): its
 // epilogue has no slab branch -- that branch alone costs the ordinary path 1.5-2.5 % on K = 3072 shapes (same-box A/B,
-// gpurun_out/r2c22) because it cuts the unrolled epilogue into blocks.
+// profiles/r2_gemm_epilogue_variants_same_box.txt) because it cuts the unrolled epilogue into blocks.
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_m, int tiles_n, int batch, int split_arg,
                                                           int min_seg) {
