@@ -1,0 +1,49 @@
+"""The bench.py contract (one JSON line; metric / config of BASELINE.json; roofline and cpu_baseline objects) checked on the
+committed output of the end-of-round run (profiles/r2_v2_bench.json = stdout of ``python bench.py --steps 5 --warmup 2`` on
+an MI355X) and on the script's command line, without a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(path):
+    lines = [l for l in open(path).read().splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, "bench.py prints exactly ONE JSON line"
+    return json.loads(lines[0])
+
+
+def test_committed_bench_line_meets_the_contract():
+    d = _line(os.path.join(ROOT, "profiles", "r2_v2_bench.json"))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    # BASELINE.json: "denoise-steps/sec + latent frames/sec, 49x480x720 bf16, 1/2/4/8 MI355X"
+    assert base["metric"].startswith(d["metric"]) and d["unit"] == "steps/s" and "latent_frames_per_sec" in d
+    for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["layers"] == 42
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["peak"] == 2500.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == d["unit"]
+    # the dominant kernel by time is the one reported as `roofline`
+    km = d["kernel_ms_per_step"]
+    assert max(km, key=km.get) == "bya_gemm_bf16" and "bya_gemm_bf16" in r["kernel"]
+
+
+def test_bench_command_line_parses_without_a_gpu():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
