@@ -6,7 +6,8 @@ q / k / v, with board power and shader clock sampled while each arm loops.
   mask bits: 1 v_exp -> one FMA | 2 no K fragment reads from LDS | 4 half of the V fragment reads | 8 no K/V staging after
              the first tile (no global / LDS-DMA traffic) | 16 no row-sum adds
   schedule variants (same work, must give the same bits): kprefetch = all K fragment reads of a tile up front, occ3 = three
-             waves per SIMD, ring3 = three K/V stages in LDS (staging two tiles ahead) at three blocks per CU
+             waves per SIMD, ring3 = three K/V stages in LDS (staging two tiles ahead) at three blocks per CU, qb2 = two 32-row
+             query blocks per wave sharing every K / V fragment (256 rows per workgroup, two waves per SIMD)
   (An ablation must not let the compiler drop MFMAs: the first version of mask 2 fed both score chains the same operands,
   hipcc merged them, and the "gain" was a quarter of the matrix work missing -- check the instruction counts in the ISA.)
 
@@ -27,7 +28,7 @@ sys.path.insert(0, ROOT)
 MASKS = [0, 1, 16, 17, 2, 4, 6, 8, 14, 31]
 # schedule variants of the SAME work (results must be bit-identical to the product build): name -> extra flags
 VARIANTS = {"kprefetch": ["-DBYA_ATTN_KPREFETCH=1"], "occ3": ["-DBYA_ATTN_OCC=3"],
-            "ring3": ["-DBYA_ATTN_RING=3", "-DBYA_ATTN_OCC=3"]}
+            "ring3": ["-DBYA_ATTN_RING=3", "-DBYA_ATTN_OCC=3"], "qb2": ["-DBYA_ATTN_QB2=1"]}
 S, H, D = 17776, 48, 64
 
 
