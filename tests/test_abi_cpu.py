@@ -97,3 +97,13 @@ def test_product_path_fails_loudly_without_gpu():
         open(os.path.join(ROOT, "bind_your_avatar_implementation_amd", "transformer.py")).read()
     assert "oracle" not in src.replace("oracle's", ""), "the product must never import the oracle"
     assert "F.scaled_dot_product_attention" not in src and "torch.nn.functional" not in src
+
+
+def test_generated_gemm_schedules_match_their_tables():
+    """The hand-placed instruction streams of gemm_v3.hip / gemm_v4.hip are emitted by tools/gen_gemm_v*_schedule.py from
+    placement tables; the committed sources must be exactly what the tables generate."""
+    import subprocess
+    import sys
+    for gen in ("gen_gemm_v4_schedule.py", "gen_gemm_v3_schedule.py"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), "--check"], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr

@@ -18,6 +18,7 @@ block between the GENERATED markers of csrc/gemm_v4.hip.
 """
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATH = os.path.join(ROOT, "bind_your_avatar_implementation_amd", "csrc", "gemm_v4.hip")
@@ -82,6 +83,11 @@ def main():
     new, n = re.subn(r"(// GENERATED-BEGIN[^\n]*\n).*?([ \t]*// GENERATED-END)",
                      lambda m: m.group(1) + emit() + "\n" + m.group(2), src, flags=re.S)
     assert n == 1, "GENERATED markers not found"
+    if "--check" in sys.argv:                       # the committed kernel source must be what the tables generate
+        if new != src:
+            raise SystemExit(f"{PATH}: the GENERATED block is out of date (run this script without --check)")
+        print("up to date", PATH)
+        return
     open(PATH, "w").write(new)
     print("rewrote", PATH)
 
