@@ -875,9 +875,17 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         if (SPLIT && cur.role == 2) {
             // ---- finisher of a split tile: the other K-ranges were started together with this one; wait for their slabs
             if (tid == 0) {
+                // bounded wait (~1 s): a hand-off that never arrives must not hang the GPU; it leaves a mark in the last
+                // counter word instead (tests assert it stays zero) and the tile is finished without the missing sums
+                int spins = 0;
                 while (__hip_atomic_load(p.ws_counters + cur.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-                       (unsigned)(cur.parts - 1))
+                       (unsigned)(cur.parts - 1)) {
                     __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 22)) {
+                        __hip_atomic_store(p.ws_counters + 1023, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
                 if (split == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

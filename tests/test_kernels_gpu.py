@@ -114,6 +114,8 @@ def test_gemm_split_k_last_round(ops, dev, M, N, K, epi, monkeypatch):
     torch.cuda.synchronize()
     assert all(torch.equal(first, o) for o in outs)
     assert torch.equal(run(), first)
+    # the finisher's bounded wait never gave up (it would have left 0xdead in the last counter word of the workspace)
+    assert int(ops._GEMM_WS[4092:4096].view(torch.int32).item()) == 0
 
 
 def test_gemm_split_k_inside_a_replayed_hip_graph(ops, dev):
