@@ -42,7 +42,10 @@ struct AttnArgs {
 #define BYA_ATTN_OCC 4
 #endif
 #ifndef BYA_ATTN_QB2
-#define BYA_ATTN_QB2 0           // 1 = two query blocks per wave for the static-bound kernel (experiment switch)
+#define BYA_ATTN_QB2 1           // two query blocks per wave for the static-bound kernel (0 = the one-block kernel of round 1)
+#endif
+#ifndef BYA_ATTN_QB2_RING3
+#define BYA_ATTN_QB2_RING3 3     // with BYA_ATTN_QB2: 3 or 4 K/V stages and the rendezvous in the middle of the tile (0 = 2 stages)
 #endif
 #ifndef BYA_ATTN_RING
 #define BYA_ATTN_RING 2          // K/V stages in LDS for head_dim 64 (3 = staging two tiles ahead; experiment switch)
@@ -469,9 +472,9 @@ __device__ __forceinline__ void softmax_chunk(const f32x16 (&sacc)[2], int c, bf
 // The tile is software-pipelined INSIDE the wave: the softmax of block A runs between the QK^T MFMAs of block B, the
 // softmax of block B between the PV MFMAs of block A (sched_barrier pins the interleaving; a wave of the one-block kernel
 // leaves the matrix pipe idle during its softmax and relies on the other waves of the SIMD).
-template <bool TAIL>
+template <bool TAIL, typename Mid>
 __device__ __forceinline__ void attn_tile2(const char* kt, const uint32_t (&vbase)[2], const bf16x8 (&qf)[2][4],
-                                           f32x16 (&oacc)[2][2], float (&l_run)[2], int kv_valid, int r, int hf) {
+                                           f32x16 (&oacc)[2][2], float (&l_run)[2], int kv_valid, int r, int hf, Mid&& mid) {
     constexpr int D = 64, ROW_BYTES = D * 2;
     bf16x8 kf[2][4];
 #pragma unroll
@@ -508,6 +511,7 @@ __device__ __forceinline__ void attn_tile2(const char* kt, const uint32_t (&vbas
         __builtin_amdgcn_sched_barrier(0);
     }
     l_run[0] += psum0;
+    mid();                                             // (three-stage ring: the tile's rendezvous + next staging sit here)
     // PV of block A || softmax of block B, then PV of block B, key step by key step (V fragments shared)
     v_issue<D, 1>(fb, vbase);
     lgkm_wait<4>();
@@ -605,7 +609,7 @@ __device__ __forceinline__ void attn_fwd_body2(const AttnArgs& p, char* smem) {
     }
     const int k_tile_stride = KV_TILE * (int)p.k_row * 2, v_tile_stride = KV_TILE * (int)p.v_row * 2;
     auto stage = [&](int t) {
-        char* st = smem + (t & 1) * 2 * TILE_BYTES + wave * 16 * ROW_BYTES;
+        char* st = smem + (BYA_ATTN_QB2_RING3 ? (t % BYA_ATTN_QB2_RING3) : (t & 1)) * 2 * TILE_BYTES + wave * 16 * ROW_BYTES;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_PTR(st + q * 1024), 16, kvo[q], t * k_tile_stride, 0, 0);
@@ -613,7 +617,48 @@ __device__ __forceinline__ void attn_fwd_body2(const AttnArgs& p, char* smem) {
         }
     };
     const int ntiles = (p.Skv + KV_TILE - 1) / KV_TILE, nfull = p.Skv / KV_TILE;
+#if BYA_ATTN_QB2_RING3
+    // Three K/V stages, staging TWO tiles ahead, and the per-tile rendezvous in the MIDDLE of the tile (behind the QK^T
+    // MFMAs, in front of the PV phase): a wave runs from the last PV MFMA of one tile straight into the K fragment reads
+    // of the next -- tile t + 1 landed, for everybody, at tile t's rendezvous.  Tile t + 2 goes into the stage of tile
+    // t - 1, which every wave has left when it reaches tile t's rendezvous.  (Rotating the loop further, so that the K
+    // reads of tile t + 1 are issued in front of the PV phase of tile t, needs more than 256 registers: measured -11 %.)
+    constexpr int NST = BYA_ATTN_QB2_RING3;               // 3 or 4 stages: staging NST - 1 tiles ahead
     stage(0);
+    if (ntiles > 1) stage(1);
+    if (NST == 4 && ntiles > 2) stage(2);
+    // tile 0 has landed once all but the younger requests (4 per tile) are done
+    if (NST == 4 && ntiles > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    int slot = 0;
+    for (int t = 0; t < nfull; ++t) {
+        const char* kt = smem + slot * 2 * TILE_BYTES;
+        uint32_t vbase[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) vbase[d] = lds0 + slot * 2 * TILE_BYTES + TILE_BYTES + voff[d];
+        auto mid = [&]() {
+            // tile t + 1 has landed (with four stages tile t + 2 may still be in flight)
+            if (NST == 4 && t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (t + NST - 1 < ntiles) stage(t + NST - 1);
+        };
+        attn_tile2<false>(kt, vbase, qf, oacc, l_run, KV_TILE, r, hf, mid);
+        slot = slot == NST - 1 ? 0 : slot + 1;
+    }
+    if (nfull < ntiles) {                                  // ragged last tile: landed at the previous tile's rendezvous
+        const char* kt = smem + slot * 2 * TILE_BYTES;
+        uint32_t vbase[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) vbase[d] = lds0 + slot * 2 * TILE_BYTES + TILE_BYTES + voff[d];
+        auto no_mid = []() {};
+        attn_tile2<true>(kt, vbase, qf, oacc, l_run, p.Skv - nfull * KV_TILE, r, hf, no_mid);
+    }
+#else
+    stage(0);
+    auto no_mid = []() {};
     for (int t = 0; t < nfull; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -622,7 +667,7 @@ __device__ __forceinline__ void attn_fwd_body2(const AttnArgs& p, char* smem) {
         uint32_t vbase[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) vbase[d] = lds0 + (t & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
-        attn_tile2<false>(kt, vbase, qf, oacc, l_run, KV_TILE, r, hf);
+        attn_tile2<false>(kt, vbase, qf, oacc, l_run, KV_TILE, r, hf, no_mid);
     }
     if (nfull < ntiles) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -631,8 +676,9 @@ __device__ __forceinline__ void attn_fwd_body2(const AttnArgs& p, char* smem) {
         uint32_t vbase[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) vbase[d] = lds0 + (nfull & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
-        attn_tile2<true>(kt, vbase, qf, oacc, l_run, p.Skv - nfull * KV_TILE, r, hf);
+        attn_tile2<true>(kt, vbase, qf, oacc, l_run, p.Skv - nfull * KV_TILE, r, hf, no_mid);
     }
+#endif
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qb]), __float_as_uint(l_run[qb]), false, false);
@@ -685,7 +731,7 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
         AttnArgs b = a;
         b.nqt = (a.Sq + 255) / 256;                  // 256 query rows per workgroup
         dim3 grid2((nbh * b.nqt + 7) / 8 * 8);
-        BYA_LAUNCH(attn_fwd_kernel_d64_bounded2, grid2, dim3(256), (size_t)4 * KV_TILE * D * 2, s, b);
+        BYA_LAUNCH(attn_fwd_kernel_d64_bounded2, grid2, dim3(256), (size_t)(BYA_ATTN_QB2_RING3 ? 2 * BYA_ATTN_QB2_RING3 : 4) * KV_TILE * D * 2, s, b);
     } else if (D == 64 && a.prescaled && a.score_bound > 0.f) BYA_LAUNCH(attn_fwd_kernel_d64_bounded, grid, dim3(256), lds, s, a);
     else if (D == 64 && a.prescaled) BYA_LAUNCH(attn_fwd_kernel_d64_prescaled, grid, dim3(256), lds, s, a);
     else if (D == 64) BYA_LAUNCH(attn_fwd_kernel_d64, grid, dim3(256), lds, s, a);

@@ -5,9 +5,11 @@ q / k / v, with board power and shader clock sampled while each arm loops.
 
   mask bits: 1 v_exp -> one FMA | 2 no K fragment reads from LDS | 4 half of the V fragment reads | 8 no K/V staging after
              the first tile (no global / LDS-DMA traffic) | 16 no row-sum adds
-  schedule variants (same work, must give the same bits): kprefetch = all K fragment reads of a tile up front, occ3 = three
-             waves per SIMD, ring3 = three K/V stages in LDS (staging two tiles ahead) at three blocks per CU, qb2 = two 32-row
-             query blocks per wave sharing every K / V fragment (256 rows per workgroup, two waves per SIMD)
+  schedule variants (same work, must give the same bits as the product build, mask 0 = two 32-row query blocks per wave
+             sharing every K / V fragment, 256 rows per workgroup, two waves per SIMD, three K/V stages with the per-tile
+             rendezvous behind the QK^T MFMAs): one_block = the kernel of round 1 (32 rows per wave, four waves per SIMD),
+             one_block_kprefetch / _occ3 / _ring3 = its variants (K reads up front, three waves per SIMD, three stages),
+             qb2_ring2 / qb2_ring4 = the product kernel with two / four stages
   (An ablation must not let the compiler drop MFMAs: the first version of mask 2 fed both score chains the same operands,
   hipcc merged them, and the "gain" was a quarter of the matrix work missing -- check the instruction counts in the ISA.)
 
@@ -27,8 +29,11 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 MASKS = [0, 1, 16, 17, 2, 4, 6, 8, 14, 31]
 # schedule variants of the SAME work (results must be bit-identical to the product build): name -> extra flags
-VARIANTS = {"kprefetch": ["-DBYA_ATTN_KPREFETCH=1"], "occ3": ["-DBYA_ATTN_OCC=3"],
-            "ring3": ["-DBYA_ATTN_RING=3", "-DBYA_ATTN_OCC=3"], "qb2": ["-DBYA_ATTN_QB2=1"]}
+ONE = ["-DBYA_ATTN_QB2=0", "-DBYA_ATTN_QB2_RING3=0"]          # the one-query-block kernel (round 1 .. mid round 2)
+VARIANTS = {"one_block": ONE, "one_block_kprefetch": ONE + ["-DBYA_ATTN_KPREFETCH=1"], "one_block_occ3": ONE + ["-DBYA_ATTN_OCC=3"],
+            "one_block_ring3": ONE + ["-DBYA_ATTN_RING=3", "-DBYA_ATTN_OCC=3"],
+            "qb2_ring2": ["-DBYA_ATTN_QB2=1", "-DBYA_ATTN_QB2_RING3=0"],
+            "qb2_ring4": ["-DBYA_ATTN_QB2=1", "-DBYA_ATTN_QB2_RING3=4"]}
 S, H, D = 17776, 48, 64
 
 
