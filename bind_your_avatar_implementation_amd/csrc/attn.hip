@@ -47,6 +47,9 @@ struct AttnArgs {
 #ifndef BYA_ATTN_QB2_RING3
 #define BYA_ATTN_QB2_RING3 3     // with BYA_ATTN_QB2: 3 or 4 K/V stages and the rendezvous in the middle of the tile (0 = 2 stages)
 #endif
+#ifndef BYA_ATTN_QB2_KPF
+#define BYA_ATTN_QB2_KPF 1       // two-block kernel: next tile's K fragments requested right behind the rendezvous
+#endif
 #ifndef BYA_ATTN_RING
 #define BYA_ATTN_RING 2          // K/V stages in LDS for head_dim 64 (3 = staging two tiles ahead; experiment switch)
 #endif
@@ -472,11 +475,9 @@ __device__ __forceinline__ void softmax_chunk(const f32x16 (&sacc)[2], int c, bf
 // The tile is software-pipelined INSIDE the wave: the softmax of block A runs between the QK^T MFMAs of block B, the
 // softmax of block B between the PV MFMAs of block A (sched_barrier pins the interleaving; a wave of the one-block kernel
 // leaves the matrix pipe idle during its softmax and relies on the other waves of the SIMD).
-template <bool TAIL, typename Mid>
-__device__ __forceinline__ void attn_tile2(const char* kt, const uint32_t (&vbase)[2], const bf16x8 (&qf)[2][4],
-                                           f32x16 (&oacc)[2][2], float (&l_run)[2], int kv_valid, int r, int hf, Mid&& mid) {
+// K fragments of a tile: lane (r, hf) holds keys r and r + 32, dims 16 s + 8 hf .. + 7 (A operand of S^T = K.Q^T)
+__device__ __forceinline__ void k_frag_reads(const char* kt, bf16x8 (&kf)[2][4], int r, int hf) {
     constexpr int D = 64, ROW_BYTES = D * 2;
-    bf16x8 kf[2][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int krow = u * 32 + r;
@@ -484,6 +485,16 @@ __device__ __forceinline__ void attn_tile2(const char* kt, const uint32_t (&vbas
         for (int s = 0; s < 4; ++s)
             kf[u][s] = *reinterpret_cast<const bf16x8*>(kt + krow * ROW_BYTES + (((2 * s + hf) ^ kswz<D>(krow)) << 4));
     }
+}
+
+// kf: this tile's K fragments on entry; when PREFETCH, the NEXT tile's on exit (requested right behind the rendezvous,
+// in flight under the whole PV phase: the fragment registers are dead once the QK^T MFMAs have been issued).
+template <bool TAIL, bool PREFETCH, typename Mid>
+__device__ __forceinline__ void attn_tile2(const char* kt, const uint32_t (&vbase)[2], const bf16x8 (&qf)[2][4],
+                                           f32x16 (&oacc)[2][2], float (&l_run)[2], int kv_valid, int r, int hf, Mid&& mid,
+                                           bf16x8 (&kf)[2][4], const char* next_kt) {
+    constexpr int D = 64, ROW_BYTES = D * 2;
+    if (!PREFETCH) k_frag_reads(kt, kf, r, hf);
     f32x16 sacc[2][2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
@@ -512,6 +523,10 @@ __device__ __forceinline__ void attn_tile2(const char* kt, const uint32_t (&vbas
     }
     l_run[0] += psum0;
     mid();                                             // (three-stage ring: the tile's rendezvous + next staging sit here)
+    if (PREFETCH && next_kt) {
+        k_frag_reads(next_kt, kf, r, hf);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // PV of block A || softmax of block B, then PV of block B, key step by key step (V fragments shared)
     v_issue<D, 1>(fb, vbase);
     lgkm_wait<4>();
@@ -633,6 +648,8 @@ __device__ __forceinline__ void attn_fwd_body2(const AttnArgs& p, char* smem) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     int slot = 0;
+    bf16x8 kf[2][4];
+    k_frag_reads(smem, kf, r, hf);                        // tile 0
     for (int t = 0; t < nfull; ++t) {
         const char* kt = smem + slot * 2 * TILE_BYTES;
         uint32_t vbase[2];
@@ -645,8 +662,10 @@ __device__ __forceinline__ void attn_fwd_body2(const AttnArgs& p, char* smem) {
             asm volatile("s_barrier" ::: "memory");
             if (t + NST - 1 < ntiles) stage(t + NST - 1);
         };
-        attn_tile2<false>(kt, vbase, qf, oacc, l_run, KV_TILE, r, hf, mid);
-        slot = slot == NST - 1 ? 0 : slot + 1;
+        const int nslot = slot == NST - 1 ? 0 : slot + 1;
+        attn_tile2<false, BYA_ATTN_QB2_KPF != 0>(kt, vbase, qf, oacc, l_run, KV_TILE, r, hf, mid, kf,
+                                                 t + 1 < ntiles ? smem + nslot * 2 * TILE_BYTES : nullptr);
+        slot = nslot;
     }
     if (nfull < ntiles) {                                  // ragged last tile: landed at the previous tile's rendezvous
         const char* kt = smem + slot * 2 * TILE_BYTES;
@@ -654,11 +673,12 @@ __device__ __forceinline__ void attn_fwd_body2(const AttnArgs& p, char* smem) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) vbase[d] = lds0 + slot * 2 * TILE_BYTES + TILE_BYTES + voff[d];
         auto no_mid = []() {};
-        attn_tile2<true>(kt, vbase, qf, oacc, l_run, p.Skv - nfull * KV_TILE, r, hf, no_mid);
+        attn_tile2<true, BYA_ATTN_QB2_KPF != 0>(kt, vbase, qf, oacc, l_run, p.Skv - nfull * KV_TILE, r, hf, no_mid, kf, nullptr);
     }
 #else
     stage(0);
     auto no_mid = []() {};
+    bf16x8 kf2[2][4];
     for (int t = 0; t < nfull; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -667,7 +687,7 @@ __device__ __forceinline__ void attn_fwd_body2(const AttnArgs& p, char* smem) {
         uint32_t vbase[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) vbase[d] = lds0 + (t & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
-        attn_tile2<false>(kt, vbase, qf, oacc, l_run, KV_TILE, r, hf, no_mid);
+        attn_tile2<false, false>(kt, vbase, qf, oacc, l_run, KV_TILE, r, hf, no_mid, kf2, nullptr);
     }
     if (nfull < ntiles) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -676,7 +696,7 @@ __device__ __forceinline__ void attn_fwd_body2(const AttnArgs& p, char* smem) {
         uint32_t vbase[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) vbase[d] = lds0 + (nfull & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
-        attn_tile2<true>(kt, vbase, qf, oacc, l_run, p.Skv - nfull * KV_TILE, r, hf, no_mid);
+        attn_tile2<true, false>(kt, vbase, qf, oacc, l_run, p.Skv - nfull * KV_TILE, r, hf, no_mid, kf2, nullptr);
     }
 #endif
 #pragma unroll
