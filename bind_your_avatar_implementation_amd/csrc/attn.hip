@@ -48,7 +48,8 @@ struct AttnArgs {
 #define BYA_ATTN_QB2_RING3 3     // with BYA_ATTN_QB2: 3 or 4 K/V stages and the rendezvous in the middle of the tile (0 = 2 stages)
 #endif
 #ifndef BYA_ATTN_QB2_KPF
-#define BYA_ATTN_QB2_KPF 1       // two-block kernel: next tile's K fragments requested right behind the rendezvous
+#define BYA_ATTN_QB2_KPF 0       // 1 = two-block kernel requests the next tile's K fragments right behind the rendezvous
+                                 // (no measurable change once the kernel sits at the power limit: off)
 #endif
 #ifndef BYA_ATTN_RING
 #define BYA_ATTN_RING 2          // K/V stages in LDS for head_dim 64 (3 = staging two tiles ahead; experiment switch)

@@ -9,8 +9,8 @@ q / k / v, with board power and shader clock sampled while each arm loops.
              sharing every K / V fragment, 256 rows per workgroup, two waves per SIMD, three K/V stages with the per-tile
              rendezvous behind the QK^T MFMAs): one_block = the kernel of round 1 (32 rows per wave, four waves per SIMD),
              one_block_kprefetch / _occ3 / _ring3 = its variants (K reads up front, three waves per SIMD, three stages),
-             qb2_ring2 / qb2_ring4 = the product kernel with two / four stages, qb2_no_kprefetch = without the early K fragment
-             requests for the next tile
+             qb2_ring2 / qb2_ring4 = the product kernel with two / four stages, qb2_kprefetch = with the next tile's K fragments
+             requested right behind the rendezvous
   (An ablation must not let the compiler drop MFMAs: the first version of mask 2 fed both score chains the same operands,
   hipcc merged them, and the "gain" was a quarter of the matrix work missing -- check the instruction counts in the ISA.)
 
@@ -34,7 +34,7 @@ ONE = ["-DBYA_ATTN_QB2=0", "-DBYA_ATTN_QB2_RING3=0"]          # the one-query-bl
 VARIANTS = {"one_block": ONE, "one_block_kprefetch": ONE + ["-DBYA_ATTN_KPREFETCH=1"], "one_block_occ3": ONE + ["-DBYA_ATTN_OCC=3"],
             "one_block_ring3": ONE + ["-DBYA_ATTN_RING=3", "-DBYA_ATTN_OCC=3"],
             "qb2_ring2": ["-DBYA_ATTN_QB2=1", "-DBYA_ATTN_QB2_RING3=0"],
-            "qb2_ring4": ["-DBYA_ATTN_QB2=1", "-DBYA_ATTN_QB2_RING3=4"], "qb2_no_kprefetch": ["-DBYA_ATTN_QB2_KPF=0"]}
+            "qb2_ring4": ["-DBYA_ATTN_QB2=1", "-DBYA_ATTN_QB2_RING3=4"], "qb2_kprefetch": ["-DBYA_ATTN_QB2_KPF=1"]}
 S, H, D = 17776, 48, 64
 
 
