@@ -5,8 +5,15 @@
 // the matrix core (measured 390-545 TFLOP/s).  Here a wave keeps its 32 rows of X -- all 512 K -- in 128 VGPRs as MFMA
 // operands (loaded straight from global memory in fragment layout, no LDS), and streams 64-column chunks of W
 // (64 KiB each, one 1-KiB W row per LDS-DMA instruction) through a 2-stage LDS ring shared by the block's 8 waves:
-// 8 LDS-DMA instructions and one barrier per 128 MFMAs of a wave (a first version with 4 waves and 32-column chunks
-// spent as long issuing LDS-DMA as computing: 35 % matrix-core utilisation).
+// 8 LDS-DMA instructions and one barrier per 128 MFMAs of a wave.
+//
+// What bounds it (round-2 ablations, profiles/r2_rowgemm_ablation.txt): every wave reads the whole W chunk from LDS for its
+// own 32 rows, so a chunk costs 8 waves x 64 KiB = 512 KiB of ds_read_b128 = 4096 LDS cycles at 128 B/clk -- exactly the
+// 4096 matrix-core cycles of its 1024 MFMAs: the loop is LDS-read-bound at ~60 % of that rate even with the X loads and
+// output stores compiled out (1180 of 2000 TFLOP/s).  The two build-time alternatives kept below were measured and lost:
+// BYA_ROWGEMM_CH=32 (two independent 4-wave workgroups per CU: same LDS bytes, -7 % on N = 1536, +2 % on N = 512) and
+// BYA_ROWGEMM_HB=4 (64 rows per wave, X in 256 registers, one wave per SIMD: half the LDS bytes, but hipcc's schedule of
+// the single wave loses 17 %; it would need a hand-placed loop like gemm_v4's).
 // The product is computed transposed (W fragment = A operand, X fragment = B operand), so a lane ends up with 16
 // consecutive output columns of one token: 16-byte stores, no LDS transpose.
 //
@@ -19,6 +26,10 @@
 #include "bya_common.h"
 #include "../../include/bya.h"
 
+#ifndef BYA_ROWGEMM_ABLATE
+#define BYA_ROWGEMM_ABLATE 0     // timing-only ablations (tools/): 1 = no X loads, 2 = no output stores
+#endif
+
 namespace {
 
 struct RowGemmArgs {
@@ -28,9 +39,23 @@ struct RowGemmArgs {
 };
 
 constexpr int RK = 512;                   // K
-constexpr int CH = 64;                    // output columns per chunk
-constexpr int STAGE_BYTES = CH * RK * 2;  // 64 KiB
-constexpr int NW = 8;                     // waves per block, 32 rows each
+#ifndef BYA_ROWGEMM_CH
+#define BYA_ROWGEMM_CH 64                 // output columns per chunk (64: one 8-wave workgroup per CU; 32: two 4-wave ones)
+#endif
+constexpr int CH = BYA_ROWGEMM_CH;
+constexpr int NJ = CH / 16;               // 16-column W fragments per chunk
+constexpr int LPC = CH / 4;               // consecutive output columns a lane ends up with
+constexpr int STAGE_BYTES = CH * RK * 2;  // 64 / 32 KiB
+#ifndef BYA_ROWGEMM_HB
+#define BYA_ROWGEMM_HB 2                 // 16-row halves per wave: 2 = 32 rows of X in 128 registers, 4 = 64 rows in 256
+#endif
+constexpr int HB = BYA_ROWGEMM_HB;
+constexpr int NW = CH / (4 * HB);         // waves per workgroup (16*HB rows each)
+constexpr int SR = CH / NW;               // W rows of a chunk every wave stages
+constexpr int RB = 16 * HB * NW;          // rows per workgroup pass
+constexpr int WG_PER_CU = (CH == 64) ? 1 : 2;
+constexpr int AHEAD = CH == 64 ? 1 : 2;   // k-steps of W fragments in flight (a k-step is 2*NJ MFMAs)
+static_assert(CH == 64 || CH == 32, "chunk width");
 
 template <int OFF>
 __device__ __forceinline__ void lds_read_w(bf16x8& dst, uint32_t addr) {
@@ -44,15 +69,21 @@ template <int N>
 __device__ __forceinline__ void lgkm_wait(bf16x8 (&w)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "i"(N));
 }
-// the four W fragments (column blocks j = 0..3) of k-step 4*KH + kl; kl selects the lane-constant address
+template <int N>
+__device__ __forceinline__ void lgkm_wait(bf16x8 (&w)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "i"(N));
+}
+// the NJ W fragments (column blocks j) of k-step 4*KH + kl; kl selects the lane-constant address
 template <int KH>
-__device__ __forceinline__ void read_quad(bf16x8 (&wf)[4], uint32_t addr) {
+__device__ __forceinline__ void read_quad(bf16x8 (&wf)[NJ], uint32_t addr) {
     lds_read_w<0 * 16384 + KH * 256>(wf[0], addr);
     lds_read_w<1 * 16384 + KH * 256>(wf[1], addr);
-    lds_read_w<2 * 16384 + KH * 256>(wf[2], addr);
-    lds_read_w<3 * 16384 + KH * 256>(wf[3], addr);
+    if constexpr (NJ == 4) {
+        lds_read_w<2 * 16384 + KH * 256>(wf[2], addr);
+        lds_read_w<3 * 16384 + KH * 256>(wf[3], addr);
+    }
 }
-__device__ __forceinline__ void read_kstep(bf16x8 (&wf)[4], const uint32_t (&wa)[4], int ks) {
+__device__ __forceinline__ void read_kstep(bf16x8 (&wf)[NJ], const uint32_t (&wa)[4], int ks) {
     switch (ks >> 2) {            // ks is a constant after unrolling: the switch folds away
         case 0: read_quad<0>(wf, wa[ks & 3]); break;
         case 1: read_quad<1>(wf, wa[ks & 3]); break;
@@ -89,14 +120,22 @@ __device__ __forceinline__ float gelu_erf_f(float v) {
 // divide, and a range touches at most two or three row blocks, so the X fragments (and the row statistics) are
 // reloaded only there.  The W-chunk LDS-DMA pipeline runs straight through a row-block change.
 template <bool LN, bool RES, int ACT>
-__global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
+__global__ __launch_bounds__(64 * NW, HB == 4 ? 1 : 2) void rowgemm512_kernel(RowGemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int nrb = (p.M + 32 * NW - 1) / (32 * NW), ncc = p.N / CH;
+    const int nrb = (p.M + RB - 1) / RB, ncc = p.N / CH;
     const long long total = (long long)nrb * ncc;
-    const int q0 = (int)(total * blockIdx.x / gridDim.x), q1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    // work range of this workgroup.  Neighbouring ranges share a row block (a range is about half a row block at N = 1536):
+    // give consecutive ranges to the SAME XCD (blockIdx % 8 under round-robin dispatch) so that the second reader of a row
+    // block's X finds it in that XCD's L2
+#ifndef BYA_ROWGEMM_PLAIN_ORDER
+    const int rid = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+#else
+    const int rid = (int)blockIdx.x;
+#endif
+    const int q0 = (int)(total * rid / gridDim.x), q1 = (int)(total * (rid + 1) / gridDim.x);
     if (q0 >= q1) return;
 
     // LDS: [colsum: N f32][cvec: N f32][ring: 2 x 64 KiB]
@@ -121,13 +160,13 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
     // chunk0 + 16*(i>>2) + 4*j + (i&3), so that lane group g ends up with the 16 consecutive columns chunk0 + 16g ..;
     // its 64 16-byte pieces are XOR-swizzled with i: the 16 rows read by one fragment instruction hit 16 bank groups.
     auto stage_chunk = [&](int q, int stg) {
-        char* dst = ring + stg * STAGE_BYTES + wave * 8 * 1024;
+        char* dst = ring + stg * STAGE_BYTES + wave * SR * 1024;
         const int col0 = (q % ncc) * CH;
         const uint32_t l16 = lane_now() << 4;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int R = wave * 8 + r, i = R & 15, j = R >> 4;        // wave-uniform
-            const uint32_t vo = (l16 ^ (uint32_t)(i << 4)) + (uint32_t)(16 * (i >> 2) + 4 * j + (i & 3)) * (RK * 2);
+        for (int r = 0; r < SR; ++r) {
+            const int R = wave * SR + r, i = R & 15, j = R >> 4;        // wave-uniform
+            const uint32_t vo = (l16 ^ (uint32_t)(i << 4)) + (uint32_t)(LPC * (i >> 2) + 4 * j + (i & 3)) * (RK * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dst + r * 1024), 16, vo, col0 * (RK * 2), 0, 0);
         }
     };
@@ -139,23 +178,29 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
     // Outer loop: the row blocks this workgroup's range touches (two or three); inner loop: their chunks.  The X fragments
     // are read-only inside the inner loop, which has no row-block branch -- with the branch inside, hipcc shuffled and
     // spilled fragments around the MFMA section (every scratch reload drags an s_waitcnt vmcnt(0) with it).
-    bf16x8 xf[2][16];
+    bf16x8 xf[HB][16];
     stage_chunk(q0, 0);
     int q = q0, it = 0;
     while (q < q1) {
         const int rb = q / ncc;
         const int qe = (rb + 1) * ncc < q1 ? (rb + 1) * ncc : q1;
-        const int r0 = rb * (32 * NW) + wave * 32;
-        float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
+        const int r0 = rb * RB + wave * (16 * HB);
+        float mean[HB], rstd[HB];
+#pragma unroll
+        for (int h = 0; h < HB; ++h) mean[h] = 0.f, rstd[h] = 1.f;
         {
             // X fragments: rows r0 + h*16 + t, k = ks*32 + g*8 .. +8 (rows >= M read as zeros through the descriptor)
             const uint32_t ln = lane_now(), to = ln & 15u, go = ln >> 4;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < HB; ++h) {
                 const uint32_t vo = ((uint32_t)(r0 + h * 16) + to) * (uint32_t)(p.ldx * 2) + go * 16;
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks)
+#if BYA_ROWGEMM_ABLATE & 1
+                    { u32x4 t = {vo + ks, vo, ln, 0x3f803f80u}; asm volatile("" : "+v"(t)); xf[h][ks] = __builtin_bit_cast(bf16x8, t); }
+#else
                     xf[h][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, vo + ks * 64, 0, 0));
+#endif
             }
             if (LN) {
                 // row statistics on the matrix core: sum(x) = ones . x^T, sum(x^2) = diag(x . x^T)
@@ -163,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < HB; ++h) {
                     f32x4 sm = {0.f, 0.f, 0.f, 0.f}, gr = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 16; ++ks) {
@@ -187,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
         // chunk's LDS-DMA land in the middle of this chunk's MFMAs instead of by the next barrier.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < HB; ++h)
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(xf[h][ks]));
 
@@ -195,19 +240,19 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
             const int cc = q - rb * ncc, stg = it & 1;
             const uint32_t ln = lane_now(), to = ln & 15u, go = ln >> 4;           // for the addresses of this chunk
             // chunk q has landed (requested one chunk period ago).  vmcnt counts stores too and retires in order: the only
-            // operations younger than chunk q's LDS-DMA are the previous chunk's four output stores, so a counted wait lets
+            // operations younger than chunk q's LDS-DMA are the previous chunk's NJ output stores, so a counted wait lets
             // them drain under this chunk's MFMAs (vmcnt(0) here exposed one store round trip per chunk).
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NJ * HB / 2) : "memory");
             __builtin_amdgcn_s_barrier();                      // ... for every wave; stage stg^1 is free
-            u32x4 rv[2][2];
+            u32x4 rv[HB][NJ / 2];
             if (RES) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < HB; ++h)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
+                    for (int u = 0; u < NJ / 2; ++u)
                         rv[h][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                             rsR, ((uint32_t)(r0 + h * 16) + to) * (uint32_t)(p.ldres * 2) +
-                                     ((uint32_t)(cc * CH + 8 * u) + 16 * go) * 2, 0, 0));
+                                     ((uint32_t)(cc * CH + 8 * u) + LPC * go) * 2, 0, 0));
             }
             if (q + 1 < q1) stage_chunk(q + 1, stg ^ 1);
 
@@ -216,33 +261,36 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
                 wa[m] = ring_base + stg * STAGE_BYTES + to * 1024 + (((go ^ (to & 3)) | ((m ^ (to >> 2)) << 2)) << 4);
-            const uint32_t sc_base = smem_base + go * 64;                      // 16 floats per lane group per chunk
-            f32x4 acc[2][4];
+            const uint32_t sc_base = smem_base + go * (LPC * 4);               // LPC floats per lane group per chunk
+            f32x4 acc[HB][NJ];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < HB; ++h)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bf16x8 wf[2][4];
-            read_kstep(wf[0], wa, 0);
+                for (int j = 0; j < NJ; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 wf[AHEAD + 1][NJ];
+#pragma unroll
+            for (int a = 0; a < AHEAD; ++a) read_kstep(wf[a], wa, a);
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
-                const int cur = ks & 1;
-                if (ks + 1 < 16) {
-                    read_kstep(wf[cur ^ 1], wa, ks + 1);
-                    lgkm_wait<4>(wf[cur]);
+                const int cur = ks % (AHEAD + 1);
+                if (ks + AHEAD < 16) {
+                    read_kstep(wf[(ks + AHEAD) % (AHEAD + 1)], wa, ks + AHEAD);
+                    lgkm_wait<AHEAD * NJ>(wf[cur]);
+                } else if (ks + 1 < 16 && AHEAD == 2) {
+                    lgkm_wait<NJ>(wf[cur]);
                 } else {
                     lgkm_wait<0>(wf[cur]);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < HB; ++h)
                         acc[h][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][j], xf[h][ks], acc[h][j], 0, 0, 0);
             }
 
-            // ---- epilogue: lane (g, t) holds token t's columns chunk0 + 16g + 4j + e
+            // ---- epilogue: lane (g, t) holds token t's columns chunk0 + LPC*g + 4j + e
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {                        // 8 columns at a time: j = 2u, 2u+1
+            for (int u = 0; u < NJ / 2; ++u) {                   // 8 columns at a time: j = 2u, 2u+1
                 f32x4 s0, s1, c0, c1;
                 const uint32_t a = sc_base + (uint32_t)(cc * CH + 8 * u) * 4, ac = a + (uint32_t)p.N * 4;
                 lds_read_f<0>(s0, a);
@@ -251,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
                 lds_read_f<16>(c1, ac);
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0), "+v"(s1), "+v"(c0), "+v"(c1));
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < HB; ++h) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -266,8 +314,11 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
                     u32x4 ov;
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) ov[w2] = pack2bf(v[2 * w2], v[2 * w2 + 1]);
+#if BYA_ROWGEMM_ABLATE & 2
+                    if (ov[0] == 0x12345678u && ov[3] == 0x9abcdef0u)
+#endif
                     __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, ((uint32_t)(r0 + h * 16) + to) * (uint32_t)(p.ldc * 2) +
-                                                                        ((uint32_t)(cc * CH + 8 * u) + 16 * go) * 2, 0, 0);
+                                                                        ((uint32_t)(cc * CH + 8 * u) + LPC * go) * 2, 0, 0);
                 }
             }
         }
@@ -276,8 +327,8 @@ __global__ __launch_bounds__(512, 2) void rowgemm512_kernel(RowGemmArgs p) {
 
 template <bool LN, bool RES, int ACT>
 int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
-    const long long total = (long long)((a.M + 32 * NW - 1) / (32 * NW)) * (a.N / CH);
-    const int blocks = (int)(total < 256 ? total : 256);
+    const long long total = (long long)((a.M + RB - 1) / RB) * (a.N / CH);
+    const int blocks = (int)(total < 256 * WG_PER_CU ? total : 256 * WG_PER_CU);
     const size_t lds = (size_t)a.N * 8 + 2 * STAGE_BYTES;
     static std::atomic<unsigned long long> attr_done{0};
     if (bya_allow_big_lds(reinterpret_cast<const void*>(rowgemm512_kernel<LN, RES, ACT>), 160 * 1024, attr_done) != BYA_OK)
