@@ -107,3 +107,40 @@ def test_generated_gemm_schedules_match_their_tables():
     for gen in ("gen_gemm_v4_schedule.py", "gen_gemm_v3_schedule.py"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), "--check"], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_valu_only_kernels_hold_no_packed_fp32(lib_path):
+    """packed-fp32 VALU arithmetic (v_pk_mul / fma / add / mov) in the VALU-only kernels returned
+    wrong lanes whenever another process kept MFMA workgroups resident; build.py compiles those translation units
+    without the SLP vectoriser.  Guard it on the built device code (and check the disassembly is really read: the
+    router's tiny-attention kernels hold MFMAs, the MFMA GEMM holds both)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from bind_your_avatar_implementation_amd import build
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm llvm binutils not found")
+    packed = re.compile(r"\bv_pk_(mul|fma|add|mov)_(f32|b32)\b")
+
+    def device_asm(src, tmp):
+        obj = os.path.join(build.PKG_DIR, "build", src.replace(".hip", ".o"))
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", obj], check=True, stdin=subprocess.DEVNULL)
+        subprocess.run([tools[1], "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
+                        f"--output={co}", "--unbundle"], check=True, stdin=subprocess.DEVNULL)
+        return subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True,
+                              stdin=subprocess.DEVNULL).stdout
+
+    tmp = tempfile.mkdtemp()
+    try:
+        for src in sorted(build.NO_SLP_SOURCES):
+            asm = device_asm(src, tmp)
+            assert "s_endpgm" in asm, f"{src}: no device code disassembled"
+            hits = packed.findall(asm)
+            assert not hits, f"{src}: {len(hits)} packed-fp32 instructions in a VALU-only translation unit"
+        assert "v_mfma" in device_asm("router.hip", tmp)
+        assert packed.search(device_asm("gemm.hip", tmp))          # the pattern does match where packed ops exist
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
