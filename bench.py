@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="2 = the CFG pair of BASELINE config 3 (not the headline)")
     ap.add_argument("--latent-frames", type=int, default=13, help="25 = the 97-frame clip of BASELINE config 4 (not the headline)")
     ap.add_argument("--identities", type=int, default=2, help="3 = BASELINE config 4's character count (not the headline)")
+    ap.add_argument("--fp8-weights", action="store_true",
+                    help="BASELINE config 5's weight format: e4m3 operands in the DiT Linears (not the headline, which is bf16)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -179,6 +181,8 @@ def main():
     lt, nid = args.latent_frames, args.identities
     kw = dict(MODEL_KW, num_layers=args.layers, sample_height=lh, sample_width=lw, sample_frames=(lt - 1) * 4 + 1)
     model = BindyouravatarTransformer3DModel(**kw, device=dev).init_synthetic(seed=0, fast=True)
+    if args.fp8_weights:
+        model.enable_fp8_weights()
     if world > 1:
         from bind_your_avatar_implementation_amd.parallel import shard_cfg, shard_sequence
         if args.batch == 2:
@@ -230,14 +234,16 @@ def main():
         torch.cuda.synchronize()
         ktimes = ops.collect_kernel_timers()
 
-    headline = (lh, lw, lt, nid) == (60, 90, 13, 2) and args.batch == 1
+    headline = (lh, lw, lt, nid) == (60, 90, 13, 2) and args.batch == 1 and not args.fp8_weights
     if rank == 0:
         sec_per_step = dt / args.steps
         value = 1.0 / sec_per_step
         res = {
             "metric": "denoise-steps/sec", "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "fp8 (e4m3 operands, fp32 accumulate) in the DiT Linears, bf16 elsewhere" if args.fp8_weights else "bf16",
+            "data": "synthetic",
             "latent_frames_per_sec": lt * value,
             "mfma_roofline_frac_whole_step": (TFLOP_PER_STEP * (args.layers / 42) * value / (world * PEAK_BF16_TFLOPS)
                                               if headline else None),
@@ -245,7 +251,8 @@ def main():
                                     "tokens + 226 text), 2 characters (2 ID + 2 audio), batch 1, random-init 8.6B-param "
                                     "architecture") if headline else
                                    (f"NOT the headline config: full transformer.forward, {(lt - 1) * 4 + 1}x{lh * 8}x{lw * 8} "
-                                    f"({lt}x{lh // 2}x{lw // 2} latent tokens + 226 text), {nid} characters, batch {args.batch}"),
+                                    f"({lt}x{lh // 2}x{lw // 2} latent tokens + 226 text), {nid} characters, batch {args.batch}"
+                                    + (", fp8 weights" if args.fp8_weights else "")),
                        "layers": args.layers, "tokens": 226 + lt * (lh // 2) * (lw // 2), "batch": args.batch,
                        "launch": "hipGraph replay" if (args.graph and world == 1) else "eager",
                        "parallelism": "single GPU" if world == 1 else

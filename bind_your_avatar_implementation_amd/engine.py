@@ -73,6 +73,9 @@ class DenoiseEngine:
         # route-then-project (exact by linearity of to_out; halves those GEMMs and drops the [2,N,D] round trip).
         # False = the reference's order of operations (project each identity, then combine).
         self.mix_before_projection = os.environ.get("BYA_MIX_BEFORE_PROJECTION", "1") != "0"
+        # BASELINE configs[4]: the four big Linears of every DiT block on e4m3 operands (per-channel weight scales taken at
+        # pack time, per-row activation scales on the fly; fp32 accumulation, bf16 everywhere else)
+        self.fp8_weights = bool(getattr(model, "_fp8_weights", False)) or os.environ.get("BYA_FP8_WEIGHTS") == "1"
         self._inv_cache = {}
         self._ws_key, self._ws = None, None
         self._parts = {}
@@ -127,6 +130,13 @@ class DenoiseEngine:
                       for b in m.transformer_blocks]
         self.qkv_b = [cat([b.attn1.to_q.bias, b.attn1.to_k.bias, b.attn1.to_v.bias]).contiguous()
                       for b in m.transformer_blocks]
+        self.w8 = None
+        if self.fp8_weights:
+            blocks = m.transformer_blocks
+            self.w8 = {"qkv": [ops.quantize_rows_fp8(w) for w in self.qkv_w],
+                       "out": [ops.quantize_rows_fp8(b.attn1.to_out[0].weight) for b in blocks],
+                       "ff1": [ops.quantize_rows_fp8(b.ff.net[0].proj.weight) for b in blocks],
+                       "ff2": [ops.quantize_rows_fp8(b.ff.net[2].weight) for b in blocks]}
         pe = getattr(m.patch_embed, "pos_embedding", None)
         use_pe = (not self.cfg.use_rotary_positional_embeddings) or self.cfg.use_learned_positional_embeddings
         self.pos_embedding = pe[0] if (pe is not None and use_pe) else None
@@ -184,6 +194,20 @@ class DenoiseEngine:
             t = torch.empty(*shape, dtype=torch.bfloat16, device=self.dev)
             self._ws[name] = t
         return t
+
+    def _dit_linear(self, which, i, a, w, out, **kw):
+        """One of the four big Linears of DiT block ``i`` (models/transformer.py:241-260): the bf16 GEMM, or -- when the
+        engine holds fp8 weights -- row-quantise the activations and run the e4m3 GEMM with the same epilogue."""
+        if self.w8 is None:
+            return ops.gemm(a, w, out, **kw)
+        key = ("a8", tuple(a.shape))
+        hold = self._ws.get(key)
+        if hold is None:
+            hold = self._ws[key] = (torch.empty(*a.shape, dtype=torch.uint8, device=self.dev),
+                                    torch.empty(*a.shape[:-1], dtype=torch.float32, device=self.dev))
+        a8, sa = ops.quantize_rows_fp8(a, q=hold[0], scale=hold[1])
+        w8, sw = self.w8[which][i]
+        return ops.gemm_fp8(a8, sa, w8, sw, out, **kw)
 
     def _linear(self, x, lin_w, lin_b, out, act=None, res=None):
         """x: [(G,) M, K] -> out; weight-streaming kernel for tiny M, MFMA GEMM otherwise."""
@@ -460,7 +484,7 @@ class DenoiseEngine:
                     if head_parallel:
                         # exchange A, head-parallel: the projection writes per-destination column blocks, q/k-norm +
                         # RoPE run on the local rows, then rows are traded for heads (every element moves once)
-                        ops.gemm(xn[0], self.qkv_w[i], qkvb[0], bias=self.qkv_b[i], split=(Dl, S_loc * Dl))
+                        self._dit_linear("qkv", i, xn[0], self.qkv_w[i], qkvb[0], bias=self.qkv_b[i], split=(Dl, S_loc * Dl))
                         # v needs no norm: its exchange runs on the RCCL stream underneath the q/k-norm + RoPE kernel
                         pending = [sh.rows_to_heads(qkvb[2 * W:], vh, async_op=True)]
                         ops.qknorm_rope(qkvb[:W], qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
@@ -475,10 +499,10 @@ class DenoiseEngine:
                         ops.self_attention(qh[None], kh[None], vh[None], oh[None], heads=H // W, tag="joint", prescaled=True,
                                            score_bound=self.score_bound[i])
                         sh.heads_to_rows(oh, xn[0])
-                        ops.gemm(xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
+                        self._dit_linear("out", i, xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
                                  gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                         continue
-                    ops.gemm(xn, self.qkv_w[i], q, bias=self.qkv_b[i], split=(D, B * S_loc * D))
+                    self._dit_linear("qkv", i, xn, self.qkv_w[i], q, bias=self.qkv_b[i], split=(D, B * S_loc * D))
                     ops.qknorm_rope(q, k, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
                                     heads=H, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
                                         k_scale=self.k_scale)
@@ -490,11 +514,11 @@ class DenoiseEngine:
                     else:
                         ops.self_attention(q, k, v, xn, heads=H, tag="joint", prescaled=True,
                                            score_bound=self.score_bound[i])
-                    ops.gemm(xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
+                    self._dit_linear("out", i, xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
                              gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                 else:
-                    ops.gemm(xn, blk.ff.net[0].proj.weight, ff, bias=blk.ff.net[0].proj.bias, act="gelu_tanh")
-                    ops.gemm(ff, blk.ff.net[2].weight, x, bias=blk.ff.net[2].bias, res=x, gate0=mo[:, 5 * D:],
+                    self._dit_linear("ff1", i, xn, blk.ff.net[0].proj.weight, ff, bias=blk.ff.net[0].proj.bias, act="gelu_tanh")
+                    self._dit_linear("ff2", i, ff, blk.ff.net[2].weight, x, bias=blk.ff.net[2].bias, res=x, gate0=mo[:, 5 * D:],
                              gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
             if taps is not None:
                 taps[f"block{i}"] = x.clone()

@@ -169,6 +169,62 @@ def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, g
     return out
 
 
+def quantize_rows_fp8(x, q=None, scale=None):
+    """Per-row symmetric e4m3 quantisation of a bf16 matrix [(B,) M, K] -> (uint8 [.., M, K], fp32 scale [.., M])."""
+    lib = _hip.load()
+    b, M, K, bs, ldx = _mat(x, "x")
+    if b > 1 and bs != M * ldx:
+        raise ValueError("quantize_rows_fp8: batch entries must be evenly stacked rows")
+    if q is None:
+        q = torch.empty(*x.shape, dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty(*x.shape[:-1], dtype=torch.float32, device=x.device)
+    assert q.dtype == torch.uint8 and q.is_contiguous() and scale.dtype == torch.float32 and scale.is_contiguous()
+    assert q.numel() == b * M * K and scale.numel() == b * M
+    tok = _begin("bya_quantize_rows_fp8")
+    check(lib.bya_quantize_rows_fp8(_p(x), _p(q), _p(scale), b * M, K, ldx, K, _stream()), "bya_quantize_rows_fp8")
+    _end(tok)
+    return q, scale
+
+
+def gemm_fp8(a8, a_scale, w8, w_scale, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0,
+             gate_batch_stride=0, act=None, split=None, alpha=1.0):
+    """out = res + gate * act(a_scale * w_scale * (a8 @ w8.T) + bias) with e4m3 operands (``quantize_rows_fp8``)."""
+    lib = _hip.load()
+    if a8.dim() == 2:
+        ab, (M, K) = 1, a8.shape
+    else:
+        ab, M, K = a8.shape
+    ob, Mo, N, c_bs, ldc = _mat(out, "out")
+    if split is not None:
+        N = w8.shape[0]
+    assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.is_contiguous() and w8.is_contiguous()
+    assert w8.shape == (N, K) and (ab, M) == (ob, Mo)
+    assert a_scale.dtype == torch.float32 and a_scale.numel() == ab * M and a_scale.is_contiguous()
+    assert w_scale.dtype == torch.float32 and w_scale.numel() == N and w_scale.is_contiguous()
+    d = GemmDesc()
+    d.M, d.N, d.K, d.batch = M, N, K, ab
+    d.lda, d.ldw, d.ldc = K, K, ldc
+    d.a_batch_stride, d.c_batch_stride = M * K, c_bs
+    d.ldres, d.res_batch_stride = 0, 0
+    if res is not None:
+        rb, Mr, Nr, r_bs, ldres = _mat(res, "res")
+        if (Mr, Nr) != (M, N) or rb not in (1, ab):
+            raise ValueError("res shape mismatch")
+        d.ldres, d.res_batch_stride = ldres, (r_bs if rb == ab else 0)
+    d.gate_batch_stride, d.gate_split, d.act = gate_batch_stride, gate_split, ACT[act]
+    d.n_split, d.c_split_stride = (0, 0) if split is None else split
+    d.bias_rowscale, d.alpha = None, float(alpha)
+    name = "bya_gemm_fp8"
+    if _SHAPE_LABELS:
+        name += f":{ab}x{M}x{N}x{K}:{act or 'none'}{'+gate' if gate0 is not None else ''}{'+res' if res is not None else ''}"
+    tok = _begin(name, 2.0 * ab * M * N * K)
+    check(lib.bya_gemm_fp8(_p(a8), _p(a_scale), _p(w8), _p(w_scale), _p(bias), _p(out), _p(res), _p(gate0), _p(gate1),
+                           ctypes.byref(d), _stream()), "bya_gemm_fp8")
+    _end(tok)
+    return out
+
+
 def linear_small_m(x, w, bias, out, silu_in=False, act_out=None):
     """out[M<=8, N] = f(x) @ w.T + bias (weight-streaming kernel)."""
     lib = _hip.load()
@@ -246,7 +302,10 @@ def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_
         assert t.dtype == torch.bfloat16 and t.is_cuda
     var = ATTN_VARIANT_NAMES.get(lib.bya_attn_variant(ctypes.byref(d)), "rejected")
     ATTN_VARIANTS[tag, var] = ATTN_VARIANTS.get((tag, var), 0) + 1
-    tok = _begin("bya_attn_fwd:" + tag, 4.0 * nb1 * nb2 * heads * Sq * Skv * head_dim)
+    label = "bya_attn_fwd:" + tag
+    if _SHAPE_LABELS:
+        label += f":{nb1}x{nb2}x{heads}h_q{Sq}_kv{Skv}_d{head_dim}"
+    tok = _begin(label, 4.0 * nb1 * nb2 * heads * Sq * Skv * head_dim)
     check(lib.bya_attn_fwd(_p(q), _p(k), _p(v), _p(out), ctypes.byref(d), _stream()), "bya_attn_fwd")
     _end(tok)
     return out

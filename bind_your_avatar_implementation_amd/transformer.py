@@ -363,6 +363,14 @@ class BindyouravatarTransformer3DModel(nn.Module):
         self._pending_lora = []
         return n
 
+    def enable_fp8_weights(self, enabled: bool = True):
+        """BASELINE configs[4]: run attn1.to_q|k|v / to_out and the MLP of every DiT block on OCP e4m3 operands (weights
+        quantised per output channel when the engine packs them, activations per row on the fly; everything else stays
+        bf16).  No reference counterpart (the reference is bf16/fp16 only); returns self."""
+        self._fp8_weights = bool(enabled)
+        self.invalidate_engine()
+        return self
+
     def invalidate_engine(self):
         """Drop packed weights / workspaces / captured graphs (call after changing parameters in place)."""
         self._engine = None

@@ -72,6 +72,26 @@ int bya_set_gemm_workspace(void* ws, int64_t bytes);
 int bya_gemm_workspace_bytes(int64_t* bytes);
 
 /* ---------------------------------------------------------------------------------------------
+ * fp8 weights (BASELINE configs[4]; no reference counterpart: the reference runs bf16/fp16 only).
+ * OCP e4m3fn bytes, symmetric per-row scales:  x[m,k] ~= scale[m] * fp8(q[m,k]).
+ *
+ * bya_quantize_rows_fp8:  scale[m] = max_k |x[m,k]| / 448 (1 for an all-zero row),
+ *                         q[m,k]  = e4m3( x[m,k] * (448 / max_k |x[m,k]|) ), round to nearest even.
+ *   Used once per weight at load time (rows = output channels) and on the fly for the activations of each fp8 GEMM.
+ *   x bf16 [M, K] (row stride ldx), q uint8 [M, K] (row stride ldq), scale fp32 [M].  K % 8 == 0, K <= 12288.
+ *
+ * bya_gemm_fp8:  C[z][m,n] = res + gate * alpha * act( a_scale[z*M+m] * w_scale[n] * sum_k A8[z][m,k] * W8[n,k] + rowscale*bias[n] )
+ *   on v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulation); same descriptor and epilogue as bya_gemm_bf16, with lda / ldw /
+ *   a_batch_stride counted in fp8 elements (bytes).  Replaces attn1.to_q|k|v, attn1.to_out, ff.net.0.proj and ff.net.2 of a
+ *   CogVideoXBlock (models/transformer.py:241-260) when the engine is built with fp8 weights.
+ *   Requirements: K % 128 == 0, N % 4 == 0, lda/ldw % 16 == 0, A8/W8/w_scale 16-byte aligned; act in {NONE, GELU_TANH(_IEEE)}.
+ * --------------------------------------------------------------------------------------------- */
+int bya_quantize_rows_fp8(const void* x, void* q, float* scale, int32_t M, int32_t K, int64_t ldx, int64_t ldq,
+                          hipStream_t stream);
+int bya_gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* bias, void* C,
+                 const void* res, const void* gate0, const void* gate1, const bya_gemm_desc* desc, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Small-M linear (M <= 8 rows):  out[m,n] = sum_k f(x[m,k]) * W[n,k] + bias[n],  f = identity or SiLU.
  * HBM-bound weight stream.  Replaces TimestepEmbedding.linear_1/2, CogVideoXLayerNormZero.linear
  * (models/transformer.py:198,212 -- all 2*num_layers of them in ONE launch over packed weights) and

@@ -1,0 +1,169 @@
+"""fp8 weights (BASELINE configs[4]): the row quantiser and the e4m3 GEMM against CPU restatements on the same operands.
+
+The reference has no fp8 path, so the oracle here is the definition in include/bya.h written out in
+torch on the CPU: symmetric per-row scales amax / 448, OCP e4m3fn with round-to-nearest-even (torch.float8_e4m3fn), exact
+products accumulated in fp32 -- the quantiser is compared BYTE FOR BYTE, the GEMM against the fp64 product of the very
+bytes the GPU multiplied, rounded to bf16 (tolerance 1e-3 relative Frobenius, the bar of every bf16-output kernel)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, seed, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * std).to(torch.bfloat16)
+
+
+def quant_ref(x):
+    """include/bya.h, bya_quantize_rows_fp8, on the CPU."""
+    xf = x.float()
+    amax = xf.abs().amax(dim=-1, keepdim=True)
+    inv = torch.where(amax > 0, 448.0 / amax, torch.zeros_like(amax))
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    q = (xf * inv).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale.squeeze(-1)
+
+
+def dequant(q_u8):
+    return q_u8.view(torch.float8_e4m3fn).double()
+
+
+@pytest.mark.parametrize("M,K", [(300, 3072), (64, 12288), (17, 128), (5, 1000)])
+def test_quantize_rows_matches_the_definition_byte_for_byte(dev, M, K):
+    from bind_your_avatar_implementation_amd import ops
+    x = rnd((M, K), 1, std=3.0)
+    x[1] = 0                                    # an all-zero row: scale 1, zeros
+    x[2, :7] = torch.tensor([448., -448., 1e-3, -0.0, 0.0, 1e4, -3e-5]).to(torch.bfloat16)
+    q, s = ops.quantize_rows_fp8(x.to(dev))
+    q_ref, s_ref = quant_ref(x)
+    assert torch.equal(s.cpu(), s_ref)
+    same = (q.cpu() == q_ref)
+    print(f"{M}x{K}: {int((~same).sum())} of {same.numel()} bytes differ")
+    assert same.all()
+
+
+@pytest.mark.parametrize("M,N,K,kw", [
+    (384, 512, 1024, {}),
+    (300, 260, 256, {"bias": True}),                                  # ragged tiles in both directions
+    (1000, 768, 3072, {"bias": True, "act": "gelu_tanh"}),
+    (777, 1024, 512, {"bias": True, "gate_res": True}),
+    (640, 1536, 1024, {"bias": True, "split": True}),
+])
+def test_gemm_fp8_vs_exact_product_of_the_same_bytes(dev, M, N, K, kw):
+    from bind_your_avatar_implementation_amd import ops
+    a, w = rnd((M, K), 2), rnd((N, K), 3, std=K ** -0.5)
+    bias = rnd((N,), 4) if kw.get("bias") else None
+    a8, sa = ops.quantize_rows_fp8(a.to(dev))
+    w8, sw = ops.quantize_rows_fp8(w.to(dev))
+    ref = (dequant(a8.cpu()) @ dequant(w8.cpu()).T) * sa.cpu().double()[:, None] * sw.cpu().double()[None, :]
+    if bias is not None:
+        ref = ref + bias.double()
+    if kw.get("act") == "gelu_tanh":
+        ref = F.gelu(ref, approximate="tanh")
+    args = {}
+    if kw.get("gate_res"):
+        gate, res = rnd((2, N), 5), rnd((M, N), 6)
+        split_row = 226
+        g = torch.where(torch.arange(M)[:, None] < split_row, gate[0].double()[None], gate[1].double()[None])
+        ref = res.double() + g * ref
+        args = dict(res=res.to(dev), gate0=gate[0].to(dev).contiguous(), gate1=gate[1].to(dev).contiguous(),
+                    gate_split=split_row)
+    if kw.get("split"):
+        out = torch.empty(3, M, N // 3, dtype=torch.bfloat16, device=dev)
+        ops.gemm_fp8(a8, sa, w8, sw, out[0], bias=None if bias is None else bias.to(dev), split=(N // 3, M * (N // 3)))
+        got = out.permute(1, 0, 2).reshape(M, N)
+    else:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm_fp8(a8, sa, w8, sw, out, bias=None if bias is None else bias.to(dev), act=kw.get("act"), **args)
+        got = out
+    err = rel_fro(got.float().cpu(), ref.float().to(torch.bfloat16).float())
+    print(f"{M}x{N}x{K} {kw}: rel-Fro vs bf16(exact) = {err:.3e}")
+    assert err <= 1e-3
+    # and the quantisation itself costs what e4m3 costs: a few percent against the unquantised bf16 product
+    if not kw:
+        full = a.double() @ w.double().T
+        print(f"   vs the unquantised product: {rel_fro(got.float().cpu(), full.float()):.3e}")
+        assert rel_fro(got.float().cpu(), full.float()) < 6e-2
+
+
+# ------------------------------------------------------------------------------------------ forward level
+class FakeQuantLinear(torch.nn.Module):
+    """The definition of bya_gemm_fp8 applied to one nn.Linear of the CPU oracle: e4m3 rows of x, e4m3 rows of W,
+    exact products, fp32 accumulation and scales, then bias -- whatever dtype the oracle is run in."""
+
+    def __init__(self, lin):
+        super().__init__()
+        self.lin = lin
+
+    def forward(self, x):
+        xq, sx = quant_ref(x)
+        wq, sw = quant_ref(self.lin.weight)
+        y = (xq.view(torch.float8_e4m3fn).float() @ wq.view(torch.float8_e4m3fn).float().T) * sx[..., None] * sw
+        if self.lin.bias is not None:
+            y = y + self.lin.bias.float()
+        return y.to(x.dtype)
+
+
+def with_fp8_dit_linears(orc):
+    for blk in orc.transformer_blocks:
+        at = blk.attn1
+        at.to_q, at.to_k, at.to_v = FakeQuantLinear(at.to_q), FakeQuantLinear(at.to_k), FakeQuantLinear(at.to_v)
+        at.to_out[0] = FakeQuantLinear(at.to_out[0])
+        blk.ff.net[0].proj = FakeQuantLinear(blk.ff.net[0].proj)
+        blk.ff.net[2] = FakeQuantLinear(blk.ff.net[2])
+    return orc
+
+
+def test_forward_with_fp8_weights_vs_fake_quantised_oracle(dev):
+    """Small geometry (3 x 8 x 12 video tokens + 226 text rows, full 3072-wide model, 2 layers, 2 identities, CFG batch of
+    2): the engine with fp8 weights against the CPU oracle whose six DiT Linears per block are replaced by the fp8
+    definition above.  Bar, stage by stage, as for the bf16 engine: err(engine, fp32 oracle) <= 1.5 x err(oracle run in
+    bf16, fp32 oracle) + 1e-3 (both carry the same e4m3 operands; what differs is bf16 rounding around them -- which also
+    moves a few e4m3 roundings by one step, on both sides).  The distance to the unquantised model is printed and bounded
+    loosely: that is the price of e4m3, not an implementation property."""
+    from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel
+    from bind_your_avatar_implementation_amd.synth import synth_inputs
+    from oracle.model import OracleTransformer
+    from test_forward_gpu import SMALL_KW, to_dev
+    model = BindyouravatarTransformer3DModel(**SMALL_KW, device=dev).init_synthetic(seed=1, fast=True)
+    sd = {k: v.float().cpu() for k, v in model.state_dict().items()}
+    with torch.device("meta"):
+        orc = OracleTransformer(**SMALL_KW)
+    orc = orc.to_empty(device="cpu")
+    orc.load_state_dict(sd, strict=True)
+    orc.eval()
+    inp = synth_inputs(batch=2, frames=3, height=16, width=24, seed=3, uncond_first=True)
+    gi = to_dev(inp, dev)
+    out_bf16 = model(**gi)[0].float().cpu()
+    taps32, taps16, tapsg = {}, {}, {}
+    with torch.no_grad():
+        plain = orc(**inp)[0]
+        orc = with_fp8_dit_linears(orc)
+        ref = orc(taps=taps32, **inp)[0]
+        orc16 = orc.to(torch.bfloat16)
+        inp16 = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
+        inp16["id_cond"] = [t.to(torch.bfloat16) for t in inp["id_cond"]]
+        inp16["id_vit_hidden"] = [[t.to(torch.bfloat16) for t in l] for l in inp["id_vit_hidden"]]
+        ref16 = orc16(taps=taps16, **inp16)[0]
+    model.enable_fp8_weights()
+    out = model(**gi)[0]
+    assert model._engine.w8 is not None
+    model._engine.step(gi["hidden_states"], gi["encoder_hidden_states"], gi["timestep"], gi["image_rotary_emb"],
+                       gi["id_cond"], gi["id_vit_hidden"], gi["audio_embeds"], gi["af_matrix"], None, taps=tapsg)
+    for name in ["block0", "face0", "audio0", "block1", "audio1"]:
+        g, r32, r16 = tapsg[name].float().cpu(), taps32[name].float(), taps16[name].float()
+        e_g, e_16 = rel_fro(g, r32), rel_fro(r16, r32)
+        print(f"{name:8s} engine(fp8)-vs-fp32(fp8) {e_g:.3e}   bf16(fp8)-oracle-vs-fp32(fp8) {e_16:.3e}")
+        assert e_g <= 1.5 * e_16 + 1e-3, name
+    e_g, e_16 = rel_fro(out, ref), rel_fro(ref16, ref)
+    print(f"output   engine(fp8)-vs-fp32(fp8) {e_g:.3e}   bf16(fp8)-oracle-vs-fp32(fp8) {e_16:.3e}")
+    assert e_g <= 1.5 * e_16 + 1e-3
+    d_model, d_engine = rel_fro(ref, plain), rel_fro(out.float().cpu(), out_bf16)
+    print(f"price of e4m3 on this model: oracle {d_model:.3e}, engine fp8 vs engine bf16 {d_engine:.3e}")
+    assert d_engine < 0.15 and abs(d_engine - d_model) < 0.5 * d_model + 5e-3
+    model.enable_fp8_weights(False)
+    assert torch.equal(model(**gi)[0].float().cpu(), out_bf16)            # and back: bit-identical bf16 engine

@@ -55,7 +55,9 @@ def main():
     print(f"total {tot_ms:.2f} ms/step, {tot_tf / tot_ms * 1e3:.0f} TFLOP/s")
     others = {k: sum(v) / a.steps * 1e3 for k, v in times.items() if not k.startswith("bya_gemm_bf16:")}
     for k, v in sorted(others.items(), key=lambda kv: -kv[1]):
-        print(f"{k:44s}        {v:8.3f} ms")
+        n, fl = len(times[k]) // a.steps, flops.get(k, 0.0)
+        rate = f"{fl / sum(times[k]) / 1e12:7.0f} TFLOP/s" if fl else ""
+        print(f"{k:60s} x{n:4d}  {v:8.3f} ms  {rate}")
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         json.dump(dict(gemm=rows, other_ms_per_step=others), open(a.out, "w"), indent=1)

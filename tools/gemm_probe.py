@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--data", default="gaussian,zeros")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--fp8", action="store_true", help="add the e4m3 GEMM (bya_gemm_fp8), alone and with its row quantiser")
     args = ap.parse_args()
     variants = args.variants.split(",")
     rounds, iters = (1, 3) if args.quick else (args.rounds, 10)
@@ -166,6 +167,19 @@ def main():
                             os.environ["BYA_GEMM_VARIANT"] = v
                             ops.gemm(a, w, out, bias=bias, act="gelu_tanh_ieee")
                         arms[f"bya_{v}_gelu_ieee_div"] = ieee
+            if kw is not None and args.fp8 and K % 128 == 0:
+                a8, sa = ops.quantize_rows_fp8(a)
+                w8, sw = ops.quantize_rows_fp8(w)
+                kw8 = {k: v for k, v in kw.items()}
+
+                def fp8_gemm(kw8=kw8):
+                    ops.gemm_fp8(a8, sa, w8, sw, out, bias=bias, **kw8)
+
+                def fp8_with_quant(kw8=kw8):
+                    ops.quantize_rows_fp8(a, q=a8, scale=sa)
+                    ops.gemm_fp8(a8, sa, w8, sw, out, bias=bias, **kw8)
+                arms["bya_fp8_gemm_only"] = fp8_gemm
+                arms["bya_fp8_quantise+gemm"] = fp8_with_quant
             times = {k: [] for k in arms}
             est = {k: time_once(fn, 2) for k, fn in arms.items()}               # warm-up + rough duration
             smi = {}
