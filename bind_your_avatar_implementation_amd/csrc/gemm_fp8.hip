@@ -133,8 +133,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_fp8_kernel(GemmAr
 }
 
 // ---- row quantiser: one workgroup per row.  scale[m] = max|x[m,:]| / 448 (1 for an all-zero row),
-// q[m,k] = e4m3( x[m,k] * (448 / max|x[m,:]|) ), round-to-nearest-even (v_cvt_pk_fp8_f32).
+// q[m,k] = e4m3( x[m,k] * (448 / max|x[m,:]|) ), round-to-nearest-even (f32_to_e4m3 below).
 constexpr int QT = 256, QV = 6;                 // threads per row, 8-element vectors per thread: K <= 12288
+
+// fp32 -> OCP e4m3fn, round to nearest even, |v| <= 448, in integer arithmetic: byte for byte torch's float8_e4m3fn
+// converter (checked on 2.5 M values incl. the subnormal range and signed zeros), independent of the conversion
+// instruction's mode bits.  ~10 VALU ops per element under an HBM-bound pass: no measurable cost.
+__device__ __forceinline__ uint32_t f32_to_e4m3(float v) {
+    const uint32_t u = __float_as_uint(v), sign = (u >> 24) & 0x80u;
+    uint32_t a = u & 0x7fffffffu;
+    a = a > 0x43e00000u ? 0x43e00000u : a;                       // 448 (a product that rounded just above it)
+    uint32_t r;
+    if (a >= 0x3c800000u) {                                      // >= 2^-6: normal.  3 of 23 mantissa bits, rebias 127 -> 7
+        r = ((a + 0x7ffffu + ((a >> 20) & 1u)) >> 20) - (120u << 3);
+    } else {                                                     // subnormal: multiples of 2^-9; adding 2^14 rounds to them
+        r = __float_as_uint(__uint_as_float(a) + 16384.0f) - 0x46800000u;
+    }
+    return sign | r;
+}
 
 __global__ __launch_bounds__(QT) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ q,
                                                             float* __restrict__ scale, int K, long long ldx, long long ldq) {
@@ -156,8 +172,10 @@ __global__ __launch_bounds__(QT) void quant_rows_fp8_kernel(const bf16_t* __rest
     if ((tid & 63) == 0) red[tid >> 6] = amax;
     __syncthreads();
     amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float inv = amax > 0.f ? FP8_MAX / amax : 0.f;
-    if (tid == 0) scale[row] = amax > 0.f ? amax / FP8_MAX : 1.0f;
+    // 448 / amax correctly rounded to fp32 (NOT 448 * (1 / amax): the two differ in the last bit for one row in three, and
+    // that moves exact ties such as 8.3125 * (448 / 12.25) = 304 to the other e4m3 neighbour -- 0.13 % of the bytes)
+    const float inv = amax > 0.f ? (float)((double)FP8_MAX / (double)amax) : 0.f;
+    if (tid == 0) scale[row] = amax > 0.f ? (float)((double)amax / (double)FP8_MAX) : 1.0f;
     uint8_t* qr = q + (long long)row * ldq;
 #pragma unroll
     for (int i = 0; i < QV; ++i) {
@@ -166,10 +184,9 @@ __global__ __launch_bounds__(QT) void quant_rows_fp8_kernel(const bf16_t* __rest
             u32x2 o;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                int pk = 0;
-                pk = __builtin_amdgcn_cvt_pk_fp8_f32(bflo(v[i][2 * h]) * inv, bfhi(v[i][2 * h]) * inv, pk, false);
-                pk = __builtin_amdgcn_cvt_pk_fp8_f32(bflo(v[i][2 * h + 1]) * inv, bfhi(v[i][2 * h + 1]) * inv, pk, true);
-                o[h] = (uint32_t)pk;
+                const uint32_t w0 = v[i][2 * h], w1 = v[i][2 * h + 1];
+                o[h] = f32_to_e4m3(bflo(w0) * inv) | (f32_to_e4m3(bfhi(w0) * inv) << 8) |
+                       (f32_to_e4m3(bflo(w1) * inv) << 16) | (f32_to_e4m3(bfhi(w1) * inv) << 24);
             }
             *reinterpret_cast<u32x2*>(qr + c * 8) = o;
         }
@@ -222,11 +239,10 @@ extern "C" int bya_gemm_fp8(const void* A8, const float* a_scale, const void* W8
     a.n_split = d->n_split; a.c_split_stride = d->c_split_stride;
     a.bias_rowscale = d->bias_rowscale; a.alpha = d->alpha == 0.0f ? 1.0f : d->alpha;
     a.ws_counters = nullptr; a.ws_slabs = nullptr;
-    // 256 x 256 tiles (8 waves, 128 KiB LDS ring, one workgroup per CU) for the big DiT shapes: half the L2 -> LDS bytes per
-    // FLOP of the 128 x 128 form, which at the e4m3 rate sits at the 64 B/clk/CU fill limit.  BYA_FP8_TILE=128|256 forces one.
+    // Two 128 x 128 workgroups per CU (4 waves, 64 KiB LDS ring each) cover each other's barrier and LDS-DMA waits; a
+    // 256 x 256 form (8 waves, 128 KiB ring, one workgroup per CU, half the L2 -> LDS bytes per FLOP) measured 4-16 %
+    // slower on the four DiT shapes with this simple two-barrier loop (profiles/r2_fp8_probe.txt).  BYA_FP8_TILE=256 forces it.
     const char* tile_env = getenv("BYA_FP8_TILE");
-    const int forced = tile_env ? atoi(tile_env) : 0;
-    if (forced == 256 || (forced != 128 && d->M >= 1024 && d->N >= 1024))
-        return launch_fp8<256, 256, 2, 4>(a, a_scale, w_scale, d->batch, stream);
+    if (tile_env && atoi(tile_env) == 256) return launch_fp8<256, 256, 2, 4>(a, a_scale, w_scale, d->batch, stream);
     return launch_fp8<128, 128, 2, 2>(a, a_scale, w_scale, d->batch, stream);
 }

@@ -76,7 +76,8 @@ int bya_gemm_workspace_bytes(int64_t* bytes);
  * OCP e4m3fn bytes, symmetric per-row scales:  x[m,k] ~= scale[m] * fp8(q[m,k]).
  *
  * bya_quantize_rows_fp8:  scale[m] = max_k |x[m,k]| / 448 (1 for an all-zero row),
- *                         q[m,k]  = e4m3( x[m,k] * (448 / max_k |x[m,k]|) ), round to nearest even.
+ *                         q[m,k]  = e4m3( x[m,k] * inv ),  inv = fp32(448 / max_k |x[m,k]|) correctly rounded, the product
+ *                         in fp32, one round-to-nearest-even to e4m3 (torch.float8_e4m3fn's converter, byte for byte).
  *   Used once per weight at load time (rows = output channels) and on the fly for the activations of each fp8 GEMM.
  *   x bf16 [M, K] (row stride ldx), q uint8 [M, K] (row stride ldq), scale fp32 [M].  K % 8 == 0, K <= 12288.
  *
