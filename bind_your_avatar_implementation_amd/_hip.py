@@ -44,6 +44,8 @@ SIGNATURES = {
     "bya_gemm_workspace_bytes": [_c.POINTER(_i64)],
     "bya_quantize_rows_fp8": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp],
     "bya_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
+    "bya_layernorm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,
+                          _f32, _vp],
     "bya_linear_small_m": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "bya_timestep_features": [_vp, _vp, _i32, _i32, _i32, _f32, _vp],
     "bya_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,

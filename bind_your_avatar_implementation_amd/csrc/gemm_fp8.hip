@@ -133,24 +133,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_fp8_kernel(GemmAr
 }
 
 // ---- row quantiser: one workgroup per row.  scale[m] = max|x[m,:]| / 448 (1 for an all-zero row),
-// q[m,k] = e4m3( x[m,k] * (448 / max|x[m,:]|) ), round-to-nearest-even (f32_to_e4m3 below).
+// q[m,k] = e4m3( x[m,k] * (448 / max|x[m,:]|) ), round-to-nearest-even (f32_to_e4m3, bya_common.h).
 constexpr int QT = 256, QV = 6;                 // threads per row, 8-element vectors per thread: K <= 12288
-
-// fp32 -> OCP e4m3fn, round to nearest even, |v| <= 448, in integer arithmetic: byte for byte torch's float8_e4m3fn
-// converter (checked on 2.5 M values incl. the subnormal range and signed zeros), independent of the conversion
-// instruction's mode bits.  ~10 VALU ops per element under an HBM-bound pass: no measurable cost.
-__device__ __forceinline__ uint32_t f32_to_e4m3(float v) {
-    const uint32_t u = __float_as_uint(v), sign = (u >> 24) & 0x80u;
-    uint32_t a = u & 0x7fffffffu;
-    a = a > 0x43e00000u ? 0x43e00000u : a;                       // 448 (a product that rounded just above it)
-    uint32_t r;
-    if (a >= 0x3c800000u) {                                      // >= 2^-6: normal.  3 of 23 mantissa bits, rebias 127 -> 7
-        r = ((a + 0x7ffffu + ((a >> 20) & 1u)) >> 20) - (120u << 3);
-    } else {                                                     // subnormal: multiples of 2^-9; adding 2^14 rounds to them
-        r = __float_as_uint(__uint_as_float(a) + 16384.0f) - 0x46800000u;
-    }
-    return sign | r;
-}
 
 __global__ __launch_bounds__(QT) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ q,
                                                             float* __restrict__ scale, int K, long long ldx, long long ldq) {

@@ -18,6 +18,9 @@ struct LnArgs {
     long long rows_per_batch, ldx, ldy, x_bs, y_bs, mod_bs, split;
     int batch;
     float eps;
+    // fp8 output (bya_layernorm_fp8): y is then a byte matrix (ldy / y_bs in bytes) and q_scale[z * rows_per_batch + row]
+    // receives the row's scale
+    float* q_scale;
 };
 
 template <int VEC>
@@ -31,7 +34,7 @@ __device__ __forceinline__ void load_vec(const bf16_t* p, float* f) {
 }
 
 // D = 64 * VEC * NV ; each lane owns NV vectors of VEC contiguous elements, vector v at column (v*64 + lane)*VEC
-template <int VEC, int NV>
+template <int VEC, int NV, bool Q8 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     constexpr int D = 64 * VEC * NV;
     const int lane = threadIdx.x & 63;
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     const int z = (int)(row_lin / p.rows_per_batch);
     const long long row = row_lin - (long long)z * p.rows_per_batch;
     const bf16_t* x = p.x + z * p.x_bs + row * p.ldx;
-    bf16_t* y = p.y + z * p.y_bs + row * p.ldy;
+    bf16_t* y = Q8 ? nullptr : p.y + z * p.y_bs + row * p.ldy;
 
     float v[NV][VEC];
     float sum = 0.f;
@@ -86,20 +89,56 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] = o[e] * (1.0f + sc[e]) + sh[e];
         }
-        if constexpr (VEC == 8) {
+        if constexpr (Q8) {
+            // keep the result -- rounded to bf16 exactly as the bf16 kernel would store it -- for the row maximum
+#pragma unroll
+            for (int e = 0; e < VEC; e += 2) {
+                const uint32_t w2 = pack2bf(o[e], o[e + 1]);
+                v[i][e] = bflo(w2);
+                v[i][e + 1] = bfhi(w2);
+            }
+        } else if constexpr (VEC == 8) {
             *reinterpret_cast<u32x4*>(y + col) = pack8(o);
         } else {
             u32x2 w2; w2[0] = pack2bf(o[0], o[1]); w2[1] = pack2bf(o[2], o[3]);
             *reinterpret_cast<u32x2*>(y + col) = w2;
         }
     }
+    if constexpr (Q8) {
+        // bya_quantize_rows_fp8 of the row this wave just normalised (same bytes as LayerNorm -> bf16 -> quantiser)
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        const float inv = amax > 0.f ? (float)(448.0 / (double)amax) : 0.f;
+        if (lane == 0) p.q_scale[z * p.rows_per_batch + row] = amax > 0.f ? (float)((double)amax / 448.0) : 1.0f;
+        uint8_t* q = reinterpret_cast<uint8_t*>(p.y) + z * p.y_bs + row * p.ldy;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * VEC;
+            uint32_t w[VEC / 4];
+#pragma unroll
+            for (int h = 0; h < VEC / 4; ++h)
+                w[h] = f32_to_e4m3(v[i][4 * h] * inv) | (f32_to_e4m3(v[i][4 * h + 1] * inv) << 8) |
+                       (f32_to_e4m3(v[i][4 * h + 2] * inv) << 16) | (f32_to_e4m3(v[i][4 * h + 3] * inv) << 24);
+            if constexpr (VEC == 8) {
+                u32x2 o2; o2[0] = w[0]; o2[1] = w[1];
+                *reinterpret_cast<u32x2*>(q + col) = o2;
+            } else {
+                *reinterpret_cast<uint32_t*>(q + col) = w[0];
+            }
+        }
+    }
 }
 
-template <int VEC, int NV>
+template <int VEC, int NV, bool Q8 = false>
 int launch_ln(const LnArgs& a, hipStream_t s) {
     const long long total = a.rows_per_batch * a.batch;
     dim3 grid((unsigned)((total + 3) / 4));
-    BYA_LAUNCH((layernorm_kernel<VEC, NV>), grid, dim3(256), 0, s, a);
+    BYA_LAUNCH((layernorm_kernel<VEC, NV, Q8>), grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
@@ -217,7 +256,7 @@ extern "C" int bya_layernorm(const void* x, void* y, const void* w, const void* 
     a.shift0 = (const bf16_t*)shift0; a.scale0 = (const bf16_t*)scale0;
     a.shift1 = (const bf16_t*)(shift1 ? shift1 : shift0); a.scale1 = (const bf16_t*)(scale1 ? scale1 : scale0);
     a.rows_per_batch = rows_per_batch; a.ldx = ldx; a.ldy = ldy; a.x_bs = x_batch_stride; a.y_bs = y_batch_stride;
-    a.mod_bs = mod_batch_stride; a.split = split; a.batch = batch; a.eps = eps;
+    a.mod_bs = mod_batch_stride; a.split = split; a.batch = batch; a.eps = eps; a.q_scale = nullptr;
     switch (D) {
         case 512: return launch_ln<8, 1>(a, stream);
         case 768: return launch_ln<4, 3>(a, stream);
@@ -226,6 +265,25 @@ extern "C" int bya_layernorm(const void* x, void* y, const void* w, const void* 
         case 3072: return launch_ln<8, 6>(a, stream);
         default: return BYA_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" int bya_layernorm_fp8(const void* x, void* q, float* q_scale, const void* w, const void* b, const void* shift0,
+                                 const void* scale0, const void* shift1, const void* scale1, int64_t rows_per_batch,
+                                 int32_t batch, int32_t D, int64_t ldx, int64_t ldq, int64_t x_batch_stride,
+                                 int64_t q_batch_stride, int64_t mod_batch_stride, int64_t split, float eps,
+                                 hipStream_t stream) {
+    if (!x || !q || !q_scale || rows_per_batch <= 0 || batch <= 0) return BYA_ERR_SHAPE;
+    if ((shift0 == nullptr) != (scale0 == nullptr)) return BYA_ERR_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)q & 7)) return BYA_ERR_ALIGN;
+    if ((ldx | ldq | x_batch_stride | q_batch_stride) % 8) return BYA_ERR_ALIGN;
+    LnArgs a;
+    a.x = (const bf16_t*)x; a.y = (bf16_t*)q; a.w = (const bf16_t*)w; a.b = (const bf16_t*)b;
+    a.shift0 = (const bf16_t*)shift0; a.scale0 = (const bf16_t*)scale0;
+    a.shift1 = (const bf16_t*)(shift1 ? shift1 : shift0); a.scale1 = (const bf16_t*)(scale1 ? scale1 : scale0);
+    a.rows_per_batch = rows_per_batch; a.ldx = ldx; a.ldy = ldq; a.x_bs = x_batch_stride; a.y_bs = q_batch_stride;
+    a.mod_bs = mod_batch_stride; a.split = split; a.batch = batch; a.eps = eps; a.q_scale = q_scale;
+    if (D != 3072) return BYA_ERR_UNSUPPORTED;          // the DiT width: the only LayerNorm in front of an fp8 Linear
+    return launch_ln<8, 6, true>(a, stream);
 }
 
 extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb, const void* kw, const void* kb,

@@ -76,6 +76,7 @@ class DenoiseEngine:
         # BASELINE configs[4]: the four big Linears of every DiT block on e4m3 operands (per-channel weight scales taken at
         # pack time, per-row activation scales on the fly; fp32 accumulation, bf16 everywhere else)
         self.fp8_weights = bool(getattr(model, "_fp8_weights", False)) or os.environ.get("BYA_FP8_WEIGHTS") == "1"
+        self.fuse_ln_quant = os.environ.get("BYA_FP8_FUSED_LN", "1") != "0"     # AdaLN LayerNorm writes e4m3 directly
         self._inv_cache = {}
         self._ws_key, self._ws = None, None
         self._parts = {}
@@ -195,19 +196,26 @@ class DenoiseEngine:
             self._ws[name] = t
         return t
 
-    def _dit_linear(self, which, i, a, w, out, **kw):
+    def _dit_linear(self, which, i, a, w, out, quantised=None, **kw):
         """One of the four big Linears of DiT block ``i`` (models/transformer.py:241-260): the bf16 GEMM, or -- when the
-        engine holds fp8 weights -- row-quantise the activations and run the e4m3 GEMM with the same epilogue."""
+        engine holds fp8 weights -- row-quantise the activations (unless the producer already did: ``quantised``) and run
+        the e4m3 GEMM with the same epilogue."""
         if self.w8 is None:
             return ops.gemm(a, w, out, **kw)
-        key = ("a8", tuple(a.shape))
+        if quantised is None:
+            quantised = ops.quantize_rows_fp8(a, *self._a8(a.shape))
+        a8, sa = quantised
+        w8, sw = self.w8[which][i]
+        return ops.gemm_fp8(a8.view(*a.shape), sa.view(*a.shape[:-1]), w8, sw, out, **kw)
+
+    def _a8(self, shape):
+        """Workspace for the e4m3 copy of one activation matrix and its row scales."""
+        key = ("a8", tuple(shape))
         hold = self._ws.get(key)
         if hold is None:
-            hold = self._ws[key] = (torch.empty(*a.shape, dtype=torch.uint8, device=self.dev),
-                                    torch.empty(*a.shape[:-1], dtype=torch.float32, device=self.dev))
-        a8, sa = ops.quantize_rows_fp8(a, q=hold[0], scale=hold[1])
-        w8, sw = self.w8[which][i]
-        return ops.gemm_fp8(a8, sa, w8, sw, out, **kw)
+            hold = self._ws[key] = (torch.empty(*shape, dtype=torch.uint8, device=self.dev),
+                                    torch.empty(*shape[:-1], dtype=torch.float32, device=self.dev))
+        return hold
 
     def _linear(self, x, lin_w, lin_b, out, act=None, res=None):
         """x: [(G,) M, K] -> out; weight-streaming kernel for tiny M, MFMA GEMM otherwise."""
@@ -477,14 +485,21 @@ class DenoiseEngine:
             for half, nz in enumerate((blk.norm1, blk.norm2)):
                 mo = mods[:, (2 * i + half) * 6 * D:]
                 # chunk order: shift, scale, gate, enc_shift, enc_scale, enc_gate
-                ops.layernorm(x, xn, nz.norm.weight, nz.norm.bias, eps=nz.norm.eps, shift0=mo[:, 3 * D:],
-                              scale0=mo[:, 4 * D:], shift1=mo, scale1=mo[:, D:], split=Tt_loc, mod_batch_stride=mbs)
+                ln_kw = dict(eps=nz.norm.eps, shift0=mo[:, 3 * D:], scale0=mo[:, 4 * D:], shift1=mo, scale1=mo[:, D:],
+                             split=Tt_loc, mod_batch_stride=mbs)
+                xq = None
+                if self.w8 is not None and self.fuse_ln_quant:
+                    # the AdaLN output feeds exactly one Linear (q|k|v, or the MLP's first): emit it in e4m3 directly
+                    xq = ops.layernorm_fp8(x, *self._a8(xn.shape), nz.norm.weight, nz.norm.bias, **ln_kw)
+                else:
+                    ops.layernorm(x, xn, nz.norm.weight, nz.norm.bias, **ln_kw)
                 if half == 0:
                     at = blk.attn1
                     if head_parallel:
                         # exchange A, head-parallel: the projection writes per-destination column blocks, q/k-norm +
                         # RoPE run on the local rows, then rows are traded for heads (every element moves once)
-                        self._dit_linear("qkv", i, xn[0], self.qkv_w[i], qkvb[0], bias=self.qkv_b[i], split=(Dl, S_loc * Dl))
+                        self._dit_linear("qkv", i, xn[0], self.qkv_w[i], qkvb[0], bias=self.qkv_b[i], split=(Dl, S_loc * Dl),
+                                         quantised=None if xq is None else (xq[0][0], xq[1][0]))
                         # v needs no norm: its exchange runs on the RCCL stream underneath the q/k-norm + RoPE kernel
                         pending = [sh.rows_to_heads(qkvb[2 * W:], vh, async_op=True)]
                         ops.qknorm_rope(qkvb[:W], qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
@@ -502,7 +517,7 @@ class DenoiseEngine:
                         self._dit_linear("out", i, xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
                                  gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                         continue
-                    self._dit_linear("qkv", i, xn, self.qkv_w[i], q, bias=self.qkv_b[i], split=(D, B * S_loc * D))
+                    self._dit_linear("qkv", i, xn, self.qkv_w[i], q, bias=self.qkv_b[i], split=(D, B * S_loc * D), quantised=xq)
                     ops.qknorm_rope(q, k, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
                                     heads=H, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
                                         k_scale=self.k_scale)
@@ -517,7 +532,8 @@ class DenoiseEngine:
                     self._dit_linear("out", i, xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
                              gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                 else:
-                    self._dit_linear("ff1", i, xn, blk.ff.net[0].proj.weight, ff, bias=blk.ff.net[0].proj.bias, act="gelu_tanh")
+                    self._dit_linear("ff1", i, xn, blk.ff.net[0].proj.weight, ff, bias=blk.ff.net[0].proj.bias, act="gelu_tanh",
+                                     quantised=xq)
                     self._dit_linear("ff2", i, ff, blk.ff.net[2].weight, x, bias=blk.ff.net[2].bias, res=x, gate0=mo[:, 5 * D:],
                              gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
             if taps is not None:

@@ -265,6 +265,21 @@ def layernorm(x, out, weight=None, bias=None, eps=1e-5, shift0=None, scale0=None
     return out
 
 
+def layernorm_fp8(x, q, q_scale, weight=None, bias=None, eps=1e-5, shift0=None, scale0=None, shift1=None, scale1=None,
+                  split=0, mod_batch_stride=0):
+    """``layernorm`` + ``quantize_rows_fp8`` of its output in one pass (same bytes, no bf16 round trip)."""
+    lib = _hip.load()
+    xb, rows, D, x_bs, ldx = _mat(x, "x")
+    assert q.dtype == torch.uint8 and q.is_contiguous() and q.numel() == xb * rows * D
+    assert q_scale.dtype == torch.float32 and q_scale.is_contiguous() and q_scale.numel() == xb * rows
+    tok = _begin("bya_layernorm_fp8")
+    check(lib.bya_layernorm_fp8(_p(x), _p(q), _p(q_scale), _p(weight), _p(bias), _p(shift0), _p(scale0), _p(shift1),
+                                _p(scale1), rows, xb, D, ldx, D, x_bs, rows * D, mod_batch_stride, split, float(eps),
+                                _stream()), "bya_layernorm_fp8")
+    _end(tok)
+    return q, q_scale
+
+
 def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6, k_scale=1.0):
     """In place on q, k [B, S, heads*64]."""
     lib = _hip.load()

@@ -91,6 +91,15 @@ int bya_quantize_rows_fp8(const void* x, void* q, float* scale, int32_t M, int32
                           hipStream_t stream);
 int bya_gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* bias, void* C,
                  const void* res, const void* gate0, const void* gate1, const bya_gemm_desc* desc, hipStream_t stream);
+/* bya_layernorm_fp8: bya_layernorm (same arguments, same arithmetic) followed by bya_quantize_rows_fp8 of each output row,
+ * in one pass: the normalised + modulated row is rounded to bf16 exactly as bya_layernorm would store it, then quantised --
+ * byte for byte what the two launches produce, without the bf16 round trip.  q uint8 [batch][rows][D] (row stride ldq,
+ * batch stride q_batch_stride, bytes), q_scale fp32 [batch * rows_per_batch].  D = 3072 only (the AdaLN LayerNorms of
+ * CogVideoXBlock, models/transformer.py:233,251, in front of the q|k|v and MLP Linears). */
+int bya_layernorm_fp8(const void* x, void* q, float* q_scale, const void* w, const void* b, const void* shift0,
+                      const void* scale0, const void* shift1, const void* scale1, int64_t rows_per_batch, int32_t batch,
+                      int32_t D, int64_t ldx, int64_t ldq, int64_t x_batch_stride, int64_t q_batch_stride,
+                      int64_t mod_batch_stride, int64_t split, float eps, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small-M linear (M <= 8 rows):  out[m,n] = sum_k f(x[m,k]) * W[n,k] + bias[n],  f = identity or SiLU.

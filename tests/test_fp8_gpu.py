@@ -170,3 +170,58 @@ def test_forward_with_fp8_weights_vs_fake_quantised_oracle(dev):
     assert d_engine < 0.15 and abs(d_engine - d_model) < 0.5 * d_model + 5e-3
     model.enable_fp8_weights(False)
     assert torch.equal(model(**gi)[0].float().cpu(), out_bf16)            # and back: bit-identical bf16 engine
+
+
+def test_fp8_weights_sequence_parallel_two_ranks_matches_single(dev):
+    """fp8 weights under the sharded engine (row shards, head-parallel exchange): the activation scales are per ROW, so a
+    rank's rows quantise exactly as they do unsharded -- 2 ranks on the one test GPU must reproduce the single-GPU fp8
+    step to the same bar as the bf16 engine's sharded test (the GEMMs see different M, hence tile raggedness, not
+    different arithmetic)."""
+    import os
+    import torch.multiprocessing as mp
+    from test_forward_gpu import _sp_worker
+    os.environ["BYA_FP8_WEIGHTS"] = "1"            # inherited by the spawned ranks: every engine they build holds fp8 weights
+    try:
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(_sp_worker, args=(2, 28100 + os.getpid() % 1000, ret, (16, 24), 2), nprocs=2, join=True)
+    finally:
+        os.environ.pop("BYA_FP8_WEIGHTS", None)
+    print("fp8, sequence-parallel vs single:", dict(ret))
+    for r in (0, 1):
+        assert ret[r][0] <= 2e-2, ret[r]
+
+
+def test_layernorm_fp8_equals_layernorm_then_quantiser(dev):
+    """bya_layernorm_fp8 is bya_layernorm + bya_quantize_rows_fp8 in one pass: same bytes, same scales (AdaLN modulation with
+    the text / video split, a CFG batch of 2, rows that are not a multiple of the 4 rows of a workgroup)."""
+    from bind_your_avatar_implementation_amd import ops
+    B, S, D, split = 2, 1001, 3072, 226
+    x = rnd((B, S, D), 11, std=2.0).to(dev)
+    w, b = rnd((D,), 12).to(dev), rnd((D,), 13, std=0.1).to(dev)
+    mod = rnd((B, 4 * D), 14, std=0.3).to(dev)
+    kw = dict(eps=1e-5, shift0=mod[:, :D], scale0=mod[:, D:], shift1=mod[:, 2 * D:], scale1=mod[:, 3 * D:], split=split,
+              mod_batch_stride=mod.stride(0))
+    y = torch.empty_like(x)
+    ops.layernorm(x, y, w, b, **kw)
+    q_ref, s_ref = ops.quantize_rows_fp8(y)
+    q = torch.empty(B, S, D, dtype=torch.uint8, device=dev)
+    s = torch.empty(B, S, dtype=torch.float32, device=dev)
+    ops.layernorm_fp8(x, q, s, w, b, **kw)
+    assert torch.equal(s, s_ref)
+    assert torch.equal(q, q_ref)
+
+
+def test_fused_and_unfused_fp8_engine_are_bit_identical(dev, monkeypatch):
+    from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel
+    from bind_your_avatar_implementation_amd.synth import synth_inputs
+    from test_forward_gpu import SMALL_KW, to_dev
+    model = BindyouravatarTransformer3DModel(**SMALL_KW, device=dev).init_synthetic(seed=1, fast=True).enable_fp8_weights()
+    gi = to_dev(synth_inputs(batch=2, frames=3, height=16, width=24, seed=3, uncond_first=True), dev)
+    fused = model(**gi)[0].clone()
+    assert model._engine.fuse_ln_quant
+    monkeypatch.setenv("BYA_FP8_FUSED_LN", "0")
+    model.invalidate_engine()
+    plain = model(**gi)[0]
+    assert not model._engine.fuse_ln_quant
+    assert torch.equal(fused, plain)
