@@ -138,6 +138,11 @@ class DenoiseEngine:
                        "out": [ops.quantize_rows_fp8(b.attn1.to_out[0].weight) for b in blocks],
                        "ff1": [ops.quantize_rows_fp8(b.ff.net[0].proj.weight) for b in blocks],
                        "ff2": [ops.quantize_rows_fp8(b.ff.net[2].weight) for b in blocks]}
+            # ... and the two 3072-wide query projections that sit directly behind a LayerNorm of the video rows
+            if m.is_train_face:
+                self.w8["pq"] = [ops.quantize_rows_fp8(pc.to_q.weight) for pc in m.perceiver_cross_attention]
+            if m.is_train_audio:
+                self.w8["aq"] = [ops.quantize_rows_fp8(al["attn"].to_q.weight) for al in m.audio_model.layers]
         pe = getattr(m.patch_embed, "pos_embedding", None)
         use_pe = (not self.cfg.use_rotary_positional_embeddings) or self.cfg.use_learned_positional_embeddings
         self.pos_embedding = pe[0] if (pe is not None and use_pe) else None
@@ -200,13 +205,22 @@ class DenoiseEngine:
         """One of the four big Linears of DiT block ``i`` (models/transformer.py:241-260): the bf16 GEMM, or -- when the
         engine holds fp8 weights -- row-quantise the activations (unless the producer already did: ``quantised``) and run
         the e4m3 GEMM with the same epilogue."""
-        if self.w8 is None:
+        if self.w8 is None or which not in self.w8:
             return ops.gemm(a, w, out, **kw)
         if quantised is None:
             quantised = ops.quantize_rows_fp8(a, *self._a8(a.shape))
         a8, sa = quantised
         w8, sw = self.w8[which][i]
         return ops.gemm_fp8(a8.view(*a.shape), sa.view(*a.shape[:-1]), w8, sw, out, **kw)
+
+    def _ln_linear(self, which, i, x, xn, norm, w, out, **kw):
+        """LayerNorm(x) -> Linear for the perceiver / audio query projections (models/router.py:246-253,
+        models/audio_model.py:247-253): two launches in bf16; with fp8 weights the LayerNorm emits e4m3 directly."""
+        if self.w8 is not None and which in self.w8 and self.fuse_ln_quant:
+            xq = ops.layernorm_fp8(x, *self._a8(xn.shape), norm.weight, norm.bias, eps=norm.eps)
+            return self._dit_linear(which, i, xn, w, out, quantised=xq, **kw)
+        ops.layernorm(x, xn, norm.weight, norm.bias, eps=norm.eps)
+        return self._dit_linear(which, i, xn, w, out, **kw)
 
     def _a8(self, shape):
         """Workspace for the e4m3 copy of one activation matrix and its row scales."""
@@ -546,8 +560,7 @@ class DenoiseEngine:
                 inner_p = pc.to_q.weight.shape[0]
                 hd_p = inner_p // 16
                 lat = buf("lat", B, N_loc, D)
-                ops.layernorm(xv, lat, pc.norm2.weight, pc.norm2.bias, eps=pc.norm2.eps)
-                qp = ops.gemm(lat, pc.to_q.weight, buf("qp", B, N_loc, inner_p))
+                qp = self._ln_linear("pq", ca, xv, lat, pc.norm2, pc.to_q.weight, buf("qp", B, N_loc, inner_p))
                 kv_l = face_kv[ca]
                 ntok = kv_l.shape[2]
                 pout = buf("pout", B, n_id, N_loc, inner_p)
@@ -578,8 +591,8 @@ class DenoiseEngine:
                 al = m.audio_model.layers[i // m.audio_attn_interval]
                 at = al["attn"]
                 an = buf("lat", B, N_loc, D)
-                ops.layernorm(xv, an, al["norm_q"].weight, al["norm_q"].bias, eps=al["norm_q"].eps)
-                qa = ops.gemm(an, at.to_q.weight, buf("qa", B, N_loc, D), bias=at.to_q.bias)
+                qa = self._ln_linear("aq", i // m.audio_attn_interval, xv, an, al["norm_q"], at.to_q.weight,
+                                     buf("qa", B, N_loc, D), bias=at.to_q.bias)
                 ka, va = audio_k[i // m.audio_attn_interval], audio_v[i // m.audio_attn_interval]
                 ntok = ka.shape[3]
                 ao = buf("ao", B, n_id, N_loc, D)

@@ -118,13 +118,17 @@ def with_fp8_dit_linears(orc):
         at.to_out[0] = FakeQuantLinear(at.to_out[0])
         blk.ff.net[0].proj = FakeQuantLinear(blk.ff.net[0].proj)
         blk.ff.net[2] = FakeQuantLinear(blk.ff.net[2])
+    for pc in orc.perceiver_cross_attention:                 # the query projections behind a LayerNorm of the video rows
+        pc.to_q = FakeQuantLinear(pc.to_q)
+    for layer in orc.audio_model.layers:
+        layer["attn"].to_q = FakeQuantLinear(layer["attn"].to_q)
     return orc
 
 
 def test_forward_with_fp8_weights_vs_fake_quantised_oracle(dev):
     """Small geometry (3 x 8 x 12 video tokens + 226 text rows, full 3072-wide model, 2 layers, 2 identities, CFG batch of
-    2): the engine with fp8 weights against the CPU oracle whose six DiT Linears per block are replaced by the fp8
-    definition above.  Bar, stage by stage, as for the bf16 engine: err(engine, fp32 oracle) <= 1.5 x err(oracle run in
+    2): the engine with fp8 weights against the CPU oracle whose six DiT Linears per block (and the perceiver / audio query projections) are replaced by
+    the fp8 definition above.  Bar, stage by stage, as for the bf16 engine: err(engine, fp32 oracle) <= 1.5 x err(oracle run in
     bf16, fp32 oracle) + 1e-3 (both carry the same e4m3 operands; what differs is bf16 rounding around them -- which also
     moves a few e4m3 roundings by one step, on both sides).  The distance to the unquantised model is printed and bounded
     loosely: that is the price of e4m3, not an implementation property."""
