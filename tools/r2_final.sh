@@ -6,7 +6,7 @@ O=$R/gpurun_out/r2final5
 mkdir -p $O
 timeout 3000 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timers > $O/prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-fp8-variant > $O/prof.log 2>&1
 cd $R
 find $O/prof -name "*kernel_stats.csv" | head -2
 find $O/prof -name "*.csv" ! -name "*kernel_stats.csv" -size +2M -delete
