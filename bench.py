@@ -314,6 +314,19 @@ def main():
                 res["fp8_weights_variant"] = {"value": 1.0 / sec8, "unit": "steps/s", "ms_per_step": sec8 * 1e3, "steps": 3,
                                               "dtype": "fp8 (e4m3 operands, fp32 accumulate) in the DiT Linears, bf16 elsewhere",
                                               "note": "not the headline metric (which is bf16); parity: tests/test_fp8_gpu.py"}
+                if not args.no_kernel_timers:
+                    ops.enable_kernel_timers()
+                    step()
+                    torch.cuda.synchronize()
+                    fl8, kt8 = ops.kernel_timer_flops().get("bya_gemm_fp8", 0.0), ops.collect_kernel_timers()
+                    t8 = sum(kt8.get("bya_gemm_fp8", []))
+                    if t8 > 0:
+                        res["fp8_weights_variant"]["gemm_fp8_roofline"] = {
+                            "kernel": "bya_gemm_fp8 (gemm_fp8_kernel<128,128>: v_mfma_scale_f32_16x16x128_f8f6f4, e4m3)",
+                            "bound": "mfma", "achieved": fl8 / t8 / 1e12, "peak": 5000.0, "unit": "TFLOP/s",
+                            "frac": fl8 / t8 / 1e12 / 5000.0, "launches": len(kt8["bya_gemm_fp8"]), "ms_per_step": t8 * 1e3,
+                            "quantiser_ms_per_step": (sum(kt8.get("bya_quantize_rows_fp8", [])) +
+                                                      sum(kt8.get("bya_layernorm_fp8", []))) * 1e3}
             except Exception as e:                        # noqa: BLE001  (an extra, never a reason to lose the headline line)
                 res["fp8_weights_variant"] = {"error": str(e)[:200]}
             finally:

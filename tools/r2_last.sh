@@ -1,2 +1,12 @@
+# last call of the round: the default bench line at HEAD (with its fp8-weights variant object), wall-clocked
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests/test_fp8_gpu.py -q -s -k "depth" 2>&1 | grep -E "block|output|passed|failed|Error|error" | head -20
+O=gpurun_out/r2last2
+mkdir -p $O
+T0=$(date +%s)
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$? wall=$(( $(date +%s) - T0 )) s"
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r2last2/bench_default.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['steps'], d['warmup'], d['roofline']['frac'], d['attn_roofline']['frac'])
+print(d.get('fp8_weights_variant')); print(d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
+PY
