@@ -1,5 +1,5 @@
-# last call of the round: the whole GPU suite at HEAD
+# last call of the round: the whole GPU suite at HEAD, with the slowest tests listed
 export TMPDIR=/tmp
 O=gpurun_out/r2last3
 mkdir -p $O
-timeout 3000 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+timeout 3000 python -m pytest tests -m gpu -q --durations=15 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -24 $O/pytest_gpu.log
