@@ -1,4 +1,5 @@
+# last call of the round: the whole GPU suite at HEAD, with the slowest tests listed
 export TMPDIR=/tmp
-O=gpurun_out/r2last3
+O=gpurun_out/r2last4
 mkdir -p $O
-timeout 1500 python -m pytest tests/test_forward_gpu.py -q -s -k "depth_42" > $O/pytest_depth.log 2>&1; echo "pytest rc=$?"; grep -E "fp8-engine|passed|failed" $O/pytest_depth.log | tail -12
+timeout 3000 python -m pytest tests -m gpu -q --durations=8 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -14 $O/pytest_gpu.log
