@@ -1,5 +1,11 @@
-# last call of the round: the whole GPU suite at HEAD, with the slowest tests listed
+# rocprofv3 kernel stats of the fp8-weights step (evidence for bya_gemm_fp8 / the quantiser kernels)
 export TMPDIR=/tmp
-O=gpurun_out/r2last4
+R=$PWD
+O=$R/gpurun_out/r2fp8prof
 mkdir -p $O
-timeout 3000 python -m pytest tests -m gpu -q --durations=8 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -14 $O/pytest_gpu.log
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof --output-format csv -- python3 $R/bench.py --fp8-weights --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timers > $O/prof.log 2>&1
+cd $R
+K=$(find $O/prof -name "*kernel_stats.csv" | head -1); echo $K; head -12 $K | cut -c1-170
+find $O/prof -name "*.csv" ! -name "*kernel_stats.csv" -size +2M -delete
+tail -c 300 $O/prof.log
