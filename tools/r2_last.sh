@@ -1,11 +1,10 @@
-# rocprofv3 kernel stats of the fp8-weights step (evidence for bya_gemm_fp8 / the quantiser kernels)
+# PMC traffic of the fp8-weights step (two separate passes, as tools/run_pmc.sh)
+TAG=r2_fp8
 export TMPDIR=/tmp
 R=$PWD
-O=$R/gpurun_out/r2fp8prof
-mkdir -p $O
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof --output-format csv -- python3 $R/bench.py --fp8-weights --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timers > $O/prof.log 2>&1
+timeout 700 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch_$TAG --output-format csv -- python3 $R/bench.py --fp8-weights --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers > $R/gpurun_out/pmc_fetch_$TAG.log 2>&1
+timeout 700 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write_$TAG --output-format csv -- python3 $R/bench.py --fp8-weights --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers > $R/gpurun_out/pmc_write_$TAG.log 2>&1
 cd $R
-K=$(find $O/prof -name "*kernel_stats.csv" | head -1); echo $K; head -12 $K | cut -c1-170
-find $O/prof -name "*.csv" ! -name "*kernel_stats.csv" -size +2M -delete
-tail -c 300 $O/prof.log
+python tools/pmc_aggregate.py gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/${TAG}_pmc_traffic.json | grep -E "gemm_fp8|quant_rows|layernorm_kernel<8, 6, true>|gemm256p"
+find gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG -name "*.csv" -size +2M -delete
