@@ -11,6 +11,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK8 = 128;          // fp8 elements (= bytes) per K-tile
+constexpr int FP8_GROUP_M = 8;    // row-tiles per group of the tile order (BYA_FP8_GM overrides per call)
 constexpr float FP8_MAX = 448.0f; // largest finite e4m3fn
 
 template <int ROWS, int NWAVES>
@@ -40,7 +41,7 @@ __device__ __forceinline__ i32x8 lds_frag8(const char* tile, int row, int g) {
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_fp8_kernel(GemmArgs p, const float* __restrict__ sa,
-                                                                          const float* __restrict__ sw) {
+                                                                          const float* __restrict__ sw, int GM) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int TILE_A = BM * BK8, TILE_W = BN * BK8, STAGE = TILE_A + TILE_W;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_fp8_kernel(GemmAr
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int nwg = tiles_m * tiles_n;
     const int id = xcd_remap(blockIdx.x, nwg);
-    constexpr int GM = 8;                                   // group-M order, as in gemm_bf16_kernel
+    // group-M order: GM row-tiles sweep one column-tile before moving on (W panels are re-read once per group of rows)
     const int per_group = GM * tiles_n;
     const int group = id / per_group, first_m = group * GM;
     const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
@@ -131,7 +132,10 @@ int launch_fp8(const GemmArgs& a, const float* sa, const float* sw, int batch, h
     static std::atomic<unsigned long long> attr_done{0};
     if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm_fp8_kernel<BM, BN, WAVES_M, WAVES_N>), (int)lds, attr_done) != BYA_OK)
         return BYA_ERR_LAUNCH;
-    BYA_LAUNCH((gemm_fp8_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(64 * WAVES_M * WAVES_N), lds, s, a, sa, sw);
+    const char* gm_env = getenv("BYA_FP8_GM");              // A/B switch, read per call
+    int gm = gm_env ? atoi(gm_env) : FP8_GROUP_M;
+    gm = gm < 1 ? 1 : gm;
+    BYA_LAUNCH((gemm_fp8_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(64 * WAVES_M * WAVES_N), lds, s, a, sa, sw, gm);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
