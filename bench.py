@@ -141,6 +141,20 @@ def pmc_traffic(world, *kernels):
     return None
 
 
+def self_launch(n):
+    """One rank per GPU through ``python -m torch.distributed.run`` (the command shape the driver itself uses), rendezvous
+    on 127.0.0.1 and a free port; every argument of this invocation is passed on.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,15 +172,32 @@ def main():
     ap.add_argument("--latent-frames", type=int, default=13, help="25 = the 97-frame clip of BASELINE config 4 (not the headline)")
     ap.add_argument("--identities", type=int, default=2, help="3 = BASELINE config 4's character count (not the headline)")
     ap.add_argument("--no-fp8-variant", action="store_true", help="skip the extra fp8-weights measurement beside the headline")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only prove that the N ranks start and meet (gloo all-reduce, no GPU): CPU test of the self-launch")
     ap.add_argument("--fp8-weights", action="store_true",
                     help="BASELINE config 5's weight format: e4m3 operands in the DiT Linears (not the headline, which is bf16)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process (this process has
+        # not touched the GPU yet and never will: it only relays the child's output and exit code).
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    if args.launch_check:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": world, "rank_sum": t.item()}), flush=True)
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -234,6 +265,7 @@ def main():
             step()
         torch.cuda.synchronize()
         ktimes = ops.collect_kernel_timers()
+    ops.check_gemm_workspace()        # no split-K hand-off of the run timed out (raises otherwise: the numbers would be void)
 
     headline = (lh, lw, lt, nid) == (60, 90, 13, 2) and args.batch == 1 and not args.fp8_weights
     if rank == 0:

@@ -42,6 +42,7 @@ SIGNATURES = {
     "bya_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
     "bya_set_gemm_workspace": [_vp, _i64],
     "bya_gemm_workspace_bytes": [_c.POINTER(_i64)],
+    "bya_gemm_workspace_status": [_c.POINTER(_i32), _vp],
     "bya_quantize_rows_fp8": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp],
     "bya_gemm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
     "bya_layernorm_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,

@@ -11,9 +11,16 @@
 #include "bya_common.h"
 #include "../../include/bya.h"
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 namespace {
+
+// The handful of RCCL declarations the two wrappers need, restated here so that the library builds on a box without
+// the RCCL headers (values are ABI constants of NCCL >= 2.10 / RCCL, rccl.h: ncclSuccess = 0, ncclBfloat16 = 9).
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclBfloat16 = 9;
 
 struct Rccl {
     ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -70,13 +77,14 @@ extern "C" int bya_alltoall_router(const void* send, void* recv, const int64_t* 
     ncclComm_t c = static_cast<ncclComm_t>(comm);
     int n = 0;
     if (r.comm_count(c, &n) != ncclSuccess || n != world) return BYA_ERR_SHAPE;
+    for (int peer = 0; peer < world; ++peer)                     // validated BEFORE the group opens: nothing half-issued
+        if (send_counts[peer] < 0 || recv_counts[peer] < 0) return BYA_ERR_SHAPE;
     const bf16_t* s = static_cast<const bf16_t*>(send);
     bf16_t* d = static_cast<bf16_t*>(recv);
     if (r.group_start() != ncclSuccess) return BYA_ERR_LAUNCH;
     bool good = true;
     int64_t so = 0, ro = 0;
     for (int peer = 0; peer < world; ++peer) {                   // element ranges are the prefix sums of the counts
-        if (send_counts[peer] < 0 || recv_counts[peer] < 0) { good = false; break; }
         if (send_counts[peer]) good &= r.send(s + so, (size_t)send_counts[peer], ncclBfloat16, peer, c, stream) == ncclSuccess;
         if (recv_counts[peer]) good &= r.recv(d + ro, (size_t)recv_counts[peer], ncclBfloat16, peer, c, stream) == ncclSuccess;
         so += send_counts[peer];

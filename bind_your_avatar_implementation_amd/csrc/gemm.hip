@@ -316,11 +316,9 @@ int launch256(const GemmArgs& a, int batch, hipStream_t s) {
     // Kernel choice for the 256x256 tile shapes.  Default: the persistent one-wave-per-SIMD kernel (gemm_v4.hip) whenever
     // its 16-byte epilogue accesses are aligned and K has at least three K-tiles, else the 8-wave kernel below.
     // BYA_GEMM_VARIANT (read per call so one process can A/B them, tools/gemm_probe.py): "w8" = this file's 8-wave
-    // kernel, "w4" = gemm_w4.hip, "v3" = gemm_v3.hip, "v4" = gemm_v4.hip.
+    // kernel (the fallback), anything else = gemm_v4.hip.
     const char* variant = getenv("BYA_GEMM_VARIANT");
     const bool v4_ok = v4_eligible(a);
-    if (variant && variant[0] == 'w' && variant[1] == '4') return bya_launch_gemm256w4(&a, batch, s);
-    if (variant && variant[0] == 'v' && variant[1] == '3') return bya_launch_gemm256v3(&a, batch, s);
     if (v4_ok && !(variant && variant[0] == 'w' && variant[1] == '8')) return bya_launch_gemm256p(&a, batch, s);
     BYA_LAUNCH(gemm256_kernel, grid, dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
@@ -361,12 +359,34 @@ inline int pick_tile(int M, int N, int K, int batch, int forced, int act, bool s
 }  // namespace
 
 namespace {
-std::atomic<void*> g_gemm_ws{nullptr};          // split-K workspace of the persistent kernel (gemm_v4.hip), caller-owned
+// split-K workspaces of the persistent kernel (gemm_v4.hip), caller-owned, one per DEVICE: a launch uses the workspace
+// registered for the device that is current when it is enqueued (a slab or counter on another GPU would be a memory fault)
+constexpr int MAX_DEVICES = 64;
+std::atomic<void*> g_gemm_ws[MAX_DEVICES];
+inline int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES ? dev : -1;
+}
 }  // namespace
 
 extern "C" int bya_set_gemm_workspace(void* ws, int64_t bytes) {
     if (ws && (bytes < (int64_t)GEMM_WS_BYTES || ((uintptr_t)ws & 255))) return BYA_ERR_SHAPE;
-    g_gemm_ws.store(ws);
+    const int dev = current_device();
+    if (dev < 0) return BYA_ERR_UNSUPPORTED;
+    g_gemm_ws[dev].store(ws);
+    return BYA_OK;
+}
+
+extern "C" int bya_gemm_workspace_status(int32_t* timeouts, hipStream_t stream) {
+    if (!timeouts) return BYA_ERR_SHAPE;
+    *timeouts = 0;
+    const int dev = current_device();
+    char* const ws = dev < 0 ? nullptr : static_cast<char*>(g_gemm_ws[dev].load());
+    if (!ws) return BYA_OK;                       // no workspace, no split-K, nothing that could have timed out
+    unsigned word = 0;
+    if (hipMemcpyAsync(&word, ws + 1023 * 4, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return BYA_ERR_LAUNCH;
+    if (hipStreamSynchronize(stream) != hipSuccess) return BYA_ERR_LAUNCH;
+    *timeouts = (int32_t)word;
     return BYA_OK;
 }
 
@@ -375,6 +395,10 @@ extern "C" int bya_gemm_workspace_bytes(int64_t* bytes) {
     *bytes = (int64_t)GEMM_WS_BYTES;
     return BYA_OK;
 }
+
+namespace {
+int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream);
+}  // namespace
 
 extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, void* C, const void* res,
                              const void* gate0, const void* gate1, const bya_gemm_desc* d, hipStream_t stream) {
@@ -394,10 +418,21 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
     a.gate_bs = d->gate_batch_stride; a.gate_split = d->gate_split; a.act = d->act; a.leaky = 0.01f;
     a.n_split = d->n_split; a.c_split_stride = d->c_split_stride;
     a.bias_rowscale = d->bias_rowscale; a.alpha = d->alpha == 0.0f ? 1.0f : d->alpha;
-    char* const ws = static_cast<char*>(g_gemm_ws.load());
+    const int dev = current_device();
+    char* const ws = dev < 0 ? nullptr : static_cast<char*>(g_gemm_ws[dev].load());
     a.ws_counters = reinterpret_cast<unsigned*>(ws);
     a.ws_slabs = ws ? reinterpret_cast<float*>(ws + GEMM_WS_COUNTER_BYTES) : nullptr;
     if (d->n_split < 0 || (d->n_split > 0 && (d->n_split % 4 || d->c_split_stride % 4 || res))) return BYA_ERR_SHAPE;
+    return gemm_row_chunks(a, d->batch, 2, [&](const GemmArgs& piece, int batch, long long) {
+        return dispatch_gemm(piece, batch, stream);
+    });
+}
+
+namespace {
+int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
+    char* const ws = reinterpret_cast<char*>(a.ws_counters);
+    struct { int M, N, K, batch, act; } dd{a.M, a.N, a.K, nbatch, a.act};
+    const auto* d = &dd;
     const char* tile_env = getenv("BYA_GEMM_TILE");            // tuning / test switch, read per call
     const int forced = tile_env ? atoi(tile_env) : -1;
     const char* sk_env = getenv("BYA_GEMM_SPLITK");
@@ -443,3 +478,4 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
     }
     return launch256(a, d->batch, stream);
 }
+}  // namespace

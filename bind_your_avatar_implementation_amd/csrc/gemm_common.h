@@ -1,4 +1,4 @@
-// Shared by the GEMM translation units (gemm.hip, gemm_w4.hip): argument block, fused epilogue, LDS read helper.
+// Shared by the GEMM translation units (gemm.hip, gemm_v4.hip, gemm_fp8.hip): argument block, fused epilogue, LDS read helper.
 #pragma once
 #include "bya_common.h"
 #include "../../include/bya.h"
@@ -86,7 +86,8 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, int z, int m_b
     // 256 registers per lane with 128 of them accumulators, so it bursts one column group at a time).
     // Residual loads and C stores go through buffer descriptors: 32-bit per-lane byte offsets (one register per row, no
     // 64-bit pointer per access) and the hardware range check instead of branches -- an element outside M x N gets the
-    // offset 0xffffffff, whose load returns zero and whose store is dropped.  Every tensor here is far below 2 GiB.
+    // offset 0xffffffff, whose load returns zero and whose store is dropped.  The descriptors reach 2 GiB from their base:
+    // the host side (gemm_row_chunks below) cuts a launch whose C or residual rows span more than that into row chunks.
     static_assert(NI % IB == 0, "burst size must divide the tile");
     const bool has_res = p.res != nullptr, has_gate = p.gate0 != nullptr, has_bias = p.bias != nullptr;
     const bool has_rs = p.bias_rowscale != nullptr;
@@ -164,12 +165,50 @@ template <int OFF>
 __device__ __forceinline__ void ds_read128(bf16x8& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
+
+// ---- host side: the 2 GiB reach of the epilogue's buffer descriptors ---------------------------------------------------
+// Every epilogue here addresses C and the residual as  base(z) + 32-bit byte offset  under num_records = 0x7fffffff: an
+// element whose byte offset reaches 2^31 - 1 would be silently dropped on store and read as zero (and offsets past 4 GiB
+// would wrap onto valid rows).  97 frames at 720 x 1280 are 90226 joint rows: the MLP's [90226, 12288] bf16 activation is
+// 2.2 GB.  Such a launch is cut into row chunks (and batch entries) that each stay inside the reach; `run(args, batch,
+// row0)` launches one piece, row0 = index of its first row in per-row side arrays ([batch * M] fp32 scales).
+inline long long gemm_span_bytes(const GemmArgs& a, int M, bool res) {
+    const long long ld = res ? a.ldres : a.ldc;
+    const long long col = (!res && a.n_split > 0) ? (long long)(a.N / a.n_split - 1) * a.c_split_stride + a.n_split - 1
+                                                  : (long long)a.N - 1;
+    return ((long long)(M - 1) * ld + col) * 2 + 16;          // + the widest access of any epilogue
+}
+
+inline bool gemm_rows_reachable(const GemmArgs& a, int M) {
+    constexpr long long REACH = 0x7fffffffLL;
+    return gemm_span_bytes(a, M, false) < REACH && (!a.res || gemm_span_bytes(a, M, true) < REACH);
+}
+
+template <typename F>
+int gemm_row_chunks(const GemmArgs& a, int batch, int a_elem_bytes, F&& run) {
+    if (gemm_rows_reachable(a, a.M)) return run(a, batch, 0LL);
+    int chunk = a.M;
+    while (chunk > 256 && !gemm_rows_reachable(a, chunk)) chunk = ((chunk / 2 + 255) / 256) * 256;
+    if (!gemm_rows_reachable(a, chunk)) return BYA_ERR_UNSUPPORTED;        // a single 256-row block out of reach: strides too large
+    for (int z = 0; z < batch; ++z)
+        for (int m0 = 0; m0 < a.M; m0 += chunk) {
+            GemmArgs s = a;
+            s.M = a.M - m0 < chunk ? a.M - m0 : chunk;
+            s.A = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(a.A) +
+                                                  ((long long)z * a.a_bs + (long long)m0 * a.lda) * a_elem_bytes);
+            s.C = a.C + (long long)z * a.c_bs + (long long)m0 * a.ldc;
+            if (a.res) s.res = a.res + (long long)z * a.res_bs + (long long)m0 * a.ldres;
+            if (a.gate0) { s.gate0 = a.gate0 + (long long)z * a.gate_bs; s.gate1 = a.gate1 + (long long)z * a.gate_bs; }
+            if (a.bias_rowscale) s.bias_rowscale = a.bias_rowscale + (long long)z * a.M + m0;
+            s.gate_split = a.gate_split > m0 ? a.gate_split - m0 : 0;
+            const int rc = run(s, 1, (long long)z * a.M + m0);
+            if (rc != BYA_OK) return rc;
+        }
+    return BYA_OK;
+}
 }  // namespace
 
-// defined in gemm_w4.hip (compiled with its own register-allocation flags), called from bya_gemm_bf16
-int bya_launch_gemm256w4(const void* args, int batch, hipStream_t stream);
-// defined in gemm_v3.hip (same flags): one wave per SIMD, LDS-DMA two K-tiles ahead
-int bya_launch_gemm256v3(const void* args, int batch, hipStream_t stream);
-// defined in gemm_v4.hip (same flags): persistent form of v3 with cross-tile prefetch and 16-byte epilogue accesses
+// defined in gemm_v4.hip (compiled with its own register-allocation flags: accumulators in AGPRs), called from
+// bya_gemm_bf16: persistent one-wave-per-SIMD kernel with cross-tile prefetch and 16-byte epilogue accesses
 int bya_launch_gemm256p(const void* args, int batch, hipStream_t stream);
 int bya_gemm_split_min_ktiles();     // K-tiles per K-range below which the persistent kernel does not split a tile

@@ -96,9 +96,9 @@ extern "C" int bya_gemm_fp8(const void* A8, const float* a_scale, const void* W8
     a.ws_counters = nullptr; a.ws_slabs = nullptr;
     // Two 128 x 128 workgroups per CU (4 waves, 64 KiB LDS ring each) cover each other's barrier and LDS-DMA waits; a
     // 256 x 256 form (8 waves, 128 KiB ring, one workgroup per CU, half the L2 -> LDS bytes per FLOP) measured 4-16 %
-    // slower on the four DiT shapes with this simple two-barrier loop (profiles/r2_fp8_probe.txt).  BYA_FP8_TILE=256 forces it.
-    const char* tile_env = getenv("BYA_FP8_TILE");
-    if (tile_env && atoi(tile_env) == 256) return launch_fp8<256, 256, 2, 4>(a, a_scale, w_scale, d->batch, stream);
-    if (tile_env && atoi(tile_env) == 512) return bya_launch_gemm_fp8_w4(&a, a_scale, w_scale, d->batch, stream);   // 256 x 256, one wave per SIMD
-    return launch_fp8<128, 128, 2, 2>(a, a_scale, w_scale, d->batch, stream);
+    // slower on the four DiT shapes with this simple two-barrier loop, a one-wave-per-SIMD instantiation 8-20 % slower under
+    // hipcc's schedule (profiles/r2_fp8_probe.txt; both removed from the tree in round 3).
+    return gemm_row_chunks(a, d->batch, 1, [&](const GemmArgs& piece, int batch, long long row0) {
+        return launch_fp8<128, 128, 2, 2>(piece, a_scale + row0, w_scale, batch, stream);
+    });
 }

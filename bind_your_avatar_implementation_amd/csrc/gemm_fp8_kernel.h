@@ -1,6 +1,4 @@
-// Kernel template of the e4m3 GEMM (see gemm_fp8.hip for the description), shared by the two translation units that
-// instantiate it: gemm_fp8.hip (two-waves-per-SIMD forms, MFMA results in arch VGPRs) and gemm_fp8_w4.hip (the
-// one-wave-per-SIMD 256 x 256 form, 256 accumulator registers in AGPRs -- built without -amdgpu-mfma-vgpr-form).
+// Kernel template of the e4m3 GEMM (see gemm_fp8.hip for the description; two waves per SIMD, MFMA results in arch VGPRs).
 #pragma once
 #include "gemm_common.h"
 #include <stdlib.h>
@@ -141,5 +139,3 @@ int launch_fp8(const GemmArgs& a, const float* sa, const float* sw, int batch, h
 
 }  // namespace
 
-// defined in gemm_fp8_w4.hip
-int bya_launch_gemm_fp8_w4(const void* args, const float* sa, const float* sw, int batch, hipStream_t stream);

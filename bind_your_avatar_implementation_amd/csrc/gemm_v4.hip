@@ -173,7 +173,7 @@ __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wa
 // profiles/r2_gemm_epilogue_variants_same_box.txt) because it cuts the unrolled epilogue into blocks.
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_m, int tiles_n, int batch, int split_arg,
-                                                          int min_seg) {
+                                                          int min_seg, unsigned epoch) {
     const int split = SPLIT ? split_arg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 256, BN = 256, STAGE = (BM + BN) * BK * 2, TILE_A = BM * BK * 2;
@@ -875,14 +875,18 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         if (SPLIT && cur.role == 2) {
             // ---- finisher of a split tile: the other K-ranges were started together with this one; wait for their slabs
             if (tid == 0) {
-                // bounded wait (~1 s): a hand-off that never arrives must not hang the GPU; it leaves a mark in the last
-                // counter word instead (tests assert it stays zero) and the tile is finished without the missing sums
+                // A counter word is (launch epoch << 8) | arrivals: only arrivals of THIS launch satisfy the wait, a writer
+                // that turns up late from an earlier (timed-out) launch can neither satisfy nor disturb it.
+                // Bounded wait (~1 s): a hand-off that never arrives must not hang the GPU; the finisher then counts the
+                // event in the last counter word (bya_gemm_workspace_status reports it to the host; ops checks it) and
+                // finishes the tile without the missing sums.
                 int spins = 0;
-                while (__hip_atomic_load(p.ws_counters + cur.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-                       (unsigned)(cur.parts - 1)) {
+                for (;;) {
+                    const unsigned w = __hip_atomic_load(p.ws_counters + cur.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((w >> 8) == epoch && (w & 0xffu) >= (unsigned)(cur.parts - 1)) break;
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > (1 << 22)) {
-                        __hip_atomic_store(p.ws_counters + 1023, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(p.ws_counters + 1023, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                 }
@@ -941,8 +945,9 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
                 epilogue_wide<decltype(act_tag)::value, 2, SPLIT>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc, wave, lane);
             };
             dispatch_act_big(p.act, run);
-            asm volatile("s_barrier" ::: "memory");          // every wave has read the slabs: the counter can go back to 0
-            if (tid == 0) __hip_atomic_store(p.ws_counters + cur.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_barrier" ::: "memory");          // every wave has read the slabs: arrivals back to 0 (same epoch:
+                                                             // a hipGraph replays this launch with the same epoch)
+            if (tid == 0) __hip_atomic_store(p.ws_counters + cur.ctr, epoch << 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             // ---- whole tile (ordinary epilogue), or (role 1) a split tile's partial sums -> slab, then drained and counted
             float* const raw_out = (SPLIT && cur.role == 1) ? p.ws_slabs + (size_t)cur.slab * (GEMM_WS_SLAB_BYTES / 4) : nullptr;
@@ -959,7 +964,19 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
-                    __hip_atomic_fetch_add(p.ws_counters + cur.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // arrive: count within this launch's epoch; a word of an older epoch (or the zero-filled initial
+                    // state) is replaced, a word of a NEWER epoch means this writer is the stale one and must not touch it
+                    unsigned* const c = p.ws_counters + cur.ctr;
+                    unsigned old = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (;;) {
+                        const unsigned oe = old >> 8, age = (epoch - oe) & 0xffffffu;
+                        unsigned want;
+                        if (oe == epoch) want = old + 1u;
+                        else if (oe == 0u || age < 0x800000u) want = (epoch << 8) | 1u;
+                        else break;
+                        if (__hip_atomic_compare_exchange_strong(c, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT)) break;
+                    }
                 }
             }
         }
@@ -996,11 +1013,15 @@ int bya_launch_gemm256p(const void* args, int batch, hipStream_t s) {
     const bool leftover = split && (total % 256 != 0);
     if (leftover) {
         if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256p_kernel<true>), (int)lds, attr_done_s) != BYA_OK) return BYA_ERR_LAUNCH;
-        BYA_LAUNCH(gemm256p_kernel<true>, dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, batch, split, min_seg);
+        // launch epoch, 24 bits, never 0 (0 = the zero-filled initial state of a counter word)
+        static std::atomic<unsigned> g_epoch{0};
+        unsigned epoch = (g_epoch.fetch_add(1) + 1u) & 0xffffffu;
+        if (epoch == 0u) epoch = (g_epoch.fetch_add(1) + 1u) & 0xffffffu;
+        BYA_LAUNCH(gemm256p_kernel<true>, dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, batch, split, min_seg, epoch);
     } else {
         if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256p_kernel<false>), (int)lds, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
         if (total < 256) blocks = (int)((total + 7) / 8 * 8);
-        BYA_LAUNCH(gemm256p_kernel<false>, dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, batch, 0, min_seg);
+        BYA_LAUNCH(gemm256p_kernel<false>, dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, batch, 0, min_seg, 0u);
     }
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

@@ -36,8 +36,8 @@ class DenoiseEngine:
     # masked bmm) already runs over a leading identity axis.  Here the count follows the inputs (2..4, BASELINE
     # configs[4] uses 3); the one place with no n-identity form in the reference, the audio weights' [1, 0] swap, is
     # generalised as w[a] = prod_{b != a} (1 - av[b]) (include/bya.h, bya_masked_combine).
-    N_ID = 2
     MAX_ID = 4
+    n_id = None          # identity count of the LAST step (informational, for tests); never read by the engine itself
 
     def _count_ids(self, id_cond, audio_embeds):
         if self.m.is_train_face and id_cond is not None:
@@ -82,13 +82,21 @@ class DenoiseEngine:
         self._parts = {}
         if model.is_train_audio and not model.is_train_face:
             raise RuntimeError("audio injection needs the face router's logits (models/transformer.py:860)")
-        self._tensors = list(model.parameters()) + list(model.buffers())
         self._pack()
 
     def _fingerprint(self):
-        """Cheap identity of the parameter set the packed copies were made from: storage pointers catch replaced
-        tensors, ``_version`` catches in-place edits (``copy_``, ``load_state_dict`` of a submodule, optimiser steps)."""
-        return (sum(t.data_ptr() for t in self._tensors), sum(t._version for t in self._tensors))
+        """Cheap identity of the parameter set the packed copies were made from, taken from the LIVE module tree on every
+        call (a rebound ``module.weight = nn.Parameter(...)`` is a different tensor object): storage pointers catch
+        replaced tensors, ``_version`` catches in-place edits (``copy_``, ``load_state_dict`` of a submodule, optimiser
+        steps).  Tensors created under ``torch.inference_mode()`` have no version counter: their pointer alone counts."""
+        ptrs = vers = n = 0
+        for group in (self.m.parameters(), self.m.buffers()):
+            for t in group:
+                n += 1
+                ptrs += t.data_ptr()
+                if not t.is_inference():
+                    vers += t._version
+        return (n, ptrs, vers)
 
     def refresh_if_stale(self):
         """A submodule was loaded or edited in place without ``invalidate_engine()``: the packed copies (q|k|v, AdaLN,
@@ -246,10 +254,10 @@ class DenoiseEngine:
         return t.to(device=self.dev, dtype=torch.bfloat16).contiguous()
 
     # ------------------------------------------------------------------------------------------ invariants
-    def _face_invariants(self, id_cond, id_vit_hidden, B):
+    def _face_invariants(self, id_cond, id_vit_hidden, B, n_id):
         """LocalFacialExtractor (models/router.py:157-193) + the per-layer face K/V (router.py:247,254) and router
         keys (router.py:377-383).  Returns (kv[l] [B,n_id,32,2*inner], kr[l] [B,n_id,32,qk])."""
-        m, n_id = self.m, self.N_ID
+        m = self.m
         lfe = m.local_facial_extractor
         G, dim = n_id * B, lfe.dim
         nq, nt = lfe.num_queries, lfe.num_id_token
@@ -314,10 +322,10 @@ class DenoiseEngine:
             krs.append(kr_l.view(B, n_id, nq, -1))
         return kvs, krs
 
-    def _audio_invariants(self, audio_embeds, T, B):
+    def _audio_invariants(self, audio_embeds, T, B, n_id):
         """sliding_windows + AudioProjModel (models/audio_model.py:188-193, 78-114) and the per-layer audio K/V
         (diffusers Attention.to_k/to_v on the 32 context tokens of each latent frame)."""
-        am, n_id = self.m.audio_model, self.N_ID
+        am = self.m.audio_model
         ap = am.audio_proj_model
         if audio_embeds.dim() != 5:
             raise NotImplementedError(
@@ -385,14 +393,14 @@ class DenoiseEngine:
         launches produce them).  ``release()`` drops the cache and returns to the reference's recompute-every-step."""
         self.cache_invariants = True
         self._inv_cache = {}
-        self.N_ID = self._count_ids(id_cond, audio_embeds)
+        n_id = self._count_ids(id_cond, audio_embeds)
         if self.m.is_train_face and id_cond is not None:
             B = id_cond[0].shape[0]
-            flat = list(id_cond[:self.N_ID]) + [t for i in range(self.N_ID) for t in id_vit_hidden[i]]
-            self._cached("face", flat, lambda: self._face_invariants(id_cond, id_vit_hidden, B))
+            flat = list(id_cond[:n_id]) + [t for i in range(n_id) for t in id_vit_hidden[i]]
+            self._cached("face", flat, lambda: self._face_invariants(id_cond, id_vit_hidden, B, n_id))
         if self.m.is_train_audio and audio_embeds is not None:
             self._cached("audio", [audio_embeds],
-                         lambda: self._audio_invariants(audio_embeds, latent_frames, audio_embeds.shape[0]))
+                         lambda: self._audio_invariants(audio_embeds, latent_frames, audio_embeds.shape[0], n_id))
         return self
 
     def release(self):
@@ -409,15 +417,15 @@ class DenoiseEngine:
 
     def _step(self, hidden_states, encoder_hidden_states, timestep, image_rotary_emb, id_cond, id_vit_hidden,
               audio_embeds, af_matrix, routing_logits_forcing, taps=None):
-        self.N_ID = self._count_ids(id_cond, audio_embeds)
-        m, cfg, D, H, n_id = self.m, self.cfg, self.D, self.H, self.N_ID
+        n_id = self.n_id = self._count_ids(id_cond, audio_embeds)
+        m, cfg, D, H = self.m, self.cfg, self.D, self.H
         B, T, C, Hh, Ww = hidden_states.shape
         ht, wt = Hh // 2, Ww // 2
         per_frame, N = ht * wt, T * ht * wt
         Tt = encoder_hidden_states.shape[1]
         S = Tt + N
         sh = self._shard(getattr(m, "_seq_rank", 0), getattr(m, "_seq_world", 1), S, Tt, getattr(m, "_seq_group", None))
-        if sh.world > 1 and B != 1:
+        if sh.active and B != 1:
             raise NotImplementedError("sequence-parallel execution shards ONE sample; split a CFG batch over rank groups")
         S_loc, Tt_loc, N_loc, v0, v1 = sh.S_loc, sh.Tt_loc, sh.N_loc, sh.v0, sh.v1
         key = (B, T, C, Hh, Ww, Tt, sh.rank, sh.world, n_id)
@@ -445,9 +453,9 @@ class DenoiseEngine:
         # ---- step-invariant conditioning (replicated on every rank: it is tiny)
         if use_face:
             flat_face = list(id_cond[:n_id]) + [t for i in range(n_id) for t in id_vit_hidden[i]]
-            face_kv, router_k = self._cached("face", flat_face, lambda: self._face_invariants(id_cond, id_vit_hidden, B))
+            face_kv, router_k = self._cached("face", flat_face, lambda: self._face_invariants(id_cond, id_vit_hidden, B, n_id))
         if use_audio:
-            audio_k, audio_v = self._cached("audio", [audio_embeds], lambda: self._audio_invariants(audio_embeds, T, B))
+            audio_k, audio_v = self._cached("audio", [audio_embeds], lambda: self._audio_invariants(audio_embeds, T, B, n_id))
             af = self._bf(af_matrix)
         forced = None
         if routing_logits_forcing is not None and use_face:
@@ -484,14 +492,14 @@ class DenoiseEngine:
         qkv = buf("qkv", 3, B, S_loc, D)
         q, k, v = qkv[0], qkv[1], qkv[2]
         ff = buf("ff", B, S_loc, 4 * D)
-        head_parallel = sh.world > 1 and H % sh.world == 0 and os.environ.get("BYA_SP_ALLGATHER", "0") != "1"
+        head_parallel = sh.active and H % sh.world == 0 and os.environ.get("BYA_SP_ALLGATHER", "0") != "1"
         if head_parallel:
             W = sh.world
             Dl = D // W
             qkvb = buf("qkv_blocks", 3 * W, S_loc, Dl)         # column block t*W + j: tensor t (q,k,v), heads of rank j
             qh, kh, vh = buf("q_heads", S, Dl), buf("k_heads", S, Dl), buf("v_heads", S, Dl)
             oh = buf("o_heads", S, Dl)
-        elif sh.world > 1:
+        elif sh.active:
             k_full, v_full = buf("k_full", 1, S, D), buf("v_full", 1, S, D)
         r_logits = None
         for i, blk in enumerate(m.transformer_blocks):
@@ -535,7 +543,7 @@ class DenoiseEngine:
                     ops.qknorm_rope(q, k, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
                                     heads=H, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
                                         k_scale=self.k_scale)
-                    if sh.world > 1:      # exchange A (fallback when heads % world != 0): all-gather K and V
+                    if sh.active:      # exchange A (fallback when heads % world != 0): all-gather K and V
                         sh.gather_rows(k[0], k_full[0])
                         sh.gather_rows(v[0], v_full[0])
                         ops.self_attention(q, k_full, v_full, xn, heads=H, tag="joint", prescaled=True,
@@ -570,7 +578,7 @@ class DenoiseEngine:
                               v_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
                               o_strides=(n_id * N_loc * inner_p, N_loc * inner_p, inner_p), scale=hd_p ** -0.5)
                 if forced is None:
-                    r_logits = self._router(qp, router_k[ca], ca, B, T, per_frame, sh, taps)
+                    r_logits = self._router(qp, router_k[ca], ca, B, T, per_frame, n_id, sh, taps)
                 else:
                     r_logits = forced
                 if self.mix_before_projection:
@@ -598,7 +606,7 @@ class DenoiseEngine:
                 ao = buf("ao", B, n_id, N_loc, D)
                 kvs = (T * ntok * D, ntok * D, D)
                 for b in range(B):      # (id, frame) batch of one sample; q rows shared by both ids
-                    if sh.world == 1:
+                    if not sh.active:
                         ops.attention(qa[b], ka[b], va[b], ao[b], head_dim=64, heads=H, nb1=n_id, nb2=T, Sq=per_frame,
                                       Skv=ntok, q_strides=(0, per_frame * D, D), k_strides=kvs, v_strides=kvs,
                                       o_strides=(N_loc * D, per_frame * D, D), scale=64 ** -0.5)
@@ -630,7 +638,7 @@ class DenoiseEngine:
                       scale0=mo[:, D:], shift1=mo, scale1=mo[:, D:], split=0, mod_batch_stride=mbs)
         co = m.proj_out.weight.shape[0]
         y = ops.gemm(xo, m.proj_out.weight, buf("y", B, N_loc, co), bias=m.proj_out.bias)
-        if sh.world > 1:                                        # every rank returns the full latent prediction
+        if sh.active:                                        # every rank returns the full latent prediction
             y = sh.gather_video_rows(y, out=buf("y_full", B, N, co))
         out = torch.empty(B, T, co // 4, Hh, Ww, dtype=torch.bfloat16, device=self.dev)
         ops.unpatchify(y, out)
@@ -651,17 +659,17 @@ class DenoiseEngine:
             return ops.rowgemm512(a, rg[2], x, res=x)
         return ops.gemm(a, lin.weight, x, bias=lin.bias, res=x)
 
-    def _router(self, qp, kr, ca, B, T, per_frame, sh, taps):
+    def _router(self, qp, kr, ca, B, T, per_frame, n_id, sh, taps):
         """MultiIPRouter.forward (models/router.py:364-411) on the perceiver's q (shared by both ids) and the
         pre-projected router keys.  Returns this rank's rows of the routing logits, [B, N_loc, n_id] (sigmoid)."""
-        m, n_id, buf = self.m, self.N_ID, self._buf
+        m, buf = self.m, self._buf
         r = m.router
         N, N_loc = T * per_frame, sh.N_loc
         F = r.feat_dim
         qk = qp.shape[-1]
-        if sh.world > 1 and n_id * T >= sh.world and per_frame >= sh.world and \
+        if sh.active and n_id * T >= sh.world and per_frame >= sh.world and \
                 os.environ.get("BYA_ROUTER_REPLICATED", "0") != "1":
-            return self._router_sharded(qp, kr, ca, T, per_frame, sh, taps)
+            return self._router_sharded(qp, kr, ca, T, per_frame, n_id, sh, taps)
         qn = buf("r_qn", B, N_loc, qk)
         ops.layernorm(qp, qn, self.r_nq_w, self.r_nq_b, eps=r.norm_q.eps)
         qr = ops.gemm(qn, self.r_to_q[ca], buf("r_qr", B, N_loc, qk))
@@ -672,7 +680,7 @@ class DenoiseEngine:
                               eps=r.norm.eps)
         # exchange B: the spatial / temporal attentions mix tokens across the whole clip -> gather the 512-wide
         # router rows (36 MB) and run the four small blocks replicated
-        if sh.world > 1:
+        if sh.active:
             rs = sh.gather_video_rows(rs, out=buf("r_s_full", B, n_id, N, F))
         R = B * n_id * N
         rs2, rn = rs.view(R, F), buf("r_n", R, F)
@@ -707,14 +715,14 @@ class DenoiseEngine:
         if taps is not None:
             for b in range(B):
                 taps[f"router{ca}_b{b}"] = logits[b:b + 1].clone()
-        return logits if sh.world == 1 else logits[:, sh.v0:sh.v1].contiguous()
+        return logits if not sh.active else logits[:, sh.v0:sh.v1].contiguous()
 
-    def _router_sharded(self, qp, kr, ca, T, per_frame, sh, taps):
+    def _router_sharded(self, qp, kr, ca, T, per_frame, n_id, sh, taps):
         """Multi-GPU form of ``_router`` (B = 1): the four SpatialTemporalAttentionBlocks run SHARDED.  Spatial attention in
         the frame-major partition (whole (id, frame) pairs per rank), everything else in the location-major partition
         (a range of within-frame locations for all frames and ids per rank), one all-to-all between them
         (parallel.RouterPartition); the sigmoid logits (70 KB) are all-gathered at the end."""
-        m, n_id, buf = self.m, self.N_ID, self._buf
+        m, buf = self.m, self._buf
         r = m.router
         N, N_loc, F = T * per_frame, sh.N_loc, r.feat_dim
         pairs = n_id * T

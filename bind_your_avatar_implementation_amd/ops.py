@@ -106,25 +106,45 @@ def _mat(t, name):
     raise ValueError(f"{name}: expected 2-D or 3-D, got {t.dim()}-D")
 
 
-_GEMM_WS = None
+_GEMM_WS = {}          # device index -> workspace tensor (lives as long as the process)
 
 
 def ensure_gemm_workspace(device):
-    """Register the split-K workspace of the persistent GEMM kernel (bya_set_gemm_workspace) once per process: 64 MiB of
-    zero-filled device memory that lives as long as the process.  Without it the kernels still run (no K split)."""
-    global _GEMM_WS
-    if _GEMM_WS is not None:
-        if _GEMM_WS.device != torch.device(device):
-            raise RuntimeError("the GEMM split-K workspace is per process: one GPU per process (DESIGN.md section 5)")
-        return _GEMM_WS
+    """Register the split-K workspace of the persistent GEMM kernel (bya_set_gemm_workspace) once per DEVICE: 64 MiB of
+    zero-filled device memory that lives as long as the process.  Without it the kernels still run (no K split).  The
+    library picks the workspace of the device that is current when a GEMM is enqueued."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _GEMM_WS.get(idx)
+    if ws is not None:
+        return ws
     lib = _hip.load()
     n = ctypes.c_int64(0)
     check(lib.bya_gemm_workspace_bytes(ctypes.byref(n)), "bya_gemm_workspace_bytes")
-    ws = torch.zeros(n.value, dtype=torch.uint8, device=device)
-    torch.cuda.synchronize(device)
-    check(lib.bya_set_gemm_workspace(ws.data_ptr(), n.value), "bya_set_gemm_workspace")
-    _GEMM_WS = ws
+    with torch.cuda.device(idx):
+        ws = torch.zeros(n.value, dtype=torch.uint8, device=torch.device("cuda", idx))
+        torch.cuda.synchronize(idx)
+        check(lib.bya_set_gemm_workspace(ws.data_ptr(), n.value), "bya_set_gemm_workspace")
+    _GEMM_WS[idx] = ws
     return ws
+
+
+def gemm_workspace_status(device=None):
+    """Number of split-K tiles of this device whose finisher timed out waiting for a partial sum (bya_gemm_workspace_status):
+    0 on a healthy run.  Synchronises the current stream -- call it at step / run end.  ``check_gemm_workspace`` raises."""
+    lib = _hip.load()
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    n = ctypes.c_int32(0)
+    with torch.cuda.device(idx):
+        check(lib.bya_gemm_workspace_status(ctypes.byref(n), _stream()), "bya_gemm_workspace_status")
+    return n.value
+
+
+def check_gemm_workspace(device=None):
+    n = gemm_workspace_status(device)
+    if n:
+        raise _hip.ByaError(f"{n} split-K tile(s) of bya_gemm_bf16 were finished without all their partial sums (a hand-off "
+                            f"between workgroups timed out): results of this run are not to be trusted")
 
 
 def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, gate_batch_stride=0, act=None,
@@ -136,7 +156,7 @@ def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, g
     lib = _hip.load()
     ab, M, K, a_bs, lda = _mat(a, "a")
     ob, Mo, N, c_bs, ldc = _mat(out, "out")
-    if _GEMM_WS is None:
+    if a.device.index not in _GEMM_WS:
         ensure_gemm_workspace(a.device)
     if split is not None:
         N = w.shape[0]

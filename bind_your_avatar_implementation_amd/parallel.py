@@ -3,21 +3,40 @@
 
 The reference has no inference parallelism at all; this is new capability required by
 BASELINE.json.  Partition: the joint sequence ``[text (Tt) | video (N)]`` of S = Tt + N rows is cut into ``world``
-contiguous row ranges of equal size (S = 17776 divides by 2, 4 and 8) or sizes differing by one row (other geometries).  Everything on the path is row-local EXCEPT:
+contiguous row ranges of equal size (S = 17776 divides by 2, 4 and 8) or sizes differing by one row (other geometries,
+e.g. S = 47026 of BASELINE configs[3]).  Everything on the path is row-local EXCEPT:
 
-  * joint self-attention: every rank needs all keys/values -> one all-gather of K and one of V per layer
-    (``gather_rows``), queries stay local;
-  * the Embedding Router's spatial / temporal attentions, which mix tokens of a frame / of a location: the
-    512-wide router feature rows are all-gathered once per routing layer (36 MB) and the four small
-    SpatialTemporalAttentionBlocks run replicated (``gather_video_rows``); each rank keeps its rows of the logits;
+  * joint self-attention, HEAD-PARALLEL (``SeqShard.rows_to_heads`` / ``heads_to_rows``): the packed q|k|v projection
+    writes one column block per destination rank, three all-to-alls trade this rank's rows of every head for all rows
+    of this rank's 48 / world heads, attention runs on whole sequences of the local heads, one all-to-all trades back.
+    Every element of q, k, v and of the output crosses one xGMI link once (48 MB received per rank and layer at 8
+    ranks; all-gathering K and V would replicate 191 MB onto every rank -- kept as ``gather_rows`` for head counts the
+    rank count does not divide);
+  * the Embedding Router's SpatialTemporalAttentionBlocks, SHARDED in two partitions (``RouterPartition``): frame-major
+    (whole (id, frame) pairs per rank) for the spatial attention, location-major (a range of within-frame locations,
+    all frames and ids) for the temporal / multi-ID attentions, the MLP and the head, one uneven all-to-all per change
+    of partition; the 70 KB of sigmoid logits are all-gathered at the end;
   * the final unpatchify, which needs every token's 64 output channels (2 MB all-gather).
 
-Weights are replicated (17 GB of 288 GB).  There is no reduce: no GEMM is K-split.
+Weights are replicated (17 GB of 288 GB).  There is no reduce: no GEMM is K-split across ranks.
+
+``FORCE_COLLECTIVES`` (``BYA_SP_FORCE_COLLECTIVES=1``): take the collective code path even with ONE rank -- a 1-rank
+RCCL communicator on one GPU then executes every exchange (symbol resolution, dtypes, split lists, async handles on the
+communicator's stream) although nothing moves between devices; used by ``tests/test_rccl_gpu.py``.
 """
+import os
 from dataclasses import dataclass
 
 import torch
 import torch.distributed as dist
+
+
+FORCE_COLLECTIVES = os.environ.get("BYA_SP_FORCE_COLLECTIVES") == "1"
+COLLECTIVE_CALLS = {}          # kind -> number of device-side collectives issued (not host-staged ones); read by the tests
+
+
+def _count(kind):
+    COLLECTIVE_CALLS[kind] = COLLECTIVE_CALLS.get(kind, 0) + 1
 
 
 @dataclass
@@ -48,6 +67,11 @@ class SeqShard:
         self.N = self.S - self.Tt
         self._bufs = {}
 
+    @property
+    def active(self):
+        """True when the step takes the sharded code path (more than one rank, or the single-rank test hook)."""
+        return self.world > 1 or FORCE_COLLECTIVES
+
     # ---- exchange buffers: allocated once per (name, shape), reused by every layer of every step --------------------
     def buf(self, name, shape, like, zero=False):
         key = (name, tuple(shape), like.dtype, like.device)
@@ -69,6 +93,7 @@ class SeqShard:
             dist.all_gather_into_tensor(host_out, local.cpu(), group=self.group)
             out.copy_(host_out)
         else:
+            _count("all_gather")
             dist.all_gather_into_tensor(out, local, group=self.group)
 
     def _gather_padded(self, local):
@@ -92,7 +117,7 @@ class SeqShard:
 
     def gather_rows(self, local, out=None):
         """[S_loc, F] per rank -> [S, F], rank-major == global row order."""
-        if self.world == 1:
+        if not self.active:
             return local
         if self.even:
             if out is None:
@@ -110,7 +135,7 @@ class SeqShard:
         -> [..., N, F].  Implemented as a row all-gather of Tt_loc junk rows + the video rows.  ``out``: where the result
         goes (the engine passes a workspace tensor; without it a fresh tensor is returned); the staging buffers of the
         exchange itself are allocated once per shape and reused."""
-        if self.world == 1:
+        if not self.active:
             return local_video
         lead = local_video.shape[:-2]
         F = local_video.shape[-1]
@@ -138,6 +163,7 @@ class SeqShard:
             dist.all_to_all_single(host, inp.cpu(), out_splits, in_splits, group=self.group)
             out.copy_(host)
             return None
+        _count("all_to_all_async" if async_op else "all_to_all")
         return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
 
     def rows_to_heads(self, blocks, out=None, async_op=False):
@@ -223,6 +249,7 @@ class RouterPartition:
             dist.all_to_all_single(host_out, inp.cpu(), out_splits, in_splits, group=self.group)
             out.copy_(host_out)
         else:
+            _count("all_to_all")
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
     def a_to_b(self, xa, xb=None):
@@ -268,6 +295,7 @@ class RouterPartition:
             dist.all_gather_into_tensor(host, pad.cpu(), group=self.group)
             full.copy_(host)
         else:
+            _count("all_gather")
             dist.all_gather_into_tensor(full, pad, group=self.group)
         full = full.view(self.world, lead, nmax, C)
         if out is None:
@@ -345,6 +373,7 @@ class CfgSplit:
             dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=self.pair_group)
             out.copy_(host)
         else:
+            _count("all_gather")
             dist.all_gather_into_tensor(out, local.contiguous(), group=self.pair_group)
         return out
 

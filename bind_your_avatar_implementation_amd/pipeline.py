@@ -283,6 +283,9 @@ class BindyouravatarPipeline:
                 prompt_embeds = callback_outputs.pop("prompt_embeds", prompt_embeds)
                 negative_prompt_embeds = callback_outputs.pop("negative_prompt_embeds", negative_prompt_embeds)
         tr.release_conditioning()
+        if torch.device(dev).type == "cuda":    # end of the clip: no split-K hand-off timed out on the way (one sync, once)
+            from . import ops
+            ops.check_gemm_workspace(dev)
         if not return_dict:
             return (latents,)
         return SimpleNamespace(frames=latents)

@@ -66,10 +66,16 @@ int bya_gemm_bf16(const void* A, const void* W, const void* bias, void* C, const
 /* Optional split-K workspace of the persistent GEMM kernel (device memory owned by the caller, 256-byte aligned, at
  * least the size bya_gemm_workspace_bytes reports, ZERO-FILLED once): with it, the last partial round of 256 x 256 output tiles
  * of a bya_gemm_bf16 launch is cut along K over the idle CUs (partial sums and completion counters live here).  One
- * workspace per process: launches that use it must be ordered on one stream.  NULL unregisters.  Results do not depend
- * on it beyond fp32 summation order.  (No reference counterpart: scheduling detail of the Linear layers.) */
+ * workspace per DEVICE (registered for, and used by launches enqueued under, the current device); launches that use it
+ * must be ordered on one stream.  NULL unregisters.  Results do not depend on it beyond fp32 summation order.  (No
+ * reference counterpart: scheduling detail of the Linear layers.) */
 int bya_set_gemm_workspace(void* ws, int64_t bytes);
 int bya_gemm_workspace_bytes(int64_t* bytes);
+/* Health of the current device's workspace: *timeouts = number of split tiles whose finisher gave up waiting (~1 s) for a
+ * partial sum and finished without it -- 0 on a healthy run; anything else means outputs of that launch were wrong.
+ * Completion counters carry the launch epoch, so a late writer of such a launch cannot corrupt later launches.  The ONE
+ * entry point that synchronises (it copies a word back over `stream`): call it at step or run end, not per launch. */
+int bya_gemm_workspace_status(int32_t* timeouts, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * fp8 weights (BASELINE configs[4]; no reference counterpart: the reference runs bf16/fp16 only).

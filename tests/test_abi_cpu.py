@@ -100,11 +100,11 @@ def test_product_path_fails_loudly_without_gpu():
 
 
 def test_generated_gemm_schedules_match_their_tables():
-    """The hand-placed instruction streams of gemm_v3.hip / gemm_v4.hip are emitted by tools/gen_gemm_v*_schedule.py from
-    placement tables; the committed sources must be exactly what the tables generate."""
+    """The hand-placed instruction stream of gemm_v4.hip is emitted by tools/gen_gemm_v4_schedule.py from a placement
+    table; the committed source must be exactly what the table generates."""
     import subprocess
     import sys
-    for gen in ("gen_gemm_v4_schedule.py", "gen_gemm_v3_schedule.py"):
+    for gen in ("gen_gemm_v4_schedule.py",):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), "--check"], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
 
@@ -141,6 +141,21 @@ def test_valu_only_kernels_hold_no_packed_fp32(lib_path):
             hits = packed.findall(asm)
             assert not hits, f"{src}: {len(hits)} packed-fp32 instructions in a VALU-only translation unit"
         assert "v_mfma" in device_asm("router.hip", tmp)
-        assert packed.search(device_asm("gemm.hip", tmp))          # the pattern does match where packed ops exist
+        # The MFMA translation units DO hold packed-fp32 instructions (epilogues, softmax): if the multi-process finding of
+        # DESIGN.md section 5 is what it looks like, they are exposed in the same setting (several processes on one GPU).
+        # That finding is a workaround, not a closed root cause; the exposure is recorded here so that it is a number and
+        # not a guess (profiles/r3_packed_fp32_counts.json, rewritten with BYA_RECORD_PACKED_COUNTS=1), and must not grow
+        # unnoticed.
+        import json
+        rec_path = os.path.join(ROOT, "profiles", "r3_packed_fp32_counts.json")
+        counts = {src: len(packed.findall(device_asm(src, tmp))) for src in ("gemm.hip", "gemm_v4.hip", "attn.hip", "rowgemm.hip")}
+        print("packed-fp32 instructions in the MFMA translation units:", counts)
+        if os.environ.get("BYA_RECORD_PACKED_COUNTS") == "1":
+            with open(rec_path, "w") as f:
+                json.dump(counts, f, indent=1, sort_keys=True)
+        assert counts["gemm.hip"] > 0                               # the pattern does match where packed ops exist
+        recorded = json.load(open(rec_path))
+        for src, n in counts.items():
+            assert src in recorded and n <= 1.25 * recorded[src] + 16, (src, n, recorded.get(src))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -48,3 +48,19 @@ def test_bench_command_line_parses_without_a_gpu():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command shape for N > 1) must start
+    the two ranks itself -- as a child `python -m torch.distributed.run`, never by re-executing a process that touched the
+    GPU -- and relay rank 0's line and the exit code.  --launch-check makes the ranks meet over gloo and skip the GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"launch_check": 2, "rank_sum": 3.0}
+    # a launcher whose world disagrees with --gpus is refused before anything else happens
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=dict(env, WORLD_SIZE="4", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "nproc-per-node" in (bad.stdout + bad.stderr)

@@ -176,6 +176,56 @@ def test_forward_with_fp8_weights_vs_fake_quantised_oracle(dev):
     assert torch.equal(model(**gi)[0].float().cpu(), out_bf16)            # and back: bit-identical bf16 engine
 
 
+def test_config4_fp8_weights_three_identities_97_frames_vs_fake_quantised_oracle(dev):
+    """BASELINE configs[4] with ALL THREE of its elements in one forward: fp8 weights + 3 identities / audio streams + a
+    97-frame clip (25 latent frames), at a small spatial size (25 x 6 x 10 video tokens + 226 text rows, full 3072-wide
+    model, 2 layers, cyclic audio-to-face matrix).  Oracle: oracle/model.py (whose n-identity audio weights are the
+    build-defined generalisation of the reference's two-stream swap) with its DiT Linears and the two
+    query projections replaced by the fp8 definition of include/bya.h -- no reference counterpart exists for either
+    (models/transformer.py:638-639,784,881 hard-code two identities; nothing in the reference is fp8).  Usual stage bar:
+    err(engine, fp32 oracle) <= 1.5 x err(oracle in bf16, fp32 oracle) + 1e-3."""
+    from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel
+    from bind_your_avatar_implementation_amd.synth import synth_inputs
+    from oracle.model import OracleTransformer
+    from test_forward_gpu import SMALL_KW, to_dev
+    kw = dict(SMALL_KW, sample_frames=97, sample_height=12, sample_width=20)
+    model = BindyouravatarTransformer3DModel(**kw, device=dev).init_synthetic(seed=11, fast=True)
+    inp = synth_inputs(batch=1, frames=25, height=12, width=20, n_id=3, seed=12)
+    inp["af_matrix"] = torch.roll(torch.eye(3), 1, dims=1)[None]
+    with torch.device("meta"):
+        orc = OracleTransformer(**kw)
+    orc = orc.to_empty(device="cpu")
+    orc.load_state_dict({k: v.float().cpu() for k, v in model.state_dict().items()}, strict=True)
+    orc.eval()
+    gi = to_dev(inp, dev)
+    out_bf16 = model(**gi)[0].float().cpu()
+    taps32, taps16, tapsg = {}, {}, {}
+    with torch.no_grad():
+        orc = with_fp8_dit_linears(orc)
+        ref = orc(taps=taps32, **inp)[0]
+        inp16 = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
+        inp16["id_cond"] = [t.to(torch.bfloat16) for t in inp["id_cond"]]
+        inp16["id_vit_hidden"] = [[t.to(torch.bfloat16) for t in l] for l in inp["id_vit_hidden"]]
+        ref16 = orc.to(torch.bfloat16)(taps=taps16, **inp16)[0]
+    model.enable_fp8_weights()
+    out = model(**gi)[0]
+    eng = model._engine
+    assert eng.w8 is not None and eng.n_id == 3
+    eng.step(gi["hidden_states"], gi["encoder_hidden_states"], gi["timestep"], gi["image_rotary_emb"], gi["id_cond"],
+             gi["id_vit_hidden"], gi["audio_embeds"], gi["af_matrix"], None, taps=tapsg)
+    assert tapsg["router0_b0"].shape[-1] == 3
+    for name in ["block0", "face0", "audio0", "block1", "audio1"]:
+        g, r32, r16 = tapsg[name].float().cpu(), taps32[name].float(), taps16[name].float()
+        e_g, e_16 = rel_fro(g, r32), rel_fro(r16, r32)
+        print(f"{name:8s} engine(fp8, 3 ids, 97 frames)-vs-fp32 {e_g:.3e}   bf16-oracle-vs-fp32 {e_16:.3e}")
+        assert e_g <= 1.5 * e_16 + 1e-3, name
+    e_g, e_16 = rel_fro(out, ref), rel_fro(ref16, ref)
+    print(f"output   engine(fp8, 3 ids, 97 frames)-vs-fp32 {e_g:.3e}   bf16-oracle-vs-fp32 {e_16:.3e}")
+    assert e_g <= 1.5 * e_16 + 1e-3
+    assert 1e-3 < rel_fro(out.float().cpu(), out_bf16) < 0.15            # fp8 weights were really in use
+    model.enable_fp8_weights(False)
+
+
 def test_fp8_weights_sequence_parallel_two_ranks_matches_single(dev):
     """fp8 weights under the sharded engine (row shards, head-parallel exchange): the activation scales are per ROW, so a
     rank's rows quantise exactly as they do unsharded -- 2 ranks on the one test GPU must reproduce the single-GPU fp8

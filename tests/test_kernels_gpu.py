@@ -55,6 +55,52 @@ def test_gemm_plain(ops, dev, M, N, K):
     check(out, a.float() @ w.float().T, what=f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_gemm_output_past_the_2gib_reach_of_the_epilogue_descriptors(ops, dev, fp8):
+    """The GEMM epilogues address C and the residual as base + 32-bit byte offset under a 2 GiB buffer descriptor
+    (csrc/gemm_common.h): 97 frames at 720 x 1280 are 90226 joint rows, whose MLP activation [90226, 12288] bf16 is 2.2 GB.
+    Rows whose byte offset reaches 2^31 used to be dropped on store and read as zero.  The host side now cuts such a
+    launch into row chunks: (1) FF1 shape just over the limit -- the rows past 2 GiB are written and correct; (2) a
+    gate + residual launch whose output is a strided view (ldc = 12288) reaching past 2 GiB, residual aliasing the
+    output, text/video gate split in the first chunk."""
+    M, N, K = 87381 + 1100, 12288, 256               # row 87381 is the first whose offset reaches 2^31
+    a, w, b = rnd((M, K), dev, 41), rnd((N, K), dev, 42, K ** -0.5), rnd((N,), dev, 43)
+    out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev)
+    if fp8:
+        a8, sa = ops.quantize_rows_fp8(a)
+        w8, sw = ops.quantize_rows_fp8(w)
+        run = lambda x8, sx, o, **kw: ops.gemm_fp8(x8, sx, w8, sw, o, **kw)
+        deq = lambda q, sc: q.view(torch.float8_e4m3fn).float() * sc[:, None]
+        af, wf = deq(a8, sa), deq(w8, sw)
+        run(a8, sa, out, bias=b, act="gelu_tanh")
+    else:
+        af, wf = a.float(), w.float()
+        ops.gemm(a, w, out, bias=b, act="gelu_tanh")
+    for lo, hi in ((0, 512), (87381 - 300, 87381 + 300), (M - 500, M)):
+        ref = F.gelu(af[lo:hi] @ wf.T + b.float(), approximate="tanh")
+        check(out[lo:hi], ref, tol=2e-3, what=f"{'fp8 ' if fp8 else ''}gemm rows {lo}..{hi} of {M} x {N}")
+    assert not bool((out[87381:] == 7.0).all(dim=1).any()), "rows past the 2 GiB reach were not written"
+    # (2) in-place gated residual on the first 3072 columns of the same wide buffer
+    n2 = 3072
+    x0 = out[:, :n2].clone()
+    w2, g0, g1 = rnd((n2, K), dev, 44, K ** -0.5), rnd((n2,), dev, 45), rnd((n2,), dev, 46)
+    view = out[:, :n2]
+    kw = dict(bias=b[:n2].contiguous(), res=view, gate0=g0, gate1=g1, gate_split=226)
+    if fp8:
+        w28, sw2 = ops.quantize_rows_fp8(w2)
+        ops.gemm_fp8(a8, sa, w28, sw2, view, **kw)
+        w2f = w28.view(torch.float8_e4m3fn).float() * sw2[:, None]
+    else:
+        ops.gemm(a, w2, view, **kw)
+        w2f = w2.float()
+    for lo, hi in ((0, 512), (87381 - 300, 87381 + 300), (M - 500, M)):
+        y = af[lo:hi] @ w2f.T + b[:n2].float()
+        rows = torch.arange(lo, hi, device=dev)[:, None]
+        ref = x0[lo:hi].float() + torch.where(rows < 226, g0.float()[None], g1.float()[None]) * y
+        check(out[lo:hi, :n2], ref, tol=2e-3, what=f"{'fp8 ' if fp8 else ''}gated residual rows {lo}..{hi}")
+    assert ops.gemm_workspace_status() == 0
+
+
 @pytest.mark.parametrize("M,N,K,epi", [
     (17776, 3072, 3072, "gate_res"),      # attention out-projection: 840 tiles = 3.28 rounds -> 9 leftover tiles per XCD x 3
     (17550, 3072, 3072, "res"),           # audio out-projection: 828 tiles, XCDs with 7 and with 8 leftover tiles (x 4)
@@ -114,8 +160,9 @@ def test_gemm_split_k_last_round(ops, dev, M, N, K, epi, monkeypatch):
     torch.cuda.synchronize()
     assert all(torch.equal(first, o) for o in outs)
     assert torch.equal(run(), first)
-    # the finisher's bounded wait never gave up (it would have left 0xdead in the last counter word of the workspace)
-    assert int(ops._GEMM_WS[4092:4096].view(torch.int32).item()) == 0
+    # the finisher's bounded wait never gave up (it would have counted the event in the workspace: bya_gemm_workspace_status)
+    assert ops.gemm_workspace_status() == 0
+    ops.check_gemm_workspace()
 
 
 def test_gemm_split_k_inside_a_replayed_hip_graph(ops, dev):
@@ -308,14 +355,13 @@ def test_rowgemm512_repeatable_at_router_shape(ops, dev, N, ln, res):
     assert all(torch.equal(first, o) for o in outs)
 
 
-@pytest.mark.parametrize("variant", ["v4", "w8", "w4", "v3"])
+@pytest.mark.parametrize("variant", ["v4", "w8"])
 def test_gemm_big_tile_kernels_whole_suite(dev, variant):
     """Every GEMM parity test again with the 256x256 pipelined kernels FORCED for all shapes (BYA_GEMM_TILE=4: ragged M / N,
     K of one, two and three K-tiles -- the prologue / drain paths of the software pipelines -- batches, split outputs,
     gate + residual epilogues) and, per parameter, the kernel variant BYA_GEMM_VARIANT selects: "v4" = the default
-    (persistent, gemm_v4.hip), "w8" = 8 waves (gemm.hip), "w4" = 4 waves with register-staged loads (gemm_w4.hip), "v3" = 4 waves with LDS-DMA two K-tiles ahead
-    (gemm_v3.hip), "v4" = its persistent form with cross-tile prefetch and 16-byte epilogue accesses (gemm_v4.hip; K >= 192,
-    shorter K falls back to the default kernel).  Runs in a child process so the variables cannot leak into other tests."""
+    (persistent one-wave-per-SIMD kernel with cross-tile prefetch and 16-byte epilogue accesses, gemm_v4.hip; K >= 192, shorter
+    K falls back to the 8-wave kernel), "w8" = that 8-wave fallback kernel (gemm.hip).  Runs in a child process so the variables cannot leak into other tests."""
     import os
     import subprocess
     import sys

@@ -1,7 +1,8 @@
 """Size-independent properties at the FULL BASELINE sizes, where an fp32 oracle run would take minutes: round trips,
-idempotence, linearity, convexity, permutation equivariance.  Every test runs at both full geometries of BASELINE.json:
-49x480x720 (configs[1]: 13x30x45 = 17550 video tokens, 17776 joint rows) and 49x720x1280 (configs[3]: 13x45x80 = 46800
-video tokens, 47026 joint rows -- an ODD row count with ragged 256-row tiles everywhere).  They complement the oracle /
+idempotence, linearity, convexity, permutation equivariance.  Every test runs at the three full geometries of BASELINE.json:
+49x480x720 (configs[1]: 13x30x45 = 17550 video tokens, 17776 joint rows), 49x720x1280 (configs[3]: 13x45x80 = 46800
+video tokens, 47026 joint rows -- an ODD row count with ragged 256-row tiles everywhere) and 97x480x720 with THREE
+identities (configs[4]: 25x30x45 = 33750 video tokens, 33976 joint rows).  They complement the oracle /
 golden comparisons of test_kernels_gpu.py and test_forward_gpu.py (small sizes, exact values)."""
 import pytest
 import torch
@@ -14,13 +15,14 @@ TT, D = 226, 3072
 
 
 class Geom:
-    def __init__(self, T, HT, WT):
-        self.T, self.HT, self.WT, self.N = T, HT, WT, T * HT * WT
+    def __init__(self, T, HT, WT, n_id=2):
+        self.T, self.HT, self.WT, self.N, self.n_id = T, HT, WT, T * HT * WT, n_id
 
 
-@pytest.fixture(scope="module", params=["49x480x720", "49x720x1280"])
+@pytest.fixture(scope="module", params=["49x480x720", "49x720x1280", "97x480x720x3ids"])
 def G(request):
-    return {"49x480x720": Geom(13, 30, 45), "49x720x1280": Geom(13, 45, 80)}[request.param]
+    return {"49x480x720": Geom(13, 30, 45), "49x720x1280": Geom(13, 45, 80),
+            "97x480x720x3ids": Geom(25, 30, 45, n_id=3)}[request.param]
 
 
 def rnd(shape, dev, seed, std=1.0):
@@ -52,10 +54,10 @@ def test_forcing_max_is_idempotent_and_monotone(ops, dev, G):
     """max over frames broadcast back over frames: applying it twice changes nothing; the result dominates the input and
     stays inside {0, 1} for hard masks."""
     g = torch.Generator().manual_seed(2)
-    f = (torch.rand(T, HT * WT, 2, generator=g) > 0.93).to(torch.bfloat16).to(dev)
+    f = (torch.rand(T, HT * WT, G.n_id, generator=g) > 0.93).to(torch.bfloat16).to(dev)
     a, b = torch.empty_like(f), torch.empty_like(f)
-    ops.forcing_max_over_frames(f, a, T, HT * WT, 2)
-    ops.forcing_max_over_frames(a, b, T, HT * WT, 2)
+    ops.forcing_max_over_frames(f, a, T, HT * WT, G.n_id)
+    ops.forcing_max_over_frames(a, b, T, HT * WT, G.n_id)
     assert torch.equal(a, b) and bool((a >= f).all()) and set(a.unique().tolist()) <= {0.0, 1.0}
     assert torch.equal(a[0], a[-1])
 
@@ -65,18 +67,18 @@ def test_masked_combine_hard_masks_select_rows(ops, dev, G):
     """With 0/1 routing weights the face combine is a row selection: tokens routed to nobody keep x bit for bit, tokens
     routed to identity i receive exactly bf16(x + feat_i)."""
     x0 = rnd((1, TT + N, D), dev, 3)
-    feat = rnd((1, 2, N, D), dev, 4)
+    feat = rnd((1, G.n_id, N, D), dev, 4)
     g = torch.Generator().manual_seed(5)
-    lab = torch.randint(-1, 2, (N,), generator=g).to(dev)                 # -1 background, 0 / 1 identity
-    r = torch.zeros(1, N, 2, dtype=torch.bfloat16, device=dev)
-    r[0, lab == 0, 0] = 1
-    r[0, lab == 1, 1] = 1
+    lab = torch.randint(-1, G.n_id, (N,), generator=g).to(dev)            # -1 background, 0 .. n_id - 1 identity
+    r = torch.zeros(1, N, G.n_id, dtype=torch.bfloat16, device=dev)
+    for i in range(G.n_id):
+        r[0, lab == i, i] = 1
     x = x0.clone()
     ops.masked_combine(x[:, TT:], feat, r, None, "face", 1.0)
     assert torch.equal(x[:, :TT], x0[:, :TT])
     xv, x0v = x[0, TT:], x0[0, TT:]
     assert torch.equal(xv[lab == -1], x0v[lab == -1])
-    for i in (0, 1):
+    for i in range(G.n_id):
         want = (x0v[lab == i].float() + feat[0, i][lab == i].float()).to(torch.bfloat16)
         assert torch.equal(xv[lab == i], want)
 
@@ -86,13 +88,31 @@ def test_audio_combine_swaps_speakers_with_af_matrix(ops, dev, G):
     """G2: w = 1 - (af @ r^T)^T[:, [1, 0]].  Swapping the audio-face assignment (eye <-> 1 - eye) together with the two
     audio feature maps must give the same hidden states: the [1, 0] column swap is what makes that true."""
     x0 = rnd((1, N, D), dev, 6)
-    feat = rnd((1, 2, N, D), dev, 7)
-    r = (torch.rand(1, N, 2, generator=torch.Generator().manual_seed(8)) > 0.5).to(torch.bfloat16).to(dev)
-    eye = torch.eye(2, dtype=torch.bfloat16, device=dev)[None]
+    n = G.n_id
+    feat = rnd((1, n, N, D), dev, 7)
+    eye = torch.eye(n, dtype=torch.bfloat16, device=dev)[None]
     a, b = x0.clone(), x0.clone()
+    if n == 2:
+        r = (torch.rand(1, N, 2, generator=torch.Generator().manual_seed(8)) > 0.5).to(torch.bfloat16).to(dev)
+        ops.masked_combine(a, feat, r, eye, "audio", 1.0)
+        ops.masked_combine(b, feat.flip(1).contiguous(), r.flip(-1).contiguous(), eye, "audio", 1.0)
+        assert torch.equal(a, b)                                          # relabelling the identities changes nothing
+        return
+    # n identities (build-defined weights w[a] = prod_{b != a} (1 - av[b]), oracle/model.py::audio_weights): with one-hot
+    # masks a token on face i hears stream i only, a background token hears every stream -- and a cyclic relabelling of
+    # identities, streams and masks together changes nothing
+    lab = torch.randint(-1, n, (N,), generator=torch.Generator().manual_seed(8)).to(dev)
+    r = torch.zeros(1, N, n, dtype=torch.bfloat16, device=dev)
+    for i in range(n):
+        r[0, lab == i, i] = 1
     ops.masked_combine(a, feat, r, eye, "audio", 1.0)
-    ops.masked_combine(b, feat.flip(1).contiguous(), r.flip(-1).contiguous(), eye, "audio", 1.0)
-    assert torch.equal(a, b)                                              # relabelling the identities changes nothing
+    perm = [(i + 1) % n for i in range(n)]
+    ops.masked_combine(b, feat[:, perm].contiguous(), r[..., perm].contiguous(), eye, "audio", 1.0)
+    assert torch.equal(a[0][lab >= 0], b[0][lab >= 0])                    # one term per token: exact under relabelling
+    assert rel_fro(b.float(), a.float()) < 4e-3                           # background: a 3-term sum in another order
+    for i in range(n):
+        want = (x0[0][lab == i].float() + feat[0, i][lab == i].float()).to(torch.bfloat16)
+        assert torch.equal(a[0][lab == i], want)
 
 
 def test_joint_attention_rows_are_convex_combinations(ops, dev, G):
@@ -142,7 +162,7 @@ def test_router_rowgemm_is_invariant_to_row_shift_under_layernorm(ops, dev, G):
     T, HT, WT, N = G.T, G.HT, G.WT, G.N
     """LayerNorm removes a per-row offset: rowgemm512 with folded LayerNorm must return (almost) the same q|k|v for x
     and x + c_row -- exercises the matrix-core row statistics at the full 2 N-row router size."""
-    M = 2 * N
+    M = G.n_id * N
     x = rnd((M, 512), dev, 15)
     shift = torch.randn(M, 1, generator=torch.Generator().manual_seed(16)).to(dev) * 2
     xs = (x.float() + shift).to(torch.bfloat16)
