@@ -13,20 +13,10 @@
 // (+ its partner lane+32): the online softmax is an in-register reduction plus one cross-half exchange,
 // and the S^T accumulator is directly the B operand of O^T += V^T.P^T (no LDS round trip for P).
 // Blocks of one (batch, head) are dealt to one XCD so its K/V stream is served by that XCD's L2.
-#include "bya_common.h"
-#include "../../include/bya.h"
+#include "attn_common.h"
 #include <stdlib.h>
 
 namespace {
-
-struct AttnArgs {
-    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
-    int heads, nb1, nb2, Sq, Skv, nqt;
-    long long q_s1, q_s2, q_row, k_s1, k_s2, k_row, v_s1, v_s2, v_row, o_s1, o_s2, o_row;
-    float scale_log2;  // scale * log2(e)
-    int prescaled;     // scores already in exp2 units (scale folded into k by the producer)
-    float score_bound; // > 0: |score| <= bound guaranteed by the caller -> static-offset softmax (no running maximum)
-};
 
 // Ablation build (tools/attn_ablate.py; NEVER defined in the product build): a bit mask of work to leave out of the hot
 // loop, results become meaningless, only the time is read.  1: v_exp -> one FMA, 2: K fragments read from LDS once per
@@ -54,17 +44,11 @@ struct AttnArgs {
 #ifndef BYA_ATTN_RING
 #define BYA_ATTN_RING 2          // K/V stages in LDS for head_dim 64 (3 = staging two tiles ahead; experiment switch)
 #endif
-constexpr int KV_TILE = 64;
 constexpr int Q_PER_WAVE = 32;
 constexpr int Q_PER_BLOCK = 128;
 
-// Stage a [64 keys][D] bf16 tile (rows of D*2 bytes) into LDS, lane-linear image, swizzled source.
-// XOR applied to the 16-byte chunk index of LDS row `row` (both on the staging source and on the reads):
-//  K (ds_read_b128, 32 rows x one chunk per half-wave): 128-B rows -> (row>>1)&7, 256-B rows -> row&15
-//  V (ds_read_b64_tr_b16, 4 rows x 64 B per half-wave):  128-B rows -> ((row>>1)&1)<<2, 256-B rows -> (row&3)<<2
-template <int D> __device__ __forceinline__ int kswz(int row) { return D == 64 ? ((row >> 1) & 7) : (row & 15); }
-template <int D> __device__ __forceinline__ int vswz(int row) { return D == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }
-
+// Stage a [64 keys][D] bf16 tile (rows of D*2 bytes) into LDS, lane-linear image, swizzled source (kswz / vswz:
+// attn_common.h).
 template <int D, bool IS_V>
 __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ src, long long row_stride, int kv0, int kv_max,
                                          char* lds_tile, int wave, int lane) {
@@ -743,11 +727,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel_d128(AttnArgs p) {
     attn_fwd_body<128, false>(p, smem);
 }
 
+// BYA_ATTN_W4=0 (read per call: A/B runs) keeps the joint attention on the two-block kernel of this file
+inline bool use_w4() {
+    const char* e = getenv("BYA_ATTN_W4");
+    return !(e && e[0] == '0');
+}
+
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     const int nbh = a.nb1 * a.nb2 * a.heads;
     dim3 grid((nbh * a.nqt + 7) / 8 * 8);          // whole groups of 8 (one block per XCD); surplus blocks exit at once
     const size_t lds = (size_t)(D == 64 ? BYA_ATTN_RING : 2) * 2 * KV_TILE * D * 2;
+    if (D == 64 && a.prescaled && a.score_bound > 0.f && use_w4()) return bya_launch_attn_w4(&a, s);
     if (D == 64 && a.prescaled && a.score_bound > 0.f && BYA_ATTN_QB2) {
         AttnArgs b = a;
         b.nqt = (a.Sq + 255) / 256;                  // 256 query rows per workgroup
@@ -769,7 +760,8 @@ extern "C" int bya_attn_variant(const bya_attn_desc* d) {
     if (d->head_dim != 64) return BYA_ERR_UNSUPPORTED;
     if (!d->scores_prescaled) return BYA_ATTN_D64_RUNNING_MAX;
     // a usable static bound keeps every P = exp2(s) within [2^-48, 2^48]; otherwise the running-max kernel runs
-    return (d->score_bound > 0.f && d->score_bound <= 48.f) ? BYA_ATTN_D64_STATIC_BOUND : BYA_ATTN_D64_PRESCALED;
+    if (!(d->score_bound > 0.f && d->score_bound <= 48.f)) return BYA_ATTN_D64_PRESCALED;
+    return use_w4() ? BYA_ATTN_D64_STATIC_BOUND_W4 : BYA_ATTN_D64_STATIC_BOUND;
 }
 
 extern "C" int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya_attn_desc* d,

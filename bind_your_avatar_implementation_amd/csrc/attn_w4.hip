@@ -1,0 +1,266 @@
+// Joint self-attention of the DiT blocks (17776 x 17776 tokens, 48 heads of 64; replaces F.scaled_dot_product_attention
+// inside diffusers' CogVideoXAttnProcessor2_0, models/transformer.py:200-209,241-245) as ONE WAVE PER SIMD with a
+// hand-placed instruction stream -- the form DESIGN.md section 9.1 named as the next step after the two-block kernel.
+//
+// Same arithmetic as attn_fwd_kernel_d64_bounded2 (attn.hip): scores arrive in exp2 units (scale * log2 e folded into k
+// by bya_qknorm_rope) and are bounded by the caller (|s| <= B <= 48), so softmax needs no running maximum: P = exp2(s),
+// row sums in fp32, P rounded to bf16 for the P.V product, O / l at the end.  Swapped QK^T (S^T = K.Q^T, a query row
+// lives on one lane pair), the S accumulator IS the B operand of O^T += V^T.P^T, V by ds_read_b64_tr_b16.
+//
+// What is different is who schedules it.  A workgroup = 4 waves = 512 query rows of one (batch, head), one workgroup
+// per CU (512 registers per lane): a wave owns FOUR 32-row query blocks, every K and V fragment it reads from LDS feeds
+// all four (a quarter of the LDS reads per FLOP of the one-block kernel, half the K/V staging per FLOP of the two-block
+// one).  The 64 MFMAs of a 64-key tile run as four periods { QK_b ; PV_(b-1) } with the softmax of block b in the MFMA
+// gaps behind QK_b (tools/gen_attn_w4_schedule.py holds the placement table and describes it) -- every instruction of
+// the hot loop is a volatile asm statement in program order, hipcc only allocates registers.  At head_dim 64 the loop is
+// bound by the vector issue port (2 v_exp + 2 v_add + 1 v_cvt_pk per MFMA gap = 28 cycles + the MFMA's own 8 against the
+// matrix pipe's 32): 36.5 cycles per MFMA is the floor of ANY d = 64 softmax on this ISA; the point of placing the
+// stream by hand is that nothing else -- LDS latency, the tile rendezvous, DMA issue -- is exposed on top of it.
+//
+// K/V tiles: LDS-DMA (buffer_load ... lds) three tiles ahead into a 3-stage ring (48 KiB), one s_barrier per tile at
+// the head of PV_2: by then every wave has read tile t's V (under QK_1) and tile t+1 must have landed.
+// Rows past Skv in the last tile: their K rows land as zeros (hardware range check) -> score 0 -> P = 1 exactly, their
+// V rows are zeros too, so only the row sum is off, by exactly the number of padded keys: subtracted at the end.
+// Built WITHOUT -amdgpu-mfma-vgpr-form (O accumulators and the Q fragments live in AGPRs).
+#include "attn_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <char C> struct IntTagC { static constexpr char value = C; };
+
+__device__ __forceinline__ i32x4 raw_rsrc(const void* base, uint32_t bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu));
+    r.y = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// one 1-KiB LDS-DMA piece: 64 lanes x 16 bytes from per-lane global offsets to LDS [m0 .. m0 + 1024)
+__device__ __forceinline__ void dma_piece(uint32_t lds_dst, uint32_t voff, const i32x4& rsrc, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+
+constexpr int QB = 4;                                   // 32-row query blocks per wave
+constexpr int ROWS_PER_WG = 4 * QB * 32;                // 512
+constexpr int RB = 128, TILE_BYTES = KV_TILE * RB, STAGE_BYTES = 2 * TILE_BYTES, NST = 3;
+
+__global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int D = 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hf = lane >> 5;
+
+    // block -> (bh, q-tile): blocks with equal (blockIdx % 8) share an XCD; whole (batch, head)s per XCD when the count
+    // divides by 8, else a contiguous eighth of the (head, q-tile) order (same rule as attn.hip)
+    const int nbh = p.nb1 * p.nb2 * p.heads;
+    int bh, qt;
+    if (nbh % 8 == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        bh = (j / p.nqt) * 8 + xcd;
+        qt = j % p.nqt;
+    } else {
+        const int total = nbh * p.nqt, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int cq = total >> 3, cr = total & 7;
+        const int base = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+        if (j >= cq + (xcd < cr ? 1 : 0)) return;
+        bh = (base + j) / p.nqt;
+        qt = (base + j) % p.nqt;
+    }
+    if (bh >= nbh) return;
+    const int head = bh % p.heads, b12 = bh / p.heads;
+    const int b1 = b12 / p.nb2, b2 = b12 % p.nb2;
+    const bf16_t* Qp = p.q + b1 * p.q_s1 + b2 * p.q_s2 + (long long)head * D;
+    const bf16_t* Kp = p.k + b1 * p.k_s1 + b2 * p.k_s2 + (long long)head * D;
+    const bf16_t* Vp = p.v + b1 * p.v_s1 + b2 * p.v_s2 + (long long)head * D;
+    bf16_t* Op = p.o + b1 * p.o_s1 + b2 * p.o_s2 + (long long)head * D;
+
+    // ---- K/V staging: wave w moves rows [16 w, 16 w + 16) of the K tile and of the V tile, two 1-KiB pieces each
+    const i32x4 rsK = raw_rsrc(Kp, (uint32_t)(((long long)(p.Skv - 1) * p.k_row + D) * 2));
+    const i32x4 rsV = raw_rsrc(Vp, (uint32_t)(((long long)(p.Skv - 1) * p.v_row + D) * 2));
+    uint32_t dvo[4];                                       // per-lane source offsets of pieces K0 K1 V0 V1
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = wave * 16 + q * 8 + lane / 8, slot = lane % 8;
+        dvo[q] = (uint32_t)row * (uint32_t)(p.k_row * 2) + ((slot ^ kswz<D>(row)) << 4);
+        dvo[2 + q] = (uint32_t)row * (uint32_t)(p.v_row * 2) + ((slot ^ vswz<D>(row)) << 4);
+    }
+    const uint32_t k_tile_stride = KV_TILE * (uint32_t)p.k_row * 2, v_tile_stride = KV_TILE * (uint32_t)p.v_row * 2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+    const uint32_t lds0s = __builtin_amdgcn_readfirstlane(lds0) + wave * 16 * RB;       // this wave's first K piece, stage 0
+    const int ntiles = (p.Skv + KV_TILE - 1) / KV_TILE;
+    auto stage_tile = [&](int t, int st) {                 // tiles past the end are outside the descriptors: zeros land
+        const uint32_t dst = lds0s + st * STAGE_BYTES;
+        dma_piece(dst, dvo[0], rsK, t * k_tile_stride);
+        dma_piece(dst + 1024, dvo[1], rsK, t * k_tile_stride);
+        dma_piece(dst + TILE_BYTES, dvo[2], rsV, t * v_tile_stride);
+        dma_piece(dst + TILE_BYTES + 1024, dvo[3], rsV, t * v_tile_stride);
+    };
+    stage_tile(0, 0);
+    stage_tile(1, 1);
+    stage_tile(2, 2);
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane (r, hf) holds Q[q0 + 32 b + r][16 s + 8 hf .. + 7]
+    const int q0 = qt * ROWS_PER_WG + wave * (QB * 32);
+    bf16x8 qf[QB][4];
+    bool q_valid[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        int qrow = q0 + b * 32 + r;
+        q_valid[b] = qrow < p.Sq;
+        qrow = q_valid[b] ? qrow : p.Sq - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Qp + (long long)qrow * p.q_row + s * 16 + hf * 8));
+    }
+
+    // ---- state.  S and P are double-buffered by block parity; the loop's first period finishes "block 3 of tile -1":
+    // S[1][1] = -inf (exp2 -> 0), P[1] = 0 and V = 0 make that a no-op.
+    f32x16 oacc[QB][2], sacc[2][2];
+    u32x4 pf[2][4];
+    u32x2 vh[2][4][2];
+    bf16x8 kf[2][4];
+    float psum[QB][2];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        psum[b][0] = psum[b][1] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[b][d][i] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sacc[0][0][i] = 0.f; sacc[0][1][i] = 0.f; sacc[1][0][i] = 0.f; sacc[1][1][i] = -INFINITY; }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            pf[x][ks] = u32x4{0u, 0u, 0u, 0u};
+            vh[x][ks][0] = u32x2{0u, 0u};
+            vh[x][ks][1] = u32x2{0u, 0u};
+        }
+
+    // per-lane LDS offsets inside a stage: K fragment (u, s) at kofs[s] + u * 32 rows; V fragment (d, ks, h) at
+    // vofs[d] + (16 ks + 8 h) rows (transposed read: 4 rows x 64 B per half-wave, attn.hip)
+    uint32_t kofs[4], vofs[2];
+    {
+        const int sw = kswz<D>(r);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kofs[s] = lds0 + r * RB + (((2 * s + hf) ^ sw) << 4);
+        const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int row = 4 * hf + tq;
+            const int chunk = 4 * d + 2 * (g & 1) + (tp >> 1);
+            vofs[d] = lds0 + TILE_BYTES + row * RB + ((chunk ^ vswz<D>(row)) << 4) + (tp & 1) * 8;
+        }
+    }
+
+#define LGKM(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory")
+#define VMC(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define BAR() asm volatile("s_barrier" ::: "memory")
+    // K fragments of the tile in stage `kst`; V fragments of the tile in stage `vst`
+#define RK(U, S) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[U][S]) : "v"(kaddr[S]), "i"((U) * 32 * RB))
+    // One tile ('L') or the tail behind the last tile ('T').  kaddr: K fragment addresses of tile t + 1, vaddr: V
+    // fragment addresses of tile t, dma_dst / soffK / soffV: where tile t + 3 goes and comes from.
+    auto body = [&](auto v_c, const uint32_t (&kaddr)[4], const uint32_t (&vaddr)[2], uint32_t dma_dst, uint32_t soffK,
+                    uint32_t soffV) {
+        constexpr char VAR = decltype(v_c)::value;
+        // GENERATED-BEGIN (tools/gen_attn_w4_schedule.py)
+        if constexpr (VAR == 'L') {
+            // period 0: QK_0 | PV_3
+            { float t1_0; float t1_1; float t1_2; float t1_3; float t1_4; float t1_5; float t1_6; float t1_7; float t1_8; float t1_9; float t1_10; float t1_11; float t1_12; float t1_13; float t1_14; float t1_15; uint32_t w2_0; uint32_t w2_1; uint32_t w2_2; uint32_t w2_3; uint32_t w3_0; uint32_t w3_1; uint32_t w3_2; uint32_t w3_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, 0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %0, %32, %33, %0\n\tv_exp_f32 %3, %34\n\tv_add_f32 %5, %5, %1\n\tv_exp_f32 %4, %35\n\tv_add_f32 %6, %6, %2\n\tv_cvt_pk_bf16_f32 %7, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %36, %37, %0\n\tv_exp_f32 %8, %38\n\tv_add_f32 %5, %5, %3\n\tv_exp_f32 %9, %39\n\tv_add_f32 %6, %6, %4\n\tv_cvt_pk_bf16_f32 %10, %3, %4\n\tv_mfma_f32_32x32x16_bf16 %0, %40, %41, %0\n\tv_exp_f32 %11, %42\n\tv_add_f32 %5, %5, %8\n\tv_exp_f32 %12, %43\n\tv_add_f32 %6, %6, %9\n\tv_cvt_pk_bf16_f32 %13, %8, %9\n\tv_mfma_f32_32x32x16_bf16 %14, %44, %29, 0\n\tv_exp_f32 %15, %45\n\tv_add_f32 %5, %5, %11\n\tv_exp_f32 %16, %46\n\tv_add_f32 %6, %6, %12\n\tv_cvt_pk_bf16_f32 %17, %11, %12\n\tv_mfma_f32_32x32x16_bf16 %14, %47, %33, %14\n\tv_exp_f32 %18, %48\n\tv_add_f32 %5, %5, %15\n\tv_exp_f32 %19, %49\n\tv_add_f32 %6, %6, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %14, %50, %37, %14\n\tv_exp_f32 %21, %51\n\tv_add_f32 %5, %5, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %6, %6, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %14, %53, %41, %14\n\tv_exp_f32 %24, %54\n\tv_add_f32 %5, %5, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %6, %6, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %5, %5, %24\n\tv_add_f32 %6, %6, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "=&v"(sacc[0][0]), "=&v"(t1_0), "=&v"(t1_1), "=&v"(t1_2), "=&v"(t1_3), "+v"(psum[3][0]), "+v"(psum[3][1]), "=&v"(w2_0), "=&v"(t1_4), "=&v"(t1_5), "=&v"(w2_1), "=&v"(t1_6), "=&v"(t1_7), "=&v"(w2_2), "=&v"(sacc[0][1]), "=&v"(t1_8), "=&v"(t1_9), "=&v"(w2_3), "=&v"(t1_10), "=&v"(t1_11), "=&v"(w3_0), "=&v"(t1_12), "=&v"(t1_13), "=&v"(w3_1), "=&v"(t1_14), "=&v"(t1_15), "=&v"(w3_2), "=&v"(w3_3) : "v"(kf[0][0]), "a"(qf[0][0]), "v"(sacc[1][1][0]), "v"(sacc[1][1][1]), "v"(kf[0][1]), "a"(qf[0][1]), "v"(sacc[1][1][2]), "v"(sacc[1][1][3]), "v"(kf[0][2]), "a"(qf[0][2]), "v"(sacc[1][1][4]), "v"(sacc[1][1][5]), "v"(kf[0][3]), "a"(qf[0][3]), "v"(sacc[1][1][6]), "v"(sacc[1][1][7]), "v"(kf[1][0]), "v"(sacc[1][1][8]), "v"(sacc[1][1][9]), "v"(kf[1][1]), "v"(sacc[1][1][10]), "v"(sacc[1][1][11]), "v"(kf[1][2]), "v"(sacc[1][1][12]), "v"(sacc[1][1][13]), "v"(kf[1][3]), "v"(sacc[1][1][14]), "v"(sacc[1][1][15]) : "memory"); pf[1][2][0] = w2_0; pf[1][2][1] = w2_1; pf[1][2][2] = w2_2; pf[1][2][3] = w2_3; pf[1][3][0] = w3_0; pf[1][3][1] = w3_1; pf[1][3][2] = w3_2; pf[1][3][3] = w3_3; }
+            { const u32x4 vv0_0 = {vh[0][0][0][0], vh[0][0][0][1], vh[0][0][1][0], vh[0][0][1][1]}; const u32x4 vv1_0 = {vh[1][0][0][0], vh[1][0][0][1], vh[1][0][1][0], vh[1][0][1][1]}; const u32x4 vv0_1 = {vh[0][1][0][0], vh[0][1][0][1], vh[0][1][1][0], vh[0][1][1][1]}; const u32x4 vv1_1 = {vh[1][1][0][0], vh[1][1][0][1], vh[1][1][1][0], vh[1][1][1][1]}; const u32x4 vv0_2 = {vh[0][2][0][0], vh[0][2][0][1], vh[0][2][1][0], vh[0][2][1][1]}; const u32x4 vv1_2 = {vh[1][2][0][0], vh[1][2][0][1], vh[1][2][1][0], vh[1][2][1][1]}; const u32x4 vv0_3 = {vh[0][3][0][0], vh[0][3][0][1], vh[0][3][1][0], vh[0][3][1][1]}; const u32x4 vv1_3 = {vh[1][3][0][0], vh[1][3][0][1], vh[1][3][1][0], vh[1][3][1][1]}; float t0_0; float t0_1; float t0_2; float t0_3; float t0_4; float t0_5; float t0_6; float t0_7; float t0_8; float t0_9; float t0_10; float t0_11; float t0_12; float t0_13; float t0_14; float t0_15; uint32_t w0_0; uint32_t w0_1; uint32_t w0_2; uint32_t w0_3; uint32_t w1_0; uint32_t w1_1; uint32_t w1_2; uint32_t w1_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, %0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %3, %32, %29, %3\n\tv_exp_f32 %4, %33\n\tv_add_f32 %6, %6, %1\n\tv_exp_f32 %5, %34\n\tv_add_f32 %7, %7, %2\n\tv_cvt_pk_bf16_f32 %8, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %35, %36, %0\n\tv_exp_f32 %9, %37\n\tv_add_f32 %6, %6, %4\n\tv_exp_f32 %10, %38\n\tv_add_f32 %7, %7, %5\n\tv_cvt_pk_bf16_f32 %11, %4, %5\n\tv_mfma_f32_32x32x16_bf16 %3, %39, %36, %3\n\tv_exp_f32 %12, %40\n\tv_add_f32 %6, %6, %9\n\tv_exp_f32 %13, %41\n\tv_add_f32 %7, %7, %10\n\tv_cvt_pk_bf16_f32 %14, %9, %10\n\tv_mfma_f32_32x32x16_bf16 %0, %42, %43, %0\n\tv_exp_f32 %15, %44\n\tv_add_f32 %6, %6, %12\n\tv_exp_f32 %16, %45\n\tv_add_f32 %7, %7, %13\n\tv_cvt_pk_bf16_f32 %17, %12, %13\n\tv_mfma_f32_32x32x16_bf16 %3, %46, %43, %3\n\tv_exp_f32 %18, %47\n\tv_add_f32 %6, %6, %15\n\tv_exp_f32 %19, %48\n\tv_add_f32 %7, %7, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %0, %49, %50, %0\n\tv_exp_f32 %21, %51\n\tv_add_f32 %6, %6, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %7, %7, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %3, %53, %50, %3\n\tv_exp_f32 %24, %54\n\tv_add_f32 %6, %6, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %7, %7, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %6, %6, %24\n\tv_add_f32 %7, %7, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "+a"(oacc[3][0]), "=&v"(t0_0), "=&v"(t0_1), "+a"(oacc[3][1]), "=&v"(t0_2), "=&v"(t0_3), "+v"(psum[0][0]), "+v"(psum[0][1]), "=&v"(w0_0), "=&v"(t0_4), "=&v"(t0_5), "=&v"(w0_1), "=&v"(t0_6), "=&v"(t0_7), "=&v"(w0_2), "=&v"(t0_8), "=&v"(t0_9), "=&v"(w0_3), "=&v"(t0_10), "=&v"(t0_11), "=&v"(w1_0), "=&v"(t0_12), "=&v"(t0_13), "=&v"(w1_1), "=&v"(t0_14), "=&v"(t0_15), "=&v"(w1_2), "=&v"(w1_3) : "v"(vv0_0), "v"(pf[1][0]), "v"(sacc[0][0][0]), "v"(sacc[0][0][1]), "v"(vv1_0), "v"(sacc[0][0][2]), "v"(sacc[0][0][3]), "v"(vv0_1), "v"(pf[1][1]), "v"(sacc[0][0][4]), "v"(sacc[0][0][5]), "v"(vv1_1), "v"(sacc[0][0][6]), "v"(sacc[0][0][7]), "v"(vv0_2), "v"(pf[1][2]), "v"(sacc[0][0][8]), "v"(sacc[0][0][9]), "v"(vv1_2), "v"(sacc[0][0][10]), "v"(sacc[0][0][11]), "v"(vv0_3), "v"(pf[1][3]), "v"(sacc[0][0][12]), "v"(sacc[0][0][13]), "v"(vv1_3), "v"(sacc[0][0][14]), "v"(sacc[0][0][15]) : "memory"); pf[0][0][0] = w0_0; pf[0][0][1] = w0_1; pf[0][0][2] = w0_2; pf[0][0][3] = w0_3; pf[0][1][0] = w1_0; pf[0][1][1] = w1_1; pf[0][1][2] = w1_2; pf[0][1][3] = w1_3; }
+            // period 1: QK_1 | PV_0
+            { float t1_0; float t1_1; float t1_2; float t1_3; float t1_4; float t1_5; float t1_6; float t1_7; float t1_8; float t1_9; float t1_10; float t1_11; float t1_12; float t1_13; float t1_14; float t1_15; uint32_t w2_0; uint32_t w2_1; uint32_t w2_2; uint32_t w2_3; uint32_t w3_0; uint32_t w3_1; uint32_t w3_2; uint32_t w3_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %44, %45, 0\n\tds_read_b64_tr_b16 %1, %46 offset:0\n\tds_read_b64_tr_b16 %2, %46 offset:1024\n\tds_read_b64_tr_b16 %3, %47 offset:0\n\tv_exp_f32 %4, %48\n\tv_exp_f32 %5, %49\n\tv_mfma_f32_32x32x16_bf16 %0, %50, %51, %0\n\tds_read_b64_tr_b16 %6, %47 offset:1024\n\tds_read_b64_tr_b16 %7, %46 offset:2048\n\tds_read_b64_tr_b16 %8, %46 offset:3072\n\tv_exp_f32 %9, %52\n\tv_add_f32 %11, %11, %4\n\tv_exp_f32 %10, %53\n\tv_add_f32 %12, %12, %5\n\tv_cvt_pk_bf16_f32 %13, %4, %5\n\tv_mfma_f32_32x32x16_bf16 %0, %54, %55, %0\n\tds_read_b64_tr_b16 %14, %47 offset:2048\n\tds_read_b64_tr_b16 %15, %47 offset:3072\n\tds_read_b64_tr_b16 %16, %46 offset:4096\n\tv_exp_f32 %17, %56\n\tv_add_f32 %11, %11, %9\n\tv_exp_f32 %18, %57\n\tv_add_f32 %12, %12, %10\n\tv_cvt_pk_bf16_f32 %19, %9, %10\n\tv_mfma_f32_32x32x16_bf16 %0, %58, %59, %0\n\tds_read_b64_tr_b16 %20, %46 offset:5120\n\tds_read_b64_tr_b16 %21, %47 offset:4096\n\tds_read_b64_tr_b16 %22, %47 offset:5120\n\tv_exp_f32 %23, %60\n\tv_add_f32 %11, %11, %17\n\tv_exp_f32 %24, %61\n\tv_add_f32 %12, %12, %18\n\tv_cvt_pk_bf16_f32 %25, %17, %18\n\tv_mfma_f32_32x32x16_bf16 %26, %62, %45, 0\n\tds_read_b64_tr_b16 %27, %46 offset:6144\n\tds_read_b64_tr_b16 %28, %46 offset:7168\n\tv_exp_f32 %29, %63\n\tv_add_f32 %11, %11, %23\n\tv_exp_f32 %30, %64\n\tv_add_f32 %12, %12, %24\n\tv_cvt_pk_bf16_f32 %31, %23, %24\n\tv_mfma_f32_32x32x16_bf16 %26, %65, %51, %26\n\tds_read_b64_tr_b16 %32, %47 offset:6144\n\tds_read_b64_tr_b16 %33, %47 offset:7168\n\tv_exp_f32 %34, %66\n\tv_add_f32 %11, %11, %29\n\tv_exp_f32 %35, %67\n\tv_add_f32 %12, %12, %30\n\tv_cvt_pk_bf16_f32 %36, %29, %30\n\tv_mfma_f32_32x32x16_bf16 %26, %68, %55, %26\n\tv_exp_f32 %37, %69\n\tv_add_f32 %11, %11, %34\n\tv_exp_f32 %38, %70\n\tv_add_f32 %12, %12, %35\n\tv_cvt_pk_bf16_f32 %39, %34, %35\n\tv_mfma_f32_32x32x16_bf16 %26, %71, %59, %26\n\tv_exp_f32 %40, %72\n\tv_add_f32 %11, %11, %37\n\tv_exp_f32 %41, %73\n\tv_add_f32 %12, %12, %38\n\tv_cvt_pk_bf16_f32 %42, %37, %38\n\tv_add_f32 %11, %11, %40\n\tv_add_f32 %12, %12, %41\n\tv_cvt_pk_bf16_f32 %43, %40, %41\n\ts_waitcnt lgkmcnt(0)" : "=&v"(sacc[1][0]), "=&v"(vh[0][0][0]), "=&v"(vh[0][0][1]), "=&v"(vh[1][0][0]), "=&v"(t1_0), "=&v"(t1_1), "=&v"(vh[1][0][1]), "=&v"(vh[0][1][0]), "=&v"(vh[0][1][1]), "=&v"(t1_2), "=&v"(t1_3), "+v"(psum[0][0]), "+v"(psum[0][1]), "=&v"(w2_0), "=&v"(vh[1][1][0]), "=&v"(vh[1][1][1]), "=&v"(vh[0][2][0]), "=&v"(t1_4), "=&v"(t1_5), "=&v"(w2_1), "=&v"(vh[0][2][1]), "=&v"(vh[1][2][0]), "=&v"(vh[1][2][1]), "=&v"(t1_6), "=&v"(t1_7), "=&v"(w2_2), "=&v"(sacc[1][1]), "=&v"(vh[0][3][0]), "=&v"(vh[0][3][1]), "=&v"(t1_8), "=&v"(t1_9), "=&v"(w2_3), "=&v"(vh[1][3][0]), "=&v"(vh[1][3][1]), "=&v"(t1_10), "=&v"(t1_11), "=&v"(w3_0), "=&v"(t1_12), "=&v"(t1_13), "=&v"(w3_1), "=&v"(t1_14), "=&v"(t1_15), "=&v"(w3_2), "=&v"(w3_3) : "v"(kf[0][0]), "a"(qf[1][0]), "v"(vaddr[0]), "v"(vaddr[1]), "v"(sacc[0][1][0]), "v"(sacc[0][1][1]), "v"(kf[0][1]), "a"(qf[1][1]), "v"(sacc[0][1][2]), "v"(sacc[0][1][3]), "v"(kf[0][2]), "a"(qf[1][2]), "v"(sacc[0][1][4]), "v"(sacc[0][1][5]), "v"(kf[0][3]), "a"(qf[1][3]), "v"(sacc[0][1][6]), "v"(sacc[0][1][7]), "v"(kf[1][0]), "v"(sacc[0][1][8]), "v"(sacc[0][1][9]), "v"(kf[1][1]), "v"(sacc[0][1][10]), "v"(sacc[0][1][11]), "v"(kf[1][2]), "v"(sacc[0][1][12]), "v"(sacc[0][1][13]), "v"(kf[1][3]), "v"(sacc[0][1][14]), "v"(sacc[0][1][15]) : "memory"); pf[0][2][0] = w2_0; pf[0][2][1] = w2_1; pf[0][2][2] = w2_2; pf[0][2][3] = w2_3; pf[0][3][0] = w3_0; pf[0][3][1] = w3_1; pf[0][3][2] = w3_2; pf[0][3][3] = w3_3; }
+            { const u32x4 vv0_0 = {vh[0][0][0][0], vh[0][0][0][1], vh[0][0][1][0], vh[0][0][1][1]}; const u32x4 vv1_0 = {vh[1][0][0][0], vh[1][0][0][1], vh[1][0][1][0], vh[1][0][1][1]}; const u32x4 vv0_1 = {vh[0][1][0][0], vh[0][1][0][1], vh[0][1][1][0], vh[0][1][1][1]}; const u32x4 vv1_1 = {vh[1][1][0][0], vh[1][1][0][1], vh[1][1][1][0], vh[1][1][1][1]}; const u32x4 vv0_2 = {vh[0][2][0][0], vh[0][2][0][1], vh[0][2][1][0], vh[0][2][1][1]}; const u32x4 vv1_2 = {vh[1][2][0][0], vh[1][2][0][1], vh[1][2][1][0], vh[1][2][1][1]}; const u32x4 vv0_3 = {vh[0][3][0][0], vh[0][3][0][1], vh[0][3][1][0], vh[0][3][1][1]}; const u32x4 vv1_3 = {vh[1][3][0][0], vh[1][3][0][1], vh[1][3][1][0], vh[1][3][1][1]}; float t0_0; float t0_1; float t0_2; float t0_3; float t0_4; float t0_5; float t0_6; float t0_7; float t0_8; float t0_9; float t0_10; float t0_11; float t0_12; float t0_13; float t0_14; float t0_15; uint32_t w0_0; uint32_t w0_1; uint32_t w0_2; uint32_t w0_3; uint32_t w1_0; uint32_t w1_1; uint32_t w1_2; uint32_t w1_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, %0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %3, %32, %29, %3\n\tv_exp_f32 %4, %33\n\tv_add_f32 %6, %6, %1\n\tv_exp_f32 %5, %34\n\tv_add_f32 %7, %7, %2\n\tv_cvt_pk_bf16_f32 %8, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %35, %36, %0\n\tv_exp_f32 %9, %37\n\tv_add_f32 %6, %6, %4\n\tv_exp_f32 %10, %38\n\tv_add_f32 %7, %7, %5\n\tv_cvt_pk_bf16_f32 %11, %4, %5\n\tv_mfma_f32_32x32x16_bf16 %3, %39, %36, %3\n\tv_exp_f32 %12, %40\n\tv_add_f32 %6, %6, %9\n\tv_exp_f32 %13, %41\n\tv_add_f32 %7, %7, %10\n\tv_cvt_pk_bf16_f32 %14, %9, %10\n\tv_mfma_f32_32x32x16_bf16 %0, %42, %43, %0\n\tv_exp_f32 %15, %44\n\tv_add_f32 %6, %6, %12\n\tv_exp_f32 %16, %45\n\tv_add_f32 %7, %7, %13\n\tv_cvt_pk_bf16_f32 %17, %12, %13\n\tv_mfma_f32_32x32x16_bf16 %3, %46, %43, %3\n\tv_exp_f32 %18, %47\n\tv_add_f32 %6, %6, %15\n\tv_exp_f32 %19, %48\n\tv_add_f32 %7, %7, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %0, %49, %50, %0\n\tv_exp_f32 %21, %51\n\tv_add_f32 %6, %6, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %7, %7, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %3, %53, %50, %3\n\tv_exp_f32 %24, %54\n\tv_add_f32 %6, %6, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %7, %7, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %6, %6, %24\n\tv_add_f32 %7, %7, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "+a"(oacc[0][0]), "=&v"(t0_0), "=&v"(t0_1), "+a"(oacc[0][1]), "=&v"(t0_2), "=&v"(t0_3), "+v"(psum[1][0]), "+v"(psum[1][1]), "=&v"(w0_0), "=&v"(t0_4), "=&v"(t0_5), "=&v"(w0_1), "=&v"(t0_6), "=&v"(t0_7), "=&v"(w0_2), "=&v"(t0_8), "=&v"(t0_9), "=&v"(w0_3), "=&v"(t0_10), "=&v"(t0_11), "=&v"(w1_0), "=&v"(t0_12), "=&v"(t0_13), "=&v"(w1_1), "=&v"(t0_14), "=&v"(t0_15), "=&v"(w1_2), "=&v"(w1_3) : "v"(vv0_0), "v"(pf[0][0]), "v"(sacc[1][0][0]), "v"(sacc[1][0][1]), "v"(vv1_0), "v"(sacc[1][0][2]), "v"(sacc[1][0][3]), "v"(vv0_1), "v"(pf[0][1]), "v"(sacc[1][0][4]), "v"(sacc[1][0][5]), "v"(vv1_1), "v"(sacc[1][0][6]), "v"(sacc[1][0][7]), "v"(vv0_2), "v"(pf[0][2]), "v"(sacc[1][0][8]), "v"(sacc[1][0][9]), "v"(vv1_2), "v"(sacc[1][0][10]), "v"(sacc[1][0][11]), "v"(vv0_3), "v"(pf[0][3]), "v"(sacc[1][0][12]), "v"(sacc[1][0][13]), "v"(vv1_3), "v"(sacc[1][0][14]), "v"(sacc[1][0][15]) : "memory"); pf[1][0][0] = w0_0; pf[1][0][1] = w0_1; pf[1][0][2] = w0_2; pf[1][0][3] = w0_3; pf[1][1][0] = w1_0; pf[1][1][1] = w1_1; pf[1][1][2] = w1_2; pf[1][1][3] = w1_3; }
+            // period 2: QK_2 | PV_1
+            { float t1_0; float t1_1; float t1_2; float t1_3; float t1_4; float t1_5; float t1_6; float t1_7; float t1_8; float t1_9; float t1_10; float t1_11; float t1_12; float t1_13; float t1_14; float t1_15; uint32_t w2_0; uint32_t w2_1; uint32_t w2_2; uint32_t w2_3; uint32_t w3_0; uint32_t w3_1; uint32_t w3_2; uint32_t w3_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, 0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %0, %32, %33, %0\n\tv_exp_f32 %3, %34\n\tv_add_f32 %5, %5, %1\n\tv_exp_f32 %4, %35\n\tv_add_f32 %6, %6, %2\n\tv_cvt_pk_bf16_f32 %7, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %36, %37, %0\n\tv_exp_f32 %8, %38\n\tv_add_f32 %5, %5, %3\n\tv_exp_f32 %9, %39\n\tv_add_f32 %6, %6, %4\n\tv_cvt_pk_bf16_f32 %10, %3, %4\n\tv_mfma_f32_32x32x16_bf16 %0, %40, %41, %0\n\tv_exp_f32 %11, %42\n\tv_add_f32 %5, %5, %8\n\tv_exp_f32 %12, %43\n\tv_add_f32 %6, %6, %9\n\tv_cvt_pk_bf16_f32 %13, %8, %9\n\tv_mfma_f32_32x32x16_bf16 %14, %44, %29, 0\n\tv_exp_f32 %15, %45\n\tv_add_f32 %5, %5, %11\n\tv_exp_f32 %16, %46\n\tv_add_f32 %6, %6, %12\n\tv_cvt_pk_bf16_f32 %17, %11, %12\n\tv_mfma_f32_32x32x16_bf16 %14, %47, %33, %14\n\tv_exp_f32 %18, %48\n\tv_add_f32 %5, %5, %15\n\tv_exp_f32 %19, %49\n\tv_add_f32 %6, %6, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %14, %50, %37, %14\n\tv_exp_f32 %21, %51\n\tv_add_f32 %5, %5, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %6, %6, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %14, %53, %41, %14\n\tv_exp_f32 %24, %54\n\tv_add_f32 %5, %5, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %6, %6, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %5, %5, %24\n\tv_add_f32 %6, %6, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "=&v"(sacc[0][0]), "=&v"(t1_0), "=&v"(t1_1), "=&v"(t1_2), "=&v"(t1_3), "+v"(psum[1][0]), "+v"(psum[1][1]), "=&v"(w2_0), "=&v"(t1_4), "=&v"(t1_5), "=&v"(w2_1), "=&v"(t1_6), "=&v"(t1_7), "=&v"(w2_2), "=&v"(sacc[0][1]), "=&v"(t1_8), "=&v"(t1_9), "=&v"(w2_3), "=&v"(t1_10), "=&v"(t1_11), "=&v"(w3_0), "=&v"(t1_12), "=&v"(t1_13), "=&v"(w3_1), "=&v"(t1_14), "=&v"(t1_15), "=&v"(w3_2), "=&v"(w3_3) : "v"(kf[0][0]), "a"(qf[2][0]), "v"(sacc[1][1][0]), "v"(sacc[1][1][1]), "v"(kf[0][1]), "a"(qf[2][1]), "v"(sacc[1][1][2]), "v"(sacc[1][1][3]), "v"(kf[0][2]), "a"(qf[2][2]), "v"(sacc[1][1][4]), "v"(sacc[1][1][5]), "v"(kf[0][3]), "a"(qf[2][3]), "v"(sacc[1][1][6]), "v"(sacc[1][1][7]), "v"(kf[1][0]), "v"(sacc[1][1][8]), "v"(sacc[1][1][9]), "v"(kf[1][1]), "v"(sacc[1][1][10]), "v"(sacc[1][1][11]), "v"(kf[1][2]), "v"(sacc[1][1][12]), "v"(sacc[1][1][13]), "v"(kf[1][3]), "v"(sacc[1][1][14]), "v"(sacc[1][1][15]) : "memory"); pf[1][2][0] = w2_0; pf[1][2][1] = w2_1; pf[1][2][2] = w2_2; pf[1][2][3] = w2_3; pf[1][3][0] = w3_0; pf[1][3][1] = w3_1; pf[1][3][2] = w3_2; pf[1][3][3] = w3_3; }
+            { const u32x4 vv0_0 = {vh[0][0][0][0], vh[0][0][0][1], vh[0][0][1][0], vh[0][0][1][1]}; const u32x4 vv1_0 = {vh[1][0][0][0], vh[1][0][0][1], vh[1][0][1][0], vh[1][0][1][1]}; const u32x4 vv0_1 = {vh[0][1][0][0], vh[0][1][0][1], vh[0][1][1][0], vh[0][1][1][1]}; const u32x4 vv1_1 = {vh[1][1][0][0], vh[1][1][0][1], vh[1][1][1][0], vh[1][1][1][1]}; const u32x4 vv0_2 = {vh[0][2][0][0], vh[0][2][0][1], vh[0][2][1][0], vh[0][2][1][1]}; const u32x4 vv1_2 = {vh[1][2][0][0], vh[1][2][0][1], vh[1][2][1][0], vh[1][2][1][1]}; const u32x4 vv0_3 = {vh[0][3][0][0], vh[0][3][0][1], vh[0][3][1][0], vh[0][3][1][1]}; const u32x4 vv1_3 = {vh[1][3][0][0], vh[1][3][0][1], vh[1][3][1][0], vh[1][3][1][1]}; float t0_0; float t0_1; float t0_2; float t0_3; float t0_4; float t0_5; float t0_6; float t0_7; float t0_8; float t0_9; float t0_10; float t0_11; float t0_12; float t0_13; float t0_14; float t0_15; uint32_t w0_0; uint32_t w0_1; uint32_t w0_2; uint32_t w0_3; uint32_t w1_0; uint32_t w1_1; uint32_t w1_2; uint32_t w1_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, %0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %3, %32, %29, %3\n\tv_exp_f32 %4, %33\n\tv_add_f32 %6, %6, %1\n\tv_exp_f32 %5, %34\n\tv_add_f32 %7, %7, %2\n\tv_cvt_pk_bf16_f32 %8, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %35, %36, %0\n\tv_exp_f32 %9, %37\n\tv_add_f32 %6, %6, %4\n\tv_exp_f32 %10, %38\n\tv_add_f32 %7, %7, %5\n\tv_cvt_pk_bf16_f32 %11, %4, %5\n\tv_mfma_f32_32x32x16_bf16 %3, %39, %36, %3\n\tv_exp_f32 %12, %40\n\tv_add_f32 %6, %6, %9\n\tv_exp_f32 %13, %41\n\tv_add_f32 %7, %7, %10\n\tv_cvt_pk_bf16_f32 %14, %9, %10\n\tv_mfma_f32_32x32x16_bf16 %0, %42, %43, %0\n\tv_exp_f32 %15, %44\n\tv_add_f32 %6, %6, %12\n\tv_exp_f32 %16, %45\n\tv_add_f32 %7, %7, %13\n\tv_cvt_pk_bf16_f32 %17, %12, %13\n\tv_mfma_f32_32x32x16_bf16 %3, %46, %43, %3\n\tv_exp_f32 %18, %47\n\tv_add_f32 %6, %6, %15\n\tv_exp_f32 %19, %48\n\tv_add_f32 %7, %7, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %0, %49, %50, %0\n\tv_exp_f32 %21, %51\n\tv_add_f32 %6, %6, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %7, %7, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %3, %53, %50, %3\n\tv_exp_f32 %24, %54\n\tv_add_f32 %6, %6, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %7, %7, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %6, %6, %24\n\tv_add_f32 %7, %7, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "+a"(oacc[1][0]), "=&v"(t0_0), "=&v"(t0_1), "+a"(oacc[1][1]), "=&v"(t0_2), "=&v"(t0_3), "+v"(psum[2][0]), "+v"(psum[2][1]), "=&v"(w0_0), "=&v"(t0_4), "=&v"(t0_5), "=&v"(w0_1), "=&v"(t0_6), "=&v"(t0_7), "=&v"(w0_2), "=&v"(t0_8), "=&v"(t0_9), "=&v"(w0_3), "=&v"(t0_10), "=&v"(t0_11), "=&v"(w1_0), "=&v"(t0_12), "=&v"(t0_13), "=&v"(w1_1), "=&v"(t0_14), "=&v"(t0_15), "=&v"(w1_2), "=&v"(w1_3) : "v"(vv0_0), "v"(pf[1][0]), "v"(sacc[0][0][0]), "v"(sacc[0][0][1]), "v"(vv1_0), "v"(sacc[0][0][2]), "v"(sacc[0][0][3]), "v"(vv0_1), "v"(pf[1][1]), "v"(sacc[0][0][4]), "v"(sacc[0][0][5]), "v"(vv1_1), "v"(sacc[0][0][6]), "v"(sacc[0][0][7]), "v"(vv0_2), "v"(pf[1][2]), "v"(sacc[0][0][8]), "v"(sacc[0][0][9]), "v"(vv1_2), "v"(sacc[0][0][10]), "v"(sacc[0][0][11]), "v"(vv0_3), "v"(pf[1][3]), "v"(sacc[0][0][12]), "v"(sacc[0][0][13]), "v"(vv1_3), "v"(sacc[0][0][14]), "v"(sacc[0][0][15]) : "memory"); pf[0][0][0] = w0_0; pf[0][0][1] = w0_1; pf[0][0][2] = w0_2; pf[0][0][3] = w0_3; pf[0][1][0] = w1_0; pf[0][1][1] = w1_1; pf[0][1][2] = w1_2; pf[0][1][3] = w1_3; }
+            // period 3: QK_3 | PV_2
+            { float t1_0; float t1_1; float t1_2; float t1_3; float t1_4; float t1_5; float t1_6; float t1_7; float t1_8; float t1_9; float t1_10; float t1_11; float t1_12; float t1_13; float t1_14; float t1_15; uint32_t w2_0; uint32_t w2_1; uint32_t w2_2; uint32_t w2_3; uint32_t w3_0; uint32_t w3_1; uint32_t w3_2; uint32_t w3_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, 0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %0, %32, %33, %0\n\tv_exp_f32 %3, %34\n\tv_add_f32 %5, %5, %1\n\tv_exp_f32 %4, %35\n\tv_add_f32 %6, %6, %2\n\tv_cvt_pk_bf16_f32 %7, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %36, %37, %0\n\tv_exp_f32 %8, %38\n\tv_add_f32 %5, %5, %3\n\tv_exp_f32 %9, %39\n\tv_add_f32 %6, %6, %4\n\tv_cvt_pk_bf16_f32 %10, %3, %4\n\tv_mfma_f32_32x32x16_bf16 %0, %40, %41, %0\n\tv_exp_f32 %11, %42\n\tv_add_f32 %5, %5, %8\n\tv_exp_f32 %12, %43\n\tv_add_f32 %6, %6, %9\n\tv_cvt_pk_bf16_f32 %13, %8, %9\n\tv_mfma_f32_32x32x16_bf16 %14, %44, %29, 0\n\tv_exp_f32 %15, %45\n\tv_add_f32 %5, %5, %11\n\tv_exp_f32 %16, %46\n\tv_add_f32 %6, %6, %12\n\tv_cvt_pk_bf16_f32 %17, %11, %12\n\tv_mfma_f32_32x32x16_bf16 %14, %47, %33, %14\n\tv_exp_f32 %18, %48\n\tv_add_f32 %5, %5, %15\n\tv_exp_f32 %19, %49\n\tv_add_f32 %6, %6, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %14, %50, %37, %14\n\tv_exp_f32 %21, %51\n\tv_add_f32 %5, %5, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %6, %6, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %14, %53, %41, %14\n\tv_exp_f32 %24, %54\n\tv_add_f32 %5, %5, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %6, %6, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %5, %5, %24\n\tv_add_f32 %6, %6, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "=&v"(sacc[1][0]), "=&v"(t1_0), "=&v"(t1_1), "=&v"(t1_2), "=&v"(t1_3), "+v"(psum[2][0]), "+v"(psum[2][1]), "=&v"(w2_0), "=&v"(t1_4), "=&v"(t1_5), "=&v"(w2_1), "=&v"(t1_6), "=&v"(t1_7), "=&v"(w2_2), "=&v"(sacc[1][1]), "=&v"(t1_8), "=&v"(t1_9), "=&v"(w2_3), "=&v"(t1_10), "=&v"(t1_11), "=&v"(w3_0), "=&v"(t1_12), "=&v"(t1_13), "=&v"(w3_1), "=&v"(t1_14), "=&v"(t1_15), "=&v"(w3_2), "=&v"(w3_3) : "v"(kf[0][0]), "a"(qf[3][0]), "v"(sacc[0][1][0]), "v"(sacc[0][1][1]), "v"(kf[0][1]), "a"(qf[3][1]), "v"(sacc[0][1][2]), "v"(sacc[0][1][3]), "v"(kf[0][2]), "a"(qf[3][2]), "v"(sacc[0][1][4]), "v"(sacc[0][1][5]), "v"(kf[0][3]), "a"(qf[3][3]), "v"(sacc[0][1][6]), "v"(sacc[0][1][7]), "v"(kf[1][0]), "v"(sacc[0][1][8]), "v"(sacc[0][1][9]), "v"(kf[1][1]), "v"(sacc[0][1][10]), "v"(sacc[0][1][11]), "v"(kf[1][2]), "v"(sacc[0][1][12]), "v"(sacc[0][1][13]), "v"(kf[1][3]), "v"(sacc[0][1][14]), "v"(sacc[0][1][15]) : "memory"); pf[0][2][0] = w2_0; pf[0][2][1] = w2_1; pf[0][2][2] = w2_2; pf[0][2][3] = w2_3; pf[0][3][0] = w3_0; pf[0][3][1] = w3_1; pf[0][3][2] = w3_2; pf[0][3][3] = w3_3; }
+            { const u32x4 vv0_0 = {vh[0][0][0][0], vh[0][0][0][1], vh[0][0][1][0], vh[0][0][1][1]}; const u32x4 vv1_0 = {vh[1][0][0][0], vh[1][0][0][1], vh[1][0][1][0], vh[1][0][1][1]}; const u32x4 vv0_1 = {vh[0][1][0][0], vh[0][1][0][1], vh[0][1][1][0], vh[0][1][1][1]}; const u32x4 vv1_1 = {vh[1][1][0][0], vh[1][1][0][1], vh[1][1][1][0], vh[1][1][1][1]}; const u32x4 vv0_2 = {vh[0][2][0][0], vh[0][2][0][1], vh[0][2][1][0], vh[0][2][1][1]}; const u32x4 vv1_2 = {vh[1][2][0][0], vh[1][2][0][1], vh[1][2][1][0], vh[1][2][1][1]}; const u32x4 vv0_3 = {vh[0][3][0][0], vh[0][3][0][1], vh[0][3][1][0], vh[0][3][1][1]}; const u32x4 vv1_3 = {vh[1][3][0][0], vh[1][3][0][1], vh[1][3][1][0], vh[1][3][1][1]}; const uint32_t dma_dst0 = dma_dst + 0 + 0 * TILE_BYTES; const uint32_t dma_dst1 = dma_dst + 1024 + 0 * TILE_BYTES; const uint32_t dma_dst2 = dma_dst + 0 + 1 * TILE_BYTES; const uint32_t dma_dst3 = dma_dst + 1024 + 1 * TILE_BYTES; float t0_0; float t0_1; float t0_2; float t0_3; float t0_4; float t0_5; float t0_6; float t0_7; float t0_8; float t0_9; float t0_10; float t0_11; float t0_12; float t0_13; float t0_14; float t0_15; uint32_t w0_0; uint32_t w0_1; uint32_t w0_2; uint32_t w0_3; uint32_t w1_0; uint32_t w1_1; uint32_t w1_2; uint32_t w1_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %36, %37, %0\n\ts_waitcnt vmcnt(4)\n\ts_barrier\n\tds_read_b128 %1, %38 offset:0\n\tds_read_b128 %2, %39 offset:0\n\tv_exp_f32 %3, %40\n\tv_exp_f32 %4, %41\n\tv_mfma_f32_32x32x16_bf16 %5, %42, %37, %5\n\tds_read_b128 %6, %43 offset:0\n\tds_read_b128 %7, %44 offset:0\n\tv_exp_f32 %8, %45\n\tv_add_f32 %10, %10, %3\n\tv_exp_f32 %9, %46\n\tv_add_f32 %11, %11, %4\n\tv_cvt_pk_bf16_f32 %12, %3, %4\n\tv_mfma_f32_32x32x16_bf16 %0, %47, %48, %0\n\tds_read_b128 %13, %38 offset:4096\n\tds_read_b128 %14, %39 offset:4096\n\tv_exp_f32 %15, %49\n\tv_add_f32 %10, %10, %8\n\tv_exp_f32 %16, %50\n\tv_add_f32 %11, %11, %9\n\tv_cvt_pk_bf16_f32 %17, %8, %9\n\tv_mfma_f32_32x32x16_bf16 %5, %51, %48, %5\n\tds_read_b128 %18, %43 offset:4096\n\tds_read_b128 %19, %44 offset:4096\n\tv_exp_f32 %20, %52\n\tv_add_f32 %10, %10, %15\n\tv_exp_f32 %21, %53\n\tv_add_f32 %11, %11, %16\n\tv_cvt_pk_bf16_f32 %22, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %0, %54, %55, %0\n\ts_mov_b32 m0, %56\n\ts_nop 0\n\tbuffer_load_dwordx4 %57, %58, %59 offen lds\n\tv_exp_f32 %23, %60\n\tv_add_f32 %10, %10, %20\n\tv_exp_f32 %24, %61\n\tv_add_f32 %11, %11, %21\n\tv_cvt_pk_bf16_f32 %25, %20, %21\n\tv_mfma_f32_32x32x16_bf16 %5, %62, %55, %5\n\ts_mov_b32 m0, %63\n\ts_nop 0\n\tbuffer_load_dwordx4 %64, %58, %59 offen lds\n\tv_exp_f32 %26, %65\n\tv_add_f32 %10, %10, %23\n\tv_exp_f32 %27, %66\n\tv_add_f32 %11, %11, %24\n\tv_cvt_pk_bf16_f32 %28, %23, %24\n\tv_mfma_f32_32x32x16_bf16 %0, %67, %68, %0\n\ts_mov_b32 m0, %69\n\ts_nop 0\n\tbuffer_load_dwordx4 %70, %71, %72 offen lds\n\tv_exp_f32 %29, %73\n\tv_add_f32 %10, %10, %26\n\tv_exp_f32 %30, %74\n\tv_add_f32 %11, %11, %27\n\tv_cvt_pk_bf16_f32 %31, %26, %27\n\tv_mfma_f32_32x32x16_bf16 %5, %75, %68, %5\n\ts_mov_b32 m0, %76\n\ts_nop 0\n\tbuffer_load_dwordx4 %77, %71, %72 offen lds\n\tv_exp_f32 %32, %78\n\tv_add_f32 %10, %10, %29\n\tv_exp_f32 %33, %79\n\tv_add_f32 %11, %11, %30\n\tv_cvt_pk_bf16_f32 %34, %29, %30\n\tv_add_f32 %10, %10, %32\n\tv_add_f32 %11, %11, %33\n\tv_cvt_pk_bf16_f32 %35, %32, %33\n\ts_waitcnt lgkmcnt(0)" : "+a"(oacc[2][0]), "=&v"(kf[0][0]), "=&v"(kf[0][1]), "=&v"(t0_0), "=&v"(t0_1), "+a"(oacc[2][1]), "=&v"(kf[0][2]), "=&v"(kf[0][3]), "=&v"(t0_2), "=&v"(t0_3), "+v"(psum[3][0]), "+v"(psum[3][1]), "=&v"(w0_0), "=&v"(kf[1][0]), "=&v"(kf[1][1]), "=&v"(t0_4), "=&v"(t0_5), "=&v"(w0_1), "=&v"(kf[1][2]), "=&v"(kf[1][3]), "=&v"(t0_6), "=&v"(t0_7), "=&v"(w0_2), "=&v"(t0_8), "=&v"(t0_9), "=&v"(w0_3), "=&v"(t0_10), "=&v"(t0_11), "=&v"(w1_0), "=&v"(t0_12), "=&v"(t0_13), "=&v"(w1_1), "=&v"(t0_14), "=&v"(t0_15), "=&v"(w1_2), "=&v"(w1_3) : "v"(vv0_0), "v"(pf[0][0]), "v"(kaddr[0]), "v"(kaddr[1]), "v"(sacc[1][0][0]), "v"(sacc[1][0][1]), "v"(vv1_0), "v"(kaddr[2]), "v"(kaddr[3]), "v"(sacc[1][0][2]), "v"(sacc[1][0][3]), "v"(vv0_1), "v"(pf[0][1]), "v"(sacc[1][0][4]), "v"(sacc[1][0][5]), "v"(vv1_1), "v"(sacc[1][0][6]), "v"(sacc[1][0][7]), "v"(vv0_2), "v"(pf[0][2]), "s"(dma_dst0), "v"(dvo[0]), "s"(rsK), "s"(soffK), "v"(sacc[1][0][8]), "v"(sacc[1][0][9]), "v"(vv1_2), "s"(dma_dst1), "v"(dvo[1]), "v"(sacc[1][0][10]), "v"(sacc[1][0][11]), "v"(vv0_3), "v"(pf[0][3]), "s"(dma_dst2), "v"(dvo[2]), "s"(rsV), "s"(soffV), "v"(sacc[1][0][12]), "v"(sacc[1][0][13]), "v"(vv1_3), "s"(dma_dst3), "v"(dvo[3]), "v"(sacc[1][0][14]), "v"(sacc[1][0][15]) : "memory"); pf[1][0][0] = w0_0; pf[1][0][1] = w0_1; pf[1][0][2] = w0_2; pf[1][0][3] = w0_3; pf[1][1][0] = w1_0; pf[1][1][1] = w1_1; pf[1][1][2] = w1_2; pf[1][1][3] = w1_3; }
+        } else if constexpr (VAR == 'T') {
+            // period 4: rest of block 3's softmax | PV_3
+            { float t1_0; float t1_1; float t1_2; float t1_3; float t1_4; float t1_5; float t1_6; float t1_7; float t1_8; float t1_9; float t1_10; float t1_11; float t1_12; float t1_13; float t1_14; float t1_15; uint32_t w2_0; uint32_t w2_1; uint32_t w2_2; uint32_t w2_3; uint32_t w3_0; uint32_t w3_1; uint32_t w3_2; uint32_t w3_3; asm volatile("v_exp_f32 %0, %26\n\tv_exp_f32 %1, %27\n\tv_exp_f32 %2, %28\n\tv_add_f32 %4, %4, %0\n\tv_exp_f32 %3, %29\n\tv_add_f32 %5, %5, %1\n\tv_cvt_pk_bf16_f32 %6, %0, %1\n\tv_exp_f32 %7, %30\n\tv_add_f32 %4, %4, %2\n\tv_exp_f32 %8, %31\n\tv_add_f32 %5, %5, %3\n\tv_cvt_pk_bf16_f32 %9, %2, %3\n\tv_exp_f32 %10, %32\n\tv_add_f32 %4, %4, %7\n\tv_exp_f32 %11, %33\n\tv_add_f32 %5, %5, %8\n\tv_cvt_pk_bf16_f32 %12, %7, %8\n\tv_exp_f32 %13, %34\n\tv_add_f32 %4, %4, %10\n\tv_exp_f32 %14, %35\n\tv_add_f32 %5, %5, %11\n\tv_cvt_pk_bf16_f32 %15, %10, %11\n\tv_exp_f32 %16, %36\n\tv_add_f32 %4, %4, %13\n\tv_exp_f32 %17, %37\n\tv_add_f32 %5, %5, %14\n\tv_cvt_pk_bf16_f32 %18, %13, %14\n\tv_exp_f32 %19, %38\n\tv_add_f32 %4, %4, %16\n\tv_exp_f32 %20, %39\n\tv_add_f32 %5, %5, %17\n\tv_cvt_pk_bf16_f32 %21, %16, %17\n\tv_exp_f32 %22, %40\n\tv_add_f32 %4, %4, %19\n\tv_exp_f32 %23, %41\n\tv_add_f32 %5, %5, %20\n\tv_cvt_pk_bf16_f32 %24, %19, %20\n\tv_add_f32 %4, %4, %22\n\tv_add_f32 %5, %5, %23\n\tv_cvt_pk_bf16_f32 %25, %22, %23" : "=&v"(t1_0), "=&v"(t1_1), "=&v"(t1_2), "=&v"(t1_3), "+v"(psum[3][0]), "+v"(psum[3][1]), "=&v"(w2_0), "=&v"(t1_4), "=&v"(t1_5), "=&v"(w2_1), "=&v"(t1_6), "=&v"(t1_7), "=&v"(w2_2), "=&v"(t1_8), "=&v"(t1_9), "=&v"(w2_3), "=&v"(t1_10), "=&v"(t1_11), "=&v"(w3_0), "=&v"(t1_12), "=&v"(t1_13), "=&v"(w3_1), "=&v"(t1_14), "=&v"(t1_15), "=&v"(w3_2), "=&v"(w3_3) : "v"(sacc[1][1][0]), "v"(sacc[1][1][1]), "v"(sacc[1][1][2]), "v"(sacc[1][1][3]), "v"(sacc[1][1][4]), "v"(sacc[1][1][5]), "v"(sacc[1][1][6]), "v"(sacc[1][1][7]), "v"(sacc[1][1][8]), "v"(sacc[1][1][9]), "v"(sacc[1][1][10]), "v"(sacc[1][1][11]), "v"(sacc[1][1][12]), "v"(sacc[1][1][13]), "v"(sacc[1][1][14]), "v"(sacc[1][1][15]) : "memory"); pf[1][2][0] = w2_0; pf[1][2][1] = w2_1; pf[1][2][2] = w2_2; pf[1][2][3] = w2_3; pf[1][3][0] = w3_0; pf[1][3][1] = w3_1; pf[1][3][2] = w3_2; pf[1][3][3] = w3_3; }
+            { const u32x4 vv0_0 = {vh[0][0][0][0], vh[0][0][0][1], vh[0][0][1][0], vh[0][0][1][1]}; const u32x4 vv1_0 = {vh[1][0][0][0], vh[1][0][0][1], vh[1][0][1][0], vh[1][0][1][1]}; const u32x4 vv0_1 = {vh[0][1][0][0], vh[0][1][0][1], vh[0][1][1][0], vh[0][1][1][1]}; const u32x4 vv1_1 = {vh[1][1][0][0], vh[1][1][0][1], vh[1][1][1][0], vh[1][1][1][1]}; const u32x4 vv0_2 = {vh[0][2][0][0], vh[0][2][0][1], vh[0][2][1][0], vh[0][2][1][1]}; const u32x4 vv1_2 = {vh[1][2][0][0], vh[1][2][0][1], vh[1][2][1][0], vh[1][2][1][1]}; const u32x4 vv0_3 = {vh[0][3][0][0], vh[0][3][0][1], vh[0][3][1][0], vh[0][3][1][1]}; const u32x4 vv1_3 = {vh[1][3][0][0], vh[1][3][0][1], vh[1][3][1][0], vh[1][3][1][1]}; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %3, %1\n\tv_mfma_f32_32x32x16_bf16 %0, %5, %6, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %7, %6, %1\n\tv_mfma_f32_32x32x16_bf16 %0, %8, %9, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %10, %9, %1\n\tv_mfma_f32_32x32x16_bf16 %0, %11, %12, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %13, %12, %1" : "+a"(oacc[3][0]), "+a"(oacc[3][1]) : "v"(vv0_0), "v"(pf[1][0]), "v"(vv1_0), "v"(vv0_1), "v"(pf[1][1]), "v"(vv1_1), "v"(vv0_2), "v"(pf[1][2]), "v"(vv1_2), "v"(vv0_3), "v"(pf[1][3]), "v"(vv1_3) : "memory"); }
+        }
+        // GENERATED-END
+    };
+
+    // The Q loads are hipcc's own: make it wait for them HERE (an empty asm that takes every fragment as an AGPR operand),
+    // or it parks one s_waitcnt vmcnt(N) in front of each fragment's first MFMA inside the loop -- down to vmcnt(0), which
+    // would drain the K/V prefetch every tile.  (That drains tiles 0..2 as well: the prologue's wait below is then free.)
+#pragma unroll
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+a"(qf[b][s]));
+    // tile 0 has landed once all but the 8 younger pieces (tiles 1, 2) have; then its K fragments
+    VMC(8);
+    BAR();
+    {
+        uint32_t kaddr[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kaddr[s] = kofs[s];
+        RK(0, 0); RK(0, 1); RK(0, 2); RK(0, 3); RK(1, 0); RK(1, 1); RK(1, 2); RK(1, 3);
+        LGKM(0);
+    }
+    int st = 0;                                            // ring stage of tile t (= of tile t + 3)
+    for (int t = 0; t < ntiles; ++t) {
+        const int st1 = st == NST - 1 ? 0 : st + 1;
+        uint32_t kaddr[4], vaddr[2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kaddr[s] = kofs[s] + st1 * STAGE_BYTES;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) vaddr[d] = vofs[d] + st * STAGE_BYTES;
+        body(IntTagC<'L'>{}, kaddr, vaddr, lds0s + st * STAGE_BYTES, (uint32_t)(t + 3) * k_tile_stride,
+             (uint32_t)(t + 3) * v_tile_stride);
+        st = st1;
+    }
+    {
+        const uint32_t none4[4] = {0u, 0u, 0u, 0u}, none2[2] = {0u, 0u};
+        body(IntTagC<'T'>{}, none4, none2, 0u, 0u, 0u);
+    }
+    // the MFMAs are inline asm: pad their last results before compiler code reads them; drain the (empty) tail prefetches
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (r, hf) holds d = 32 dd + (i & 3) + 8 (i >> 2) + 4 hf
+    const float pad_keys = (float)(ntiles * KV_TILE - p.Skv);        // keys of the last tile that do not exist: P = 1 each
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const float l_half = psum[b][0] + psum[b][1];
+        const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_half), __float_as_uint(l_half), false, false);
+        const float inv = 1.0f / (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1]) - pad_keys);
+        if (q_valid[b]) {
+            bf16_t* orow = Op + (long long)(q0 + b * 32 + r) * p.o_row;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    u32x2 w;
+                    w[0] = pack2bf(oacc[b][d][gq * 4 + 0] * inv, oacc[b][d][gq * 4 + 1] * inv);
+                    w[1] = pack2bf(oacc[b][d][gq * 4 + 2] * inv, oacc[b][d][gq * 4 + 3] * inv);
+                    *reinterpret_cast<u32x2*>(orow + d * 32 + gq * 8 + hf * 4) = w;
+                }
+        }
+    }
+}
+
+}  // namespace
+
+int bya_launch_attn_w4(const void* args, hipStream_t s) {
+    AttnArgs a = *static_cast<const AttnArgs*>(args);
+    a.nqt = (a.Sq + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    const int nbh = a.nb1 * a.nb2 * a.heads;
+    dim3 grid((nbh * a.nqt + 7) / 8 * 8);
+    BYA_LAUNCH(attn_joint_w4_kernel, grid, dim3(256), (size_t)NST * STAGE_BYTES, s, a);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}

@@ -316,7 +316,8 @@ def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6, k_sc
 
 
 # (call tag, softmax variant) -> launches since the last reset; the variant is reported by the library itself
-ATTN_VARIANT_NAMES = {0: "d64_running_max", 1: "d64_prescaled_running_max", 2: "d64_static_bound", 3: "d128_running_max"}
+ATTN_VARIANT_NAMES = {0: "d64_running_max", 1: "d64_prescaled_running_max", 2: "d64_static_bound", 3: "d128_running_max",
+                      4: "d64_static_bound_w4"}
 ATTN_VARIANTS = {}
 
 

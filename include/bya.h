@@ -181,6 +181,7 @@ int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya
 #define BYA_ATTN_D64_PRESCALED 1     /* online softmax, scores already in exp2 units */
 #define BYA_ATTN_D64_STATIC_BOUND 2  /* no running maximum: P = exp2(s), |s| <= score_bound <= 48 */
 #define BYA_ATTN_D128 3
+#define BYA_ATTN_D64_STATIC_BOUND_W4 4  /* the same arithmetic on the one-wave-per-SIMD hand-placed kernel (csrc/attn_w4.hip) */
 int bya_attn_variant(const bya_attn_desc* desc);
 
 /* Tiny-sequence self-attention (sequence length L <= 16, head_dim 64) used by the router's temporal

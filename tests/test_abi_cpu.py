@@ -48,7 +48,12 @@ def test_python_binding_table_matches_header(lib_path):
     assert lib.bya_attn_fwd(None, None, None, None, ctypes.byref(a), None) == -1
     # the softmax-variant query mirrors bya_attn_fwd's kernel choice (host-side, launches nothing)
     a.head_dim, a.scores_prescaled, a.score_bound = 64, 1, 11.8
-    assert lib.bya_attn_variant(ctypes.byref(a)) == 2
+    assert lib.bya_attn_variant(ctypes.byref(a)) == 4          # static bound on the one-wave-per-SIMD kernel (default)
+    os.environ["BYA_ATTN_W4"] = "0"
+    try:
+        assert lib.bya_attn_variant(ctypes.byref(a)) == 2      # ... on the two-block kernel
+    finally:
+        del os.environ["BYA_ATTN_W4"]
     a.score_bound = 60.0
     assert lib.bya_attn_variant(ctypes.byref(a)) == 1
     a.scores_prescaled = 0
@@ -100,11 +105,11 @@ def test_product_path_fails_loudly_without_gpu():
 
 
 def test_generated_gemm_schedules_match_their_tables():
-    """The hand-placed instruction stream of gemm_v4.hip is emitted by tools/gen_gemm_v4_schedule.py from a placement
-    table; the committed source must be exactly what the table generates."""
+    """The hand-placed instruction streams of gemm_v4.hip and attn_w4.hip are emitted by tools/gen_*_schedule.py from
+    placement tables; the committed sources must be exactly what the tables generate."""
     import subprocess
     import sys
-    for gen in ("gen_gemm_v4_schedule.py",):
+    for gen in ("gen_gemm_v4_schedule.py", "gen_attn_w4_schedule.py"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), "--check"], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
 
