@@ -152,6 +152,7 @@ struct QkArgs {
     float eps;
     float k_scale;     // multiplies the finished k (fp32, before the single rounding to bf16); 1 = off
     int table_sc1;     // 1: read cos / sin past the vector L1 (sc1 loads) -- see tools/timeslice/repro.py
+    int only;          // 0: q and k; 1: q alone; 2: k alone (the sharded step norms q, starts its exchange, then norms k)
 };
 
 // DBG (tools/timeslice/repro.py, experiment builds only; 0 = the product kernel):
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
     const int lane = threadIdx.x & 63;
     const long long pairs_per_tensor = (long long)p.batch * p.S * p.heads;
     const long long pair = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);
-    if (pair >= 2 * pairs_per_tensor) return;
-    const int which = pair >= pairs_per_tensor;      // 0 = q, 1 = k
+    if (pair >= (p.only ? 1 : 2) * pairs_per_tensor) return;
+    const int which = p.only ? p.only - 1 : (pair >= pairs_per_tensor);      // 0 = q, 1 = k
     long long rest = pair - which * pairs_per_tensor;
     int head, s, z;
     if constexpr (DBG == 2) {
@@ -290,7 +291,7 @@ extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb,
                                const float* cos, const float* sin, int32_t batch, int32_t S, int32_t heads,
                                int64_t ld, int64_t batch_stride, int32_t text_rows, float eps, float k_scale,
                                hipStream_t stream) {
-    if (!q || !k || !qw || !qb || !kw || !kb || batch <= 0 || S <= 0 || heads <= 0) return BYA_ERR_SHAPE;
+    if ((!q && !k) || !qw || !qb || !kw || !kb || batch <= 0 || S <= 0 || heads <= 0) return BYA_ERR_SHAPE;
     if (text_rows < S && (!cos || !sin)) return BYA_ERR_SHAPE;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)qw | (uintptr_t)kw |
          (uintptr_t)qb | (uintptr_t)kb) & 15) return BYA_ERR_ALIGN;
@@ -303,7 +304,8 @@ extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb,
         const char* e = getenv("BYA_QKNORM_TABLE_SC1");
         a.table_sc1 = e ? atoi(e) : 0;
     }
-    const long long total = ((long long)batch * S * heads * 2 + 7) / 8;      // waves: 8 (row, head) pairs each
+    a.only = !k ? 1 : !q ? 2 : 0;                                             // one tensor alone (the other pointer is NULL)
+    const long long total = ((long long)batch * S * heads * (a.only ? 1 : 2) + 7) / 8;      // waves: 8 (row, head) pairs each
     dim3 grid((unsigned)((total + 3) / 4));
     const char* dbg = getenv("BYA_QKNORM_DBG");
     const int d = dbg ? atoi(dbg) : 0;

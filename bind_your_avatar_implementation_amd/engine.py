@@ -522,14 +522,18 @@ class DenoiseEngine:
                         # RoPE run on the local rows, then rows are traded for heads (every element moves once)
                         self._dit_linear("qkv", i, xn[0], self.qkv_w[i], qkvb[0], bias=self.qkv_b[i], split=(Dl, S_loc * Dl),
                                          quantised=None if xq is None else (xq[0][0], xq[1][0]))
-                        # v needs no norm: its exchange runs on the RCCL stream underneath the q/k-norm + RoPE kernel
+                        # v needs no norm: its exchange runs on the RCCL stream underneath q's norm + RoPE, q's exchange
+                        # underneath k's; only k's is exposed (every exchange is enqueued on the communicator's stream,
+                        # the compute stream waits by event right before the attention launch)
                         pending = [sh.rows_to_heads(qkvb[2 * W:], vh, async_op=True)]
-                        ops.qknorm_rope(qkvb[:W], qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
-                                        at.norm_k.bias, cos, sin, heads=H // W,
-                                        text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
-                                        k_scale=self.k_scale)
-                        pending += [sh.rows_to_heads(qkvb[:W], qh, async_op=True),
-                                    sh.rows_to_heads(qkvb[W:2 * W], kh, async_op=True)]
+                        qk_kw = dict(heads=H // W, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
+                                     k_scale=self.k_scale)
+                        ops.qknorm_rope(qkvb[:W], None, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias,
+                                        cos, sin, **qk_kw)
+                        pending.append(sh.rows_to_heads(qkvb[:W], qh, async_op=True))
+                        ops.qknorm_rope(None, qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
+                                        at.norm_k.bias, cos, sin, **qk_kw)
+                        pending.append(sh.rows_to_heads(qkvb[W:2 * W], kh, async_op=True))
                         for h in pending:
                             if h is not None:
                                 h.wait()            # the compute stream waits (no host synchronisation)
@@ -572,14 +576,19 @@ class DenoiseEngine:
                 kv_l = face_kv[ca]
                 ntok = kv_l.shape[2]
                 pout = buf("pout", B, n_id, N_loc, inner_p)
-                ops.attention(qp, kv_l, kv_l[..., inner_p:], pout, head_dim=hd_p, heads=16, nb1=B, nb2=n_id, Sq=N_loc,
-                              Skv=ntok, q_strides=(N_loc * inner_p, 0, inner_p),
-                              k_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
-                              v_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
-                              o_strides=(n_id * N_loc * inner_p, N_loc * inner_p, inner_p), scale=hd_p ** -0.5)
+
+                def perceiver_attention():
+                    ops.attention(qp, kv_l, kv_l[..., inner_p:], pout, head_dim=hd_p, heads=16, nb1=B, nb2=n_id, Sq=N_loc,
+                                  Skv=ntok, q_strides=(N_loc * inner_p, 0, inner_p),
+                                  k_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
+                                  v_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
+                                  o_strides=(n_id * N_loc * inner_p, N_loc * inner_p, inner_p), scale=hd_p ** -0.5)
                 if forced is None:
-                    r_logits = self._router(qp, router_k[ca], ca, B, T, per_frame, n_id, sh, taps)
+                    # (sharded: the perceiver attention -- independent of the router -- is enqueued while the router's first
+                    # repartition exchange is in flight on the RCCL stream)
+                    r_logits = self._router(qp, router_k[ca], ca, B, T, per_frame, n_id, sh, taps, perceiver_attention)
                 else:
+                    perceiver_attention()
                     r_logits = forced
                 if self.mix_before_projection:
                     # to_out is linear and bias-free: route first, project once (half the GEMM, no feat round trip)
@@ -659,7 +668,7 @@ class DenoiseEngine:
             return ops.rowgemm512(a, rg[2], x, res=x)
         return ops.gemm(a, lin.weight, x, bias=lin.bias, res=x)
 
-    def _router(self, qp, kr, ca, B, T, per_frame, n_id, sh, taps):
+    def _router(self, qp, kr, ca, B, T, per_frame, n_id, sh, taps, overlap):
         """MultiIPRouter.forward (models/router.py:364-411) on the perceiver's q (shared by both ids) and the
         pre-projected router keys.  Returns this rank's rows of the routing logits, [B, N_loc, n_id] (sigmoid)."""
         m, buf = self.m, self._buf
@@ -669,7 +678,8 @@ class DenoiseEngine:
         qk = qp.shape[-1]
         if sh.active and n_id * T >= sh.world and per_frame >= sh.world and \
                 os.environ.get("BYA_ROUTER_REPLICATED", "0") != "1":
-            return self._router_sharded(qp, kr, ca, T, per_frame, n_id, sh, taps)
+            return self._router_sharded(qp, kr, ca, T, per_frame, n_id, sh, taps, overlap)
+        overlap()
         qn = buf("r_qn", B, N_loc, qk)
         ops.layernorm(qp, qn, self.r_nq_w, self.r_nq_b, eps=r.norm_q.eps)
         qr = ops.gemm(qn, self.r_to_q[ca], buf("r_qr", B, N_loc, qk))
@@ -717,7 +727,7 @@ class DenoiseEngine:
                 taps[f"router{ca}_b{b}"] = logits[b:b + 1].clone()
         return logits if not sh.active else logits[:, sh.v0:sh.v1].contiguous()
 
-    def _router_sharded(self, qp, kr, ca, T, per_frame, n_id, sh, taps):
+    def _router_sharded(self, qp, kr, ca, T, per_frame, n_id, sh, taps, overlap):
         """Multi-GPU form of ``_router`` (B = 1): the four SpatialTemporalAttentionBlocks run SHARDED.  Spatial attention in
         the frame-major partition (whole (id, frame) pairs per rank), everything else in the location-major partition
         (a range of within-frame locations for all frames and ids per rank), one all-to-all between them
@@ -754,7 +764,7 @@ class DenoiseEngine:
                           o_strides=(per_frame * F, 0, F), scale=hd ** -0.5)
             self._r_linres(ra_a, pk, "rg_spatial_attn", st.spatial_attn.to_out[0], xa2)
             # ---- location-major: temporal, multi-ID, MLP
-            rp.a_to_b(xa, xb)
+            rp.a_to_b(xa, xb, overlap=overlap if bi == 0 else None)
             xb2 = xb.view(RB, F)
             self._r_lnlin(xb2, rn_b, st.norm2, pk, "rg_temporal_attn", *pk["temporal_attn"], qkv_b)
             ops.attn_tiny(qkv_b, qkv_b[:, F:], qkv_b[:, 2 * F:], ra_b, T, heads, n_id, rp.nLB, T * rp.nLB, rp.nLB,

@@ -301,10 +301,10 @@ def layernorm_fp8(x, q, q_scale, weight=None, bias=None, eps=1e-5, shift0=None, 
 
 
 def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6, k_scale=1.0):
-    """In place on q, k [B, S, heads*64]."""
+    """In place on q, k [B, S, heads*64]; q or k may be None (only the other one is processed)."""
     lib = _hip.load()
-    b, S, _, bs, ld = _mat(q, "q")
-    assert _mat(k, "k") == _mat(q, "q")
+    b, S, _, bs, ld = _mat(q if q is not None else k, "q")
+    assert q is None or k is None or _mat(k, "k") == _mat(q, "q")
     if cos is not None:
         assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
         assert cos.shape == (S - text_rows, 64)

@@ -179,13 +179,19 @@ class SeqShard:
         return h if async_op else out
 
     def heads_to_rows(self, o_heads, out=None):
-        """o_heads [S, Dl] (all rows, this rank's heads) -> [S_loc, world*Dl] (this rank's rows, all heads)."""
+        """o_heads [S, Dl] (all rows, this rank's heads) -> [S_loc, world*Dl] (this rank's rows, all heads).  The
+        exchange is enqueued on the communicator's own stream like every other one here (``async_op``) and the compute
+        stream waits for it by event: nothing of the step is independent of the attention output, so there is nothing to
+        put underneath it -- what the side stream buys here is that the exchange never queues behind unrelated compute."""
         S, Dl = o_heads.shape
         recv = self.buf("h2r_recv", (self.world, self.S_loc, Dl), o_heads)
         if self.even:
-            self._a2a(recv.view(-1), o_heads.reshape(-1))
+            h = self._a2a(recv.view(-1), o_heads.reshape(-1), async_op=True)
         else:
-            self._a2a(recv.view(-1), o_heads.reshape(-1), [self.S_loc * Dl] * self.world, [n * Dl for n in self.sizes])
+            h = self._a2a(recv.view(-1), o_heads.reshape(-1), [self.S_loc * Dl] * self.world, [n * Dl for n in self.sizes],
+                          async_op=True)
+        if h is not None:
+            h.wait()
         if out is None:
             out = torch.empty(self.S_loc, self.world * Dl, dtype=o_heads.dtype, device=o_heads.device)
         out.view(self.S_loc, self.world, Dl).copy_(recv.permute(1, 0, 2))        # one strided copy, no temporaries
@@ -244,16 +250,19 @@ class RouterPartition:
         return t
 
     def _a2a(self, out, inp, out_splits, in_splits):
+        """Uneven all-to-all on the communicator's own stream; returns the handle whose ``wait()`` makes the compute stream
+        wait for it (None when the exchange was staged through the host, gloo)."""
         if inp.is_cuda and dist.get_backend(self.group) == "gloo":      # single-GPU functional test path
             host_out = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(host_out, inp.cpu(), out_splits, in_splits, group=self.group)
             out.copy_(host_out)
-        else:
-            _count("all_to_all")
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+            return None
+        _count("all_to_all_async")
+        return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
 
-    def a_to_b(self, xa, xb=None):
-        """xa [nPA, per_frame, F] -> xb [pairs, nLB, F]."""
+    def a_to_b(self, xa, xb=None, overlap=None):
+        """xa [nPA, per_frame, F] -> xb [pairs, nLB, F].  ``overlap``: a callable that enqueues independent work on the
+        compute stream; it runs while the exchange is in flight on the communicator's stream."""
         F = xa.shape[-1]
         in_splits = [self.nPA * (b - a) * F for a, b in self.LB]
         send = self.buf("a2b_send", (sum(in_splits),), xa)
@@ -264,7 +273,11 @@ class RouterPartition:
         if xb is None:
             xb = torch.empty(self.pairs, self.nLB, F, dtype=xa.dtype, device=xa.device)
         out_splits = [(b - a) * self.nLB * F for a, b in self.PA]
-        self._a2a(xb.view(-1), send, out_splits, in_splits)
+        h = self._a2a(xb.view(-1), send, out_splits, in_splits)
+        if overlap is not None:
+            overlap()
+        if h is not None:
+            h.wait()
         return xb
 
     def b_to_a(self, xb, xa=None):
@@ -275,7 +288,9 @@ class RouterPartition:
         in_splits = [(b - a) * self.nLB * F for a, b in self.PA]
         out_splits = [self.nPA * (b - a) * F for a, b in self.LB]
         recv = self.buf("b2a_recv", (sum(out_splits),), xb)
-        self._a2a(recv, xb.reshape(-1), out_splits, in_splits)
+        h = self._a2a(recv, xb.reshape(-1), out_splits, in_splits)
+        if h is not None:
+            h.wait()
         off = 0
         for a, b in self.LB:
             n = self.nPA * (b - a) * F

@@ -439,11 +439,20 @@ class BindyouravatarTransformer3DModel(nn.Module):
         if cfg is not None and hidden_states.shape[0] == 2:
             # CFG batch split: this rank computes one sample, the pair exchange restores the [uncond, cond] batch
             return (cfg.join(self._engine.step(*cfg.take(args))), None, None, None, None)
-        if self.use_hip_graph and getattr(self, "_seq_world", 1) == 1 and torch.is_tensor(timestep):
+        if self.use_hip_graph and torch.is_tensor(timestep) and self._graph_capturable():
             out = self._graphed_step(args)
         else:
             out = self._engine.step(*args)
         return (out, None, None, None, None)
+
+    def _graph_capturable(self):
+        """The sharded step is capturable when its exchanges are RCCL collectives (stream-ordered, capturable); the gloo
+        path of the functional tests stages through host memory and is not."""
+        group = getattr(self, "_seq_group", None)
+        if getattr(self, "_seq_world", 1) == 1 and group is None:
+            return True
+        import torch.distributed as dist
+        return dist.is_initialized() and dist.get_backend(group) == "nccl"
 
     # ---- explicit step-invariant conditioning cache (SURVEY.md section 8f row 2) ---------------------------------
     def precompute_conditioning(self, id_cond=None, id_vit_hidden=None, audio_embeds=None, latent_frames=13):

@@ -138,7 +138,9 @@ int bya_layernorm(const void* x, void* y, const void* w, const void* b, const vo
  * (diffusers CogVideoXAttnProcessor2_0 + apply_rotary_emb; models/transformer.py:204-208).  In place.
  * q,k: [batch, S, heads*64] with row stride ld; cos,sin: fp32 [S - text_rows, 64].
  * k_scale (0 or 1 = off): the finished k is multiplied by it in fp32 before its single rounding to bf16 -- the engine
- * folds softmax_scale*log2(e) into k here so that bya_attn_fwd can run with scores_prescaled = 1. */
+ * folds softmax_scale*log2(e) into k here so that bya_attn_fwd can run with scores_prescaled = 1.
+ * q or k (not both) may be NULL: only the other tensor is processed (the sharded step norms q, starts q's exchange on
+ * the RCCL stream and norms k underneath it). */
 int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb, const void* kw, const void* kb,
                     const float* cos, const float* sin, int32_t batch, int32_t S, int32_t heads, int64_t ld,
                     int64_t batch_stride, int32_t text_rows, float eps, float k_scale, hipStream_t stream);
