@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
     const long long pair = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (lane >> 3);
     if (pair >= (p.only ? 1 : 2) * pairs_per_tensor) return;
     const int which = p.only ? p.only - 1 : (pair >= pairs_per_tensor);      // 0 = q, 1 = k
-    long long rest = pair - which * pairs_per_tensor;
+    long long rest = p.only ? pair : pair - which * pairs_per_tensor;
     int head, s, z;
     if constexpr (DBG == 2) {
         const unsigned r32 = (unsigned)rest, h32 = (unsigned)p.heads, S32 = (unsigned)p.S;

@@ -1,0 +1,256 @@
+// Video VAE either side of the denoise loop: the data-movement and normalisation kernels
+// of AutoencoderKLCogVideoX's decoder / encoder (diffusers, called at models/pipeline_bindyouravatar.py:406-424 and
+// :461-466).  Activations are CHANNELS-LAST bf16 [T, H, W, C]: a 1x1x1 convolution is a plain GEMM on them, a causal
+// 3x3x3 (or per-frame 3x3) convolution is  patches[rows, taps * C] x W[C_out, taps * C]^T  on bya_gemm_bf16 with the bias
+// and the residual in its epilogue; this file gathers the patches, computes the GroupNorm statistics and applies
+// GroupNorm (+ the decoder's spatial modulation) + SiLU in one pass.  All HBM-bound; no MFMA here (built without packed
+// fp32, like the other VALU units).
+//
+// bya_vae_patches: rows = output positions (t, h, w) of the frames [t0, t0 + nt) of a chunk; column (kt, kh, kw, c).
+//   * time is CAUSAL: tap kt of output frame t reads frame t + kt - (KT - 1) of the chunk; negative indices fall into
+//     the cache of the previous chunk (its last KT - 1 frames) or, for the first chunk, onto frame 0 (diffusers
+//     CogVideoXCausalConv3d, pad_mode "first");
+//   * space: tap (kh, kw) of output (h, w) reads (h * stride + kh - pad, w * stride + kw - pad) of the SOURCE GRID, zero
+//     outside (pad = 1: the 3x3x3 and up-sampler convolutions; pad = 0, stride 2: the down-sampler, whose (0, 1, 0, 1)
+//     zero pad is the out-of-range case at the far edge);
+//   * the source grid may be a nearest-neighbour up-sampling of the stored tensor (up = 1: h >> 1, w >> 1; time by
+//     tmode: 0 same frame, 1 every frame doubled, 2 first frame single and the rest doubled) -- CogVideoXUpsample3D's
+//     F.interpolate is never materialised.
+// bya_vae_groupnorm_stats: per (group) sum and sum of squares over a chunk's rows, fp32 atomics into [groups][2].
+// bya_vae_norm_act: y = act( (x - mean_g) rstd_g gamma_c + beta_c ) with, for the decoder,
+//   ... * Y[z(row)][c] + B[z(row)][c]  (CogVideoXSpatialNorm3D: conv_y / conv_b of the latent are 1x1x1, hence commute
+//   with its nearest resize: they are evaluated at latent resolution by a GEMM and indexed here).
+#include "bya_common.h"
+#include "../../include/bya.h"
+
+namespace {
+
+struct PatchArgs {
+    const bf16_t* x;        // stored tensor [Ts, Hs, Ws, C]
+    const bf16_t* cache;    // [KT - 1, Hs, Ws, C] of the previous chunk or null
+    bf16_t* out;            // [nt * Ho * Wo, Kpad]
+    int Ts, Hs, Ws, C, KT, stride, pad, up, tmode, Ho, Wo, t0, nt, Kpad;
+};
+
+__device__ __forceinline__ int src_frame(int tau, int tmode) {       // frame of the up-sampled grid -> stored frame
+    return tmode == 0 ? tau : tmode == 1 ? (tau >> 1) : (tau == 0 ? 0 : 1 + ((tau - 1) >> 1));
+}
+
+// one thread = one 16-byte piece (8 channels) of one (row, tap); C % 8 == 0
+__global__ __launch_bounds__(256) void vae_patches_kernel(PatchArgs p) {
+    const int cpt = p.C >> 3;                              // pieces per tap
+    const int taps = p.KT * 9;
+    const int ppr = p.Kpad >> 3;                           // pieces per row (incl. zero padding behind the last tap)
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.nt * p.Ho * p.Wo * ppr;
+    if (idx >= total) return;
+    const int piece = (int)(idx % ppr);
+    long long row = idx / ppr;
+    const int w = (int)(row % p.Wo); row /= p.Wo;
+    const int h = (int)(row % p.Ho);
+    const int t = (int)(row / p.Ho) + p.t0;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    const int tap = piece / cpt, c8 = piece - tap * cpt;
+    if (tap < taps) {
+        const int kt = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+        const int hs = h * p.stride + kh - p.pad, ws = w * p.stride + kw - p.pad;     // on the (maybe up-sampled) grid
+        const int Hg = p.up ? p.Hs * 2 : p.Hs, Wg = p.up ? p.Ws * 2 : p.Ws;
+        if (hs >= 0 && hs < Hg && ws >= 0 && ws < Wg) {
+            const int hh = p.up ? hs >> 1 : hs, ww = p.up ? ws >> 1 : ws;
+            int tau = t + kt - (p.KT - 1);
+            const bf16_t* base;
+            if (tau >= 0) {
+                base = p.x + (((long long)src_frame(tau, p.tmode) * p.Hs + hh) * p.Ws + ww) * p.C;
+            } else if (p.cache) {
+                base = p.cache + (((long long)(tau + p.KT - 1) * p.Hs + hh) * p.Ws + ww) * p.C;
+            } else {
+                base = p.x + ((long long)hh * p.Ws + ww) * p.C;                   // first chunk: its first frame again
+            }
+            v = *reinterpret_cast<const u32x4*>(base + c8 * 8);
+        }
+    }
+    *reinterpret_cast<u32x4*>(p.out + (idx << 3)) = v;
+}
+
+// C < 8 (the encoder's RGB input): one thread per (row, tap), scalar copies
+__global__ __launch_bounds__(256) void vae_patches_small_kernel(PatchArgs p) {
+    const int taps = p.KT * 9;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long rows = (long long)p.nt * p.Ho * p.Wo;
+    const int slots = (p.Kpad + p.C - 1) / p.C;           // taps + zero slots up to Kpad
+    if (idx >= rows * slots) return;
+    const int tap = (int)(idx % slots);
+    long long row = idx / slots;
+    bf16_t* dst = p.out + row * p.Kpad + (long long)tap * p.C;
+    const int n = (tap * p.C + p.C <= p.Kpad) ? p.C : p.Kpad - tap * p.C;
+    const int w = (int)(row % p.Wo); row /= p.Wo;
+    const int h = (int)(row % p.Ho);
+    const int t = (int)(row / p.Ho) + p.t0;
+    const bf16_t* base = nullptr;
+    if (tap < taps) {
+        const int kt = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+        const int hs = h * p.stride + kh - p.pad, ws = w * p.stride + kw - p.pad;
+        if (hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws) {
+            const int tau = t + kt - (p.KT - 1);
+            if (tau >= 0) base = p.x + (((long long)tau * p.Hs + hs) * p.Ws + ws) * p.C;
+            else if (p.cache) base = p.cache + (((long long)(tau + p.KT - 1) * p.Hs + hs) * p.Ws + ws) * p.C;
+            else base = p.x + ((long long)hs * p.Ws + ws) * p.C;
+        }
+    }
+    for (int c = 0; c < n; ++c) dst[c] = base ? base[c] : (bf16_t)0;
+}
+
+// ---- GroupNorm statistics: block = 256 rows x all channels; lane owns 8 channels of a row, reduces over its rows, then
+// the channels of a group (cg = C / groups channels, a multiple of 1; lanes of a group are adjacent), one atomic pair per
+// (block, group).
+__global__ __launch_bounds__(256) void vae_gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ sums, long long rows,
+                                                           int C, int groups) {
+    extern __shared__ float red[];                         // [groups][2]
+    const int cpr = C >> 3;                                // 16-byte pieces per row
+    const int tid = threadIdx.x;
+    for (int i = tid; i < groups * 2; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const int cg = C / groups;
+    constexpr int ROWS_PER_BLOCK = 512;
+    const long long r0 = (long long)blockIdx.x * ROWS_PER_BLOCK;
+    const long long pieces = (long long)ROWS_PER_BLOCK * cpr;
+    for (long long i = tid; i < pieces; i += 256) {
+        const long long r = r0 + i / cpr;
+        if (r >= rows) break;
+        const int c8 = (int)(i % cpr);
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + r * C + c8 * 8), v);
+        if (cg >= 8) {                                     // the 8 channels share a group
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s += v[e]; q += v[e] * v[e]; }
+            const int g = (c8 * 8) / cg;
+            atomicAdd(&red[2 * g], s);
+            atomicAdd(&red[2 * g + 1], q);
+        } else {                                           // 1, 2 or 4 channels per group
+#pragma unroll
+            for (int e0 = 0; e0 < 8; e0 += 1) {
+                if (e0 % cg) continue;
+                float s = 0.f, q = 0.f;
+                for (int e = e0; e < e0 + cg; ++e) { s += v[e]; q += v[e] * v[e]; }
+                const int g = (c8 * 8 + e0) / cg;
+                atomicAdd(&red[2 * g], s);
+                atomicAdd(&red[2 * g + 1], q);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < groups * 2; i += 256) atomicAdd(&sums[i], red[i]);
+}
+
+struct NormArgs {
+    const bf16_t* x; bf16_t* y; const float* sums; const bf16_t* gamma; const bf16_t* beta;
+    const bf16_t* zy; const bf16_t* zb;      // [Tz * hz * wz, C] each (decoder) or null
+    long long rows;
+    int C, groups, act;
+    float count, eps;                        // elements per group of the chunk
+    int T, H, W, Tz, hz, wz, shift, tmode;   // row -> (t, h, w) -> latent position (h >> shift, w >> shift, frame by tmode)
+    int ldz;                                 // row stride of zy / zb (they may be the two halves of one GEMM output)
+};
+
+__global__ __launch_bounds__(256) void vae_norm_act_kernel(NormArgs p) {
+    const int cpr = p.C >> 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.rows * cpr) return;
+    const long long r = idx / cpr;
+    const int c0 = (int)(idx % cpr) * 8;
+    float v[8], gm[8], bt[8];
+    unpack8(*reinterpret_cast<const u32x4*>(p.x + r * p.C + c0), v);
+    unpack8(*reinterpret_cast<const u32x4*>(p.gamma + c0), gm);
+    unpack8(*reinterpret_cast<const u32x4*>(p.beta + c0), bt);
+    const int cg = p.C / p.groups;
+    float zy[8], zb[8];
+    if (p.zy) {
+        long long rr = r;
+        const int w = (int)(rr % p.W); rr /= p.W;
+        const int h = (int)(rr % p.H);
+        const int t = (int)(rr / p.H);
+        // latent frame of frame t: tmode 0: same count; 1: t * Tz / T (even resize); 2: first frame apart
+        int tz;
+        if (p.tmode == 0) tz = t;
+        else if (p.tmode == 1) tz = (int)(((long long)t * p.Tz) / p.T);
+        else tz = t == 0 ? 0 : 1 + (int)(((long long)(t - 1) * (p.Tz - 1)) / (p.T - 1));
+        const long long zr = ((long long)tz * p.hz + (h >> p.shift)) * p.wz + (w >> p.shift);
+        unpack8(*reinterpret_cast<const u32x4*>(p.zy + zr * p.ldz + c0), zy);
+        unpack8(*reinterpret_cast<const u32x4*>(p.zb + zr * p.ldz + c0), zb);
+    }
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c0 + e) / cg;
+        const float mean = p.sums[2 * g] / p.count;
+        const float var = fmaxf(p.sums[2 * g + 1] / p.count - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        float y = (v[e] - mean) * rstd * gm[e] + bt[e];
+        if (p.zy) y = y * zy[e] + zb[e];
+        if (p.act == 1) y = y / (1.0f + __expf(-y));      // SiLU
+        o[e] = y;
+    }
+    *reinterpret_cast<u32x4*>(p.y + r * p.C + c0) = pack8(o);
+}
+
+}  // namespace
+
+extern "C" int bya_vae_patches(const void* x, const void* cache, void* out, int32_t Ts, int32_t Hs, int32_t Ws, int32_t C,
+                               int32_t KT, int32_t stride, int32_t pad, int32_t up, int32_t tmode, int32_t Ho, int32_t Wo,
+                               int32_t t0, int32_t nt, int32_t Kpad, hipStream_t stream) {
+    if (!x || !out || Ts <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || nt <= 0 || Ho <= 0 || Wo <= 0) return BYA_ERR_SHAPE;
+    if ((KT != 1 && KT != 3) || (stride != 1 && stride != 2) || (pad != 0 && pad != 1) || tmode < 0 || tmode > 2) return BYA_ERR_SHAPE;
+    if (Kpad < KT * 9 * C || Kpad % 8) return BYA_ERR_SHAPE;
+    if (up && stride != 1) return BYA_ERR_UNSUPPORTED;
+    PatchArgs p{(const bf16_t*)x, (const bf16_t*)cache, (bf16_t*)out, Ts, Hs, Ws, C, KT, stride, pad, up, tmode, Ho, Wo, t0, nt, Kpad};
+    const long long rows = (long long)nt * Ho * Wo;
+    if (C % 8 == 0) {
+        if (((uintptr_t)x | (uintptr_t)cache | (uintptr_t)out) & 15) return BYA_ERR_ALIGN;
+        const long long total = rows * (Kpad >> 3);
+        BYA_LAUNCH(vae_patches_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    } else {
+        if (up) return BYA_ERR_UNSUPPORTED;
+        const long long total = rows * ((Kpad + C - 1) / C);
+        BYA_LAUNCH(vae_patches_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    }
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+extern "C" int bya_vae_groupnorm_stats(const void* x, float* sums, int64_t rows, int32_t C, int32_t groups, hipStream_t stream) {
+    if (!x || !sums || rows <= 0 || C <= 0 || groups <= 0 || C % groups || C % 8) return BYA_ERR_SHAPE;
+    const int cg = C / groups;
+    if (!(cg >= 8 ? cg % 8 == 0 : (cg == 1 || cg == 2 || cg == 4))) return BYA_ERR_UNSUPPORTED;
+    if ((uintptr_t)x & 15) return BYA_ERR_ALIGN;
+    if (hipMemsetAsync(sums, 0, (size_t)groups * 2 * sizeof(float), stream) != hipSuccess) return BYA_ERR_LAUNCH;
+    const long long blocks = (rows + 511) / 512;
+    BYA_LAUNCH(vae_gn_stats_kernel, dim3((unsigned)blocks), dim3(256), (size_t)groups * 2 * sizeof(float), stream,
+               (const bf16_t*)x, sums, (long long)rows, C, groups);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+extern "C" int bya_vae_norm_act(const void* x, void* y, const float* sums, const void* gamma, const void* beta, const void* zy,
+                                const void* zb, int64_t rows, int32_t C, int32_t groups, int32_t act, float eps, int32_t T,
+                                int32_t H, int32_t W, int32_t Tz, int32_t hz, int32_t wz, int32_t tmode, int64_t ldz,
+                                hipStream_t stream) {
+    if (!x || !y || !sums || !gamma || !beta || rows <= 0 || C <= 0 || groups <= 0 || C % groups || C % 8) return BYA_ERR_SHAPE;
+    if ((zy == nullptr) != (zb == nullptr)) return BYA_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)zy | (uintptr_t)zb) & 15) return BYA_ERR_ALIGN;
+    NormArgs p{};
+    p.x = (const bf16_t*)x; p.y = (bf16_t*)y; p.sums = sums; p.gamma = (const bf16_t*)gamma; p.beta = (const bf16_t*)beta;
+    p.zy = (const bf16_t*)zy; p.zb = (const bf16_t*)zb; p.rows = rows; p.C = C; p.groups = groups; p.act = act;
+    p.count = (float)((double)rows * (C / groups)); p.eps = eps;
+    p.T = T; p.H = H; p.W = W; p.Tz = Tz; p.hz = hz; p.wz = wz; p.tmode = tmode; p.ldz = (int)ldz;
+    if (zy) {
+        if ((long long)T * H * W != rows || hz <= 0 || wz <= 0 || H % hz || W % wz || H / hz != W / wz || ldz % 8) return BYA_ERR_SHAPE;
+        int sh = 0;
+        while ((hz << sh) < H) ++sh;
+        if ((hz << sh) != H) return BYA_ERR_SHAPE;
+        p.shift = sh;
+        if (tmode == 0 && Tz != T) return BYA_ERR_SHAPE;
+        if (tmode == 2 && (T < 2 || Tz < 2)) return BYA_ERR_SHAPE;
+    }
+    const long long total = rows * (C >> 3);
+    BYA_LAUNCH(vae_norm_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}

@@ -522,3 +522,43 @@ def rowgemm512(x, pack, out, res=None, act=None, eps=1e-5, nsplit=0):
                              float(eps), ACT[act], int(nsplit), _stream()), "bya_rowgemm512")
     _end(tok)
     return out
+
+
+# ---- video VAE (csrc/vae.hip) ----------------------------------------------------------
+def vae_patches(x, cache, out, KT, stride, pad, up, tmode, Ho, Wo, t0, nt):
+    """Patch matrix of a causal KT x 3 x 3 convolution over channels-last x [Ts, Hs, Ws, C] -> out [nt * Ho * Wo, Kpad]."""
+    lib = _hip.load()
+    Ts, Hs, Ws, C = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and x.dtype == out.dtype == torch.bfloat16
+    assert cache is None or (cache.is_contiguous() and tuple(cache.shape) == (KT - 1, Hs, Ws, C))
+    assert out.shape[0] == nt * Ho * Wo
+    tok = _begin("bya_vae_patches")
+    check(lib.bya_vae_patches(_p(x), _p(cache), _p(out), Ts, Hs, Ws, C, KT, stride, pad, int(up), tmode, Ho, Wo, t0, nt,
+                              out.shape[1], _stream()), "bya_vae_patches")
+    _end(tok)
+    return out
+
+
+def vae_groupnorm_stats(x2d, sums, groups):
+    lib = _hip.load()
+    rows, C = x2d.shape
+    assert x2d.is_contiguous() and sums.dtype == torch.float32 and sums.numel() == 2 * groups
+    tok = _begin("bya_vae_groupnorm_stats")
+    check(lib.bya_vae_groupnorm_stats(_p(x2d), _p(sums), rows, C, groups, _stream()), "bya_vae_groupnorm_stats")
+    _end(tok)
+    return sums
+
+
+def vae_norm_act(x, y, sums, gamma, beta, groups, act="silu", eps=1e-6, zy=None, zb=None, latent_shape=None, tmode=1):
+    """x, y: [T, H, W, C] channels-last; zy / zb: [Tz * hz * wz, C] views (row stride = their .stride(0))."""
+    lib = _hip.load()
+    T, H, W, C = x.shape
+    assert x.is_contiguous() and y.is_contiguous()
+    Tz, hz, wz = latent_shape if latent_shape is not None else (T, H, W)
+    ldz = zy.stride(0) if zy is not None else 0
+    tok = _begin("bya_vae_norm_act")
+    check(lib.bya_vae_norm_act(_p(x), _p(y), _p(sums), _p(gamma), _p(beta), _p(zy), _p(zb), T * H * W, C, groups,
+                               {None: 0, "none": 0, "silu": 1}[act], float(eps), T, H, W, Tz, hz, wz, tmode, ldz,
+                               _stream()), "bya_vae_norm_act")
+    _end(tok)
+    return y

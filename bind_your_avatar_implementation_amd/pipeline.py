@@ -163,11 +163,19 @@ class DPMScheduler(_SchedulerBase):
 class BindyouravatarPipeline:
     """See module docstring.  ``transformer``: ``BindyouravatarTransformer3DModel`` of this package."""
 
-    def __init__(self, transformer, scheduler=None, vae_scale_factor_spatial=8, vae_scale_factor_temporal=4):
+    def __init__(self, transformer, scheduler=None, vae_scale_factor_spatial=8, vae_scale_factor_temporal=4, vae=None):
         self.transformer = transformer
         self.scheduler = scheduler or DDIMScheduler()
+        # ``vae``: a ``BindyouravatarVAE`` (this package's AutoencoderKLCogVideoX on the HIP kernels).  With it the pipeline
+        # takes ``image`` / ``image_bg`` (encoded like the reference's prepare_latents, models/pipeline_bindyouravatar.py
+        # :406-424) and returns frames (``decode_latents``, :461-466); without it, latents in and latents out.
+        self.vae = vae
+        if vae is not None:                                   # reference :231-240
+            vae_scale_factor_spatial = 2 ** (len(vae.config.block_out_channels) - 1)
+            vae_scale_factor_temporal = vae.config.temporal_compression_ratio
         self.vae_scale_factor_spatial = vae_scale_factor_spatial
         self.vae_scale_factor_temporal = vae_scale_factor_temporal
+        self.vae_scaling_factor_image = vae.config.scaling_factor if vae is not None else 0.7
         self._guidance_scale, self._interrupt, self._num_timesteps = 1.0, False, 0
 
     def fuse_lora(self, lora_scale=1.0, **kw):
@@ -200,11 +208,15 @@ class BindyouravatarPipeline:
         if num_frames > max_frames:     # reference :739-742 with its constant 49 = the stock config's sample_frames
             raise ValueError(f"The number of frames must be less than {max_frames} for now due to static positional "
                              "embeddings. This will be updated in the future to remove this limitation.")
-        if prompt is not None or negative_prompt is not None or image is not None or image_bg is not None:
-            raise NotImplementedError("T5 / VAE are outside the hot path: pass prompt_embeds, negative_prompt_embeds, "
-                                      "image_latents (and image_bg_latents) as tensors")
-        if output_type != "latent":
-            raise NotImplementedError("VAE decode is outside the hot path: use output_type='latent'")
+        if prompt is not None or negative_prompt is not None:
+            raise NotImplementedError("the T5 text encoder is outside the hot path: pass prompt_embeds / negative_prompt_embeds")
+        if (image is not None or image_bg is not None or output_type != "latent") and self.vae is None:
+            raise NotImplementedError("pass vae=BindyouravatarVAE(...) to the pipeline to encode `image` / `image_bg` and to "
+                                      "decode frames; without it give image_latents and use output_type='latent'")
+        if image is not None and image_latents is None:        # reference prepare_latents: posterior SAMPLE of the frame
+            image_latents = self.encode_image(image, generator)
+        if image_bg is not None and image_bg_latents is None:
+            image_bg_latents = self.encode_image(image_bg, generator)
         if prompt_embeds is None or image_latents is None:
             raise ValueError("prompt_embeds and image_latents are required")
         tr = self.transformer
@@ -224,7 +236,14 @@ class BindyouravatarPipeline:
             latents = torch.randn(shape, generator=generator, device=dev if generator is None else generator.device)
         latents = latents.to(dev, dtype)
         assert tuple(latents.shape) == shape, (tuple(latents.shape), shape)
-        image_latents = image_latents.to(dev, dtype)
+        def pad_frames(lat):        # the encoded frame first, zeros for the frames to generate (reference :426-446)
+            lat = lat.to(dev, dtype)
+            if lat.shape[1] < lat_frames:
+                lat = torch.cat([lat, lat.new_zeros(lat.shape[0], lat_frames - lat.shape[1], *lat.shape[2:])], dim=1)
+            return lat
+        image_latents = pad_frames(image_latents)
+        if image_bg_latents is not None:
+            image_bg_latents = pad_frames(image_bg_latents)
         if image_bg_latents is None or not use_inpaint:
             image_bg_latents = torch.zeros_like(image_latents) if tr.config.in_channels == 3 * ch else None
         elif image_bg_latents is not None:
@@ -286,6 +305,17 @@ class BindyouravatarPipeline:
         if torch.device(dev).type == "cuda":    # end of the clip: no split-K hand-off timed out on the way (one sync, once)
             from . import ops
             ops.check_gemm_workspace(dev)
+        if output_type != "latent":
+            latents = self.decode_latents(latents)             # [B, 3, F, H, W] in the VAE's value range (about [-1, 1])
         if not return_dict:
             return (latents,)
         return SimpleNamespace(frames=latents)
+
+    def encode_image(self, image, generator=None):
+        """image [B, 3, H, W] in [-1, 1] -> scaled latents [B, 1, C, H / 8, W / 8] (reference :406-424, one frame)."""
+        dist = self.vae.encode(image.unsqueeze(2)).latent_dist
+        return self.vae_scaling_factor_image * dist.sample(generator).permute(0, 2, 1, 3, 4)
+
+    def decode_latents(self, latents):
+        """reference :461-466."""
+        return self.vae.decode(latents.permute(0, 2, 1, 3, 4) / self.vae_scaling_factor_image).sample

@@ -287,6 +287,33 @@ int bya_masks_to_routing_logits(const void* masks, void* logits, int32_t n_id, i
                                 int32_t in_w, int32_t frames, int32_t h, int32_t w, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Video VAE either side of the denoise loop: AutoencoderKLCogVideoX (diffusers; un-vendored
+ * third-party layer) as called by models/pipeline_bindyouravatar.py:406-424 (encode of the conditioning frame) and :461-466
+ * (decode of the finished latents).  Activations are channels-last bf16 [T, H, W, C]; every convolution is
+ * bya_vae_patches + bya_gemm_bf16 (bias / residual in its epilogue), 1x1x1 convolutions are bya_gemm_bf16 alone.
+ * --------------------------------------------------------------------------------------------- */
+/* Patch matrix of a causal KT x 3 x 3 convolution (KT = 3: CogVideoXCausalConv3d; KT = 1: the per-frame 3 x 3 convolutions of
+ * CogVideoXUpsample3D / CogVideoXDownsample3D) for output frames [t0, t0 + nt) of a chunk: out [nt * Ho * Wo, Kpad] bf16, column
+ * (kt, kh, kw, c), zero beyond KT * 9 * C.  x: the chunk [Ts, Hs, Ws, C]; cache: the previous chunk's last KT - 1 frames
+ * [KT - 1, Hs, Ws, C] or NULL (first chunk: frame 0 is repeated -- diffusers pad_mode "first").  Space: tap (kh, kw) of output
+ * (h, w) reads (h * stride + kh - pad, w * stride + kw - pad), zero outside.  up = 1: the convolution runs on the
+ * nearest-neighbour x2 up-sampling of x in space (never materialised) and in time by tmode: 0 = frames as stored, 1 = every
+ * frame doubled, 2 = first frame single, the rest doubled (CogVideoXUpsample3D.compress_time with an odd frame count). */
+int bya_vae_patches(const void* x, const void* cache, void* out, int32_t Ts, int32_t Hs, int32_t Ws, int32_t C, int32_t KT,
+                    int32_t stride, int32_t pad, int32_t up, int32_t tmode, int32_t Ho, int32_t Wo, int32_t t0, int32_t nt,
+                    int32_t Kpad, hipStream_t stream);
+/* GroupNorm statistics of one chunk: sums [groups][2] fp32 = (sum, sum of squares) over x [rows, C] (zeroed here). */
+int bya_vae_groupnorm_stats(const void* x, float* sums, int64_t rows, int32_t C, int32_t groups, hipStream_t stream);
+/* y = act( GroupNorm(x; sums, gamma, beta, eps) [ * zy[z(row)] + zb[z(row)] ] ), act 0 = none, 1 = SiLU.  zy / zb (both or
+ * neither): conv_y / conv_b of CogVideoXSpatialNorm3D evaluated at LATENT resolution [Tz * hz * wz rows, row stride ldz]; row
+ * (t, h, w) of x [T, H, W, C] reads latent position (frame by tmode, h >> log2(H / hz), w >> log2(W / wz)): tmode 0 = same
+ * frame, 1 = floor(t Tz / T), 2 = first frame apart (0 -> 0, t -> 1 + floor((t - 1)(Tz - 1) / (T - 1))): torch's nearest
+ * F.interpolate, first frame and the rest resized separately when T is odd and > 1. */
+int bya_vae_norm_act(const void* x, void* y, const float* sums, const void* gamma, const void* beta, const void* zy,
+                     const void* zb, int64_t rows, int32_t C, int32_t groups, int32_t act, float eps, int32_t T, int32_t H,
+                     int32_t W, int32_t Tz, int32_t hz, int32_t wz, int32_t tmode, int64_t ldz, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Multi-GPU exchanges of the sharded step over RCCL.  ``comm`` is the caller's ncclComm_t (one
  * process per GPU); both calls only ENQUEUE on ``stream`` -- give them a stream of their own to overlap with compute.
  * The reference has no inference parallelism; these have no counterpart there.  (The Python module of this package
