@@ -31,6 +31,12 @@ class AttnDesc(_c.Structure):
                 ("scale", _f32), ("scores_prescaled", _i32), ("score_bound", _f32)]
 
 
+class AttnMixDesc(_c.Structure):
+    _fields_ = [("head_dim", _i32), ("heads", _i32), ("n_id", _i32), ("n_grp", _i32), ("Sq", _i32), ("Skv", _i32),
+                ("q_grp", _i64), ("q_row", _i64), ("k_id", _i64), ("k_grp", _i64), ("k_row", _i64),
+                ("v_id", _i64), ("v_grp", _i64), ("v_row", _i64), ("z_grp", _i64), ("z_row", _i64), ("scale", _f32)]
+
+
 class SchedCoef(_c.Structure):
     _fields_ = [("guidance", _f32), ("sqrt_alpha", _f32), ("sqrt_beta", _f32), ("k_sample", _f32),
                 ("k_denoised", _f32), ("k_noise", _f32), ("k_cur", _f32), ("k_old", _f32)]
@@ -54,6 +60,7 @@ SIGNATURES = {
     "bya_qknorm_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _f32, _vp],
     "bya_attn_fwd": [_vp, _vp, _vp, _vp, _c.POINTER(AttnDesc), _vp],
     "bya_attn_variant": [_c.POINTER(AttnDesc)],
+    "bya_attn_kv_mix": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(AttnMixDesc), _vp],
     "bya_attn_tiny": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
     "bya_router_scores": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp],
     "bya_router_head": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp],
@@ -66,7 +73,7 @@ SIGNATURES = {
     "bya_rowgemm512": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp],
     "bya_masks_to_routing_logits": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "bya_vae_patches": [_vp, _vp, _vp] + [_i32] * 14 + [_vp],
-    "bya_vae_groupnorm_stats": [_vp, _vp, _i64, _i32, _i32, _vp],
+    "bya_vae_groupnorm_stats": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "bya_vae_norm_act": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32, _i32,
                          _i32, _i64, _vp],
     "bya_allgather_kv": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],

@@ -14,6 +14,7 @@
 // and the S^T accumulator is directly the B operand of O^T += V^T.P^T (no LDS round trip for P).
 // Blocks of one (batch, head) are dealt to one XCD so its K/V stream is served by that XCD's L2.
 #include "attn_common.h"
+#include "routing_weights.h"
 #include <stdlib.h>
 
 namespace {
@@ -435,6 +436,129 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Cross-attention onto a handful of keys per identity, with the router's masked combine in its epilogue
+// (bya_attn_kv_mix): the audio cross-attention (32 keys per latent frame and identity, 48 heads of 64;
+// models/audio_model.py:247-258) and the face Perceiver cross-attention (32 face tokens per identity, 16 heads of 128;
+// models/router.py:255-270).  Both are followed in the reference by  hidden += sum_id w[n, id] * to_out(o[id, n, :])
+// (models/transformer.py:821-832, 895-936); to_out is linear, so the engine mixes first and projects once --
+// and the mix needs nothing but the attention outputs of ONE token.  Unfused that was: attention writes o for every
+// identity (2 x 108 MB), bya_routed_mix reads them back and writes z.  Here a workgroup holds its 128 query rows (shared
+// by all identities), runs the one-tile attention once per identity on the K / V of that identity and accumulates
+//     z = sum_id w[n, id] * (O_id / l_id)      in fp32, rounded to bf16 once,
+// so o never reaches HBM: q is read once, z written once.  The per-identity attention is attn_tile<TAIL> of the generic
+// kernel above (single tile, running maximum, keys past Skv masked), the weights are routing_weights.h.
+struct MixArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* z; const bf16_t* r; const bf16_t* af; float* wsum;
+    int heads, n_id, n_grp, Sq, Skv, nqt, mode;
+    long long q_grp, q_row, k_id, k_grp, k_row, v_id, v_grp, v_row, z_grp, z_row;
+    float scale_log2;
+};
+
+template <int D>
+__device__ __forceinline__ void attn_mix_body(const MixArgs& p, char* smem) {
+    constexpr int ROW_BYTES = D * 2, TILE_BYTES = KV_TILE * ROW_BYTES, DSTEPS = D / 16, DT = D / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hf = lane >> 5;
+    int bid = blockIdx.x;
+    const int qt = bid % p.nqt; bid /= p.nqt;
+    const int head = bid % p.heads;
+    const int grp = bid / p.heads;
+    const bf16_t* Q = p.q + grp * p.q_grp + (long long)head * D;
+    bf16_t* Z = p.z + grp * p.z_grp + (long long)head * D;
+    const int q0 = qt * Q_PER_BLOCK + wave * Q_PER_WAVE;
+    int qrow = q0 + r;
+    const bool q_valid = qrow < p.Sq;
+    qrow = q_valid ? qrow : p.Sq - 1;
+    bf16x8 qf[DSTEPS];
+#pragma unroll
+    for (int s = 0; s < DSTEPS; ++s)
+        qf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Q + (long long)qrow * p.q_row + s * 16 + hf * 8));
+    float w[4];
+    routing_weights_of(p.mode, p.n_id, p.af, p.r + ((long long)grp * p.Sq + qrow) * p.n_id, w);
+    if (p.wsum && head == 0 && hf == 0 && q_valid) {
+        float ws = 0.f;
+        for (int i = 0; i < p.n_id; ++i) ws += w[i];
+        p.wsum[(long long)grp * p.Sq + qrow] = ws;
+    }
+
+    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    uint32_t voff[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        const int row = 4 * hf + tq;
+        const int chunk = 4 * d + 2 * (g & 1) + (tp >> 1);
+        voff[d] = row * ROW_BYTES + ((chunk ^ vswz<D>(row)) << 4) + (tp & 1) * 8;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)((hf == 0 && e < 2) ? 1.0f : 0.0f);
+
+    f32x16 zacc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zacc[d][i] = 0.f;
+    for (int id = 0; id < p.n_id; ++id) {
+        const bf16_t* K = p.k + id * p.k_id + grp * p.k_grp + (long long)head * D;
+        const bf16_t* V = p.v + id * p.v_id + grp * p.v_grp + (long long)head * D;
+        char* st = smem + (id & 1) * 2 * TILE_BYTES;           // two stages: identity id + 1 lands while id computes
+        if (id == 0) {
+            stage_kv<D, false>(K, p.k_row, 0, p.Skv - 1, st, wave, lane);
+            stage_kv<D, true>(V, p.v_row, 0, p.Skv - 1, st + TILE_BYTES, wave, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (id + 1 < p.n_id) {
+            char* nx = smem + ((id + 1) & 1) * 2 * TILE_BYTES;
+            stage_kv<D, false>(p.k + (id + 1) * p.k_id + grp * p.k_grp + (long long)head * D, p.k_row, 0, p.Skv - 1, nx, wave, lane);
+            stage_kv<D, true>(p.v + (id + 1) * p.v_id + grp * p.v_grp + (long long)head * D, p.v_row, 0, p.Skv - 1, nx + TILE_BYTES, wave, lane);
+        }
+        f32x16 oacc[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+        bf16x8 mfrag;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mfrag[e] = (__bf16)0.0f;
+        float m_run = 0.f, l_run = 0.f;
+        uint32_t vbase[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) vbase[d] = lds0 + (id & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
+        attn_tile<D, true, false>(st, vbase, qf, oacc, ones, mfrag, m_run, l_run, true, p.Skv, r, hf, p.scale_log2);
+        const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        const float sc = w[id] / (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1]));
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) zacc[d][i] = fmaf(sc, oacc[d][i], zacc[d][i]);
+    }
+    if (q_valid) {
+        bf16_t* zrow = Z + (long long)(q0 + r) * p.z_row;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                u32x2 o;
+                o[0] = pack2bf(zacc[d][gq * 4 + 0], zacc[d][gq * 4 + 1]);
+                o[1] = pack2bf(zacc[d][gq * 4 + 2], zacc[d][gq * 4 + 3]);
+                *reinterpret_cast<u32x2*>(zrow + d * 32 + gq * 8 + hf * 4) = o;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_kv_mix_kernel_d64(MixArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_mix_body<64>(p, smem);
+}
+__global__ __launch_bounds__(256) void attn_kv_mix_kernel_d128(MixArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_mix_body<128>(p, smem);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Two query blocks per wave (static-bound softmax, head_dim 64 only): a wave owns 64 query rows, a workgroup 256, and
 // every K and V fragment read from LDS feeds BOTH 32-row blocks -- half the LDS reads, half the K/V staging and half the
 // workgroup rendezvous per FLOP of the one-block form, at two waves per SIMD (256 registers) instead of four.
@@ -787,4 +911,28 @@ extern "C" int bya_attn_fwd(const void* q, const void* k, const void* v, void* o
     // a usable static bound keeps every P = exp2(s - B) >= 2^-96 (a bf16 normal); otherwise the running-max kernel runs
     a.score_bound = (a.prescaled && d->score_bound > 0.f && d->score_bound <= 48.f) ? d->score_bound : 0.f;
     return d->head_dim == 64 ? launch_attn<64>(a, stream) : launch_attn<128>(a, stream);
+}
+
+extern "C" int bya_attn_kv_mix(const void* q, const void* k, const void* v, const void* r, const void* af, void* z, float* wsum,
+                               const bya_attn_mix_desc* d, hipStream_t stream) {
+    if (!q || !k || !v || !r || !z || !d) return BYA_ERR_SHAPE;
+    if (d->head_dim != 64 && d->head_dim != 128) return BYA_ERR_UNSUPPORTED;
+    if (d->heads <= 0 || d->n_id < 1 || d->n_id > 4 || d->n_grp <= 0 || d->Sq <= 0 || d->Skv <= 0 || d->Skv > KV_TILE) return BYA_ERR_SHAPE;
+    if ((d->q_grp | d->q_row | d->k_id | d->k_grp | d->k_row | d->v_id | d->v_grp | d->v_row) % 8) return BYA_ERR_ALIGN;
+    if ((d->z_grp | d->z_row) % 4) return BYA_ERR_ALIGN;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return BYA_ERR_ALIGN;
+    if ((uintptr_t)z & 7) return BYA_ERR_ALIGN;
+    MixArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.z = (bf16_t*)z;
+    a.r = (const bf16_t*)r; a.af = (const bf16_t*)af; a.wsum = wsum;
+    a.heads = d->heads; a.n_id = d->n_id; a.n_grp = d->n_grp; a.Sq = d->Sq; a.Skv = d->Skv;
+    a.nqt = (d->Sq + Q_PER_BLOCK - 1) / Q_PER_BLOCK; a.mode = af ? 1 : 0;
+    a.q_grp = d->q_grp; a.q_row = d->q_row; a.k_id = d->k_id; a.k_grp = d->k_grp; a.k_row = d->k_row;
+    a.v_id = d->v_id; a.v_grp = d->v_grp; a.v_row = d->v_row; a.z_grp = d->z_grp; a.z_row = d->z_row;
+    a.scale_log2 = d->scale * 1.4426950408889634f;
+    const dim3 grid((unsigned)((long long)a.nqt * a.heads * a.n_grp));
+    const size_t lds = (size_t)2 * 2 * KV_TILE * d->head_dim * 2;
+    if (d->head_dim == 64) BYA_LAUNCH(attn_kv_mix_kernel_d64, grid, dim3(256), lds, stream, a);
+    else BYA_LAUNCH(attn_kv_mix_kernel_d128, grid, dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

@@ -16,7 +16,7 @@
 //   * the source grid may be a nearest-neighbour up-sampling of the stored tensor (up = 1: h >> 1, w >> 1; time by
 //     tmode: 0 same frame, 1 every frame doubled, 2 first frame single and the rest doubled) -- CogVideoXUpsample3D's
 //     F.interpolate is never materialised.
-// bya_vae_groupnorm_stats: per (group) sum and sum of squares over a chunk's rows, fp32 atomics into [groups][2].
+// bya_vae_groupnorm_stats: per (group) sum and sum of squares over a chunk's rows -> [groups][2] fp32, in a fixed order.
 // bya_vae_norm_act: y = act( (x - mean_g) rstd_g gamma_c + beta_c ) with, for the decoder,
 //   ... * Y[z(row)][c] + B[z(row)][c]  (CogVideoXSpatialNorm3D: conv_y / conv_b of the latent are 1x1x1, hence commute
 //   with its nearest resize: they are evaluated at latent resolution by a GEMM and indexed here).
@@ -100,47 +100,64 @@ __global__ __launch_bounds__(256) void vae_patches_small_kernel(PatchArgs p) {
     for (int c = 0; c < n; ++c) dst[c] = base ? base[c] : (bf16_t)0;
 }
 
-// ---- GroupNorm statistics: block = 256 rows x all channels; lane owns 8 channels of a row, reduces over its rows, then
-// the channels of a group (cg = C / groups channels, a multiple of 1; lanes of a group are adjacent), one atomic pair per
-// (block, group).
-__global__ __launch_bounds__(256) void vae_gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ sums, long long rows,
-                                                           int C, int groups) {
-    extern __shared__ float red[];                         // [groups][2]
-    const int cpr = C >> 3;                                // 16-byte pieces per row
-    const int tid = threadIdx.x;
-    for (int i = tid; i < groups * 2; i += 256) red[i] = 0.f;
-    __syncthreads();
-    const int cg = C / groups;
-    constexpr int ROWS_PER_BLOCK = 512;
-    const long long r0 = (long long)blockIdx.x * ROWS_PER_BLOCK;
-    const long long pieces = (long long)ROWS_PER_BLOCK * cpr;
-    for (long long i = tid; i < pieces; i += 256) {
-        const long long r = r0 + i / cpr;
+// ---- GroupNorm statistics, DETERMINISTIC (no atomics: the same chunk gives the same bits on every run, which the causal
+// chunk cache of the decoder makes observable -- frames of one chunk must not change when later latents do).
+// Pass 1: a block sums 512 rows; thread t owns the 8 channels (t % cpr) * 8 .. of its rows (256 % cpr == 0: C / 8 is a power of
+// two <= 64), accumulates them in registers in row order, then the block adds the threads of a channel in thread order and the
+// channels of a group in channel order -> partial[block][group][2].  Pass 2: one block per (group, moment) adds the partials in
+// a fixed order (strided per thread, then a shared-memory tree).
+constexpr int GN_ROWS = 512;
+
+__global__ __launch_bounds__(256) void vae_gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, long long rows,
+                                                             int C, int groups) {
+    __shared__ float sh[2][256][8];
+    __shared__ float chs[2][512];
+    const int cpr = C >> 3, tid = threadIdx.x;
+    const int c8 = tid % cpr, rstep = 256 / cpr;
+    const long long r0 = (long long)blockIdx.x * GN_ROWS;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    for (int rr = tid / cpr; rr < GN_ROWS; rr += rstep) {
+        const long long r = r0 + rr;
         if (r >= rows) break;
-        const int c8 = (int)(i % cpr);
         float v[8];
         unpack8(*reinterpret_cast<const u32x4*>(x + r * C + c8 * 8), v);
-        if (cg >= 8) {                                     // the 8 channels share a group
-            float s = 0.f, q = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s += v[e]; q += v[e] * v[e]; }
-            const int g = (c8 * 8) / cg;
-            atomicAdd(&red[2 * g], s);
-            atomicAdd(&red[2 * g + 1], q);
-        } else {                                           // 1, 2 or 4 channels per group
+        for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] = fmaf(v[e], v[e], q[e]); }
+    }
 #pragma unroll
-            for (int e0 = 0; e0 < 8; e0 += 1) {
-                if (e0 % cg) continue;
-                float s = 0.f, q = 0.f;
-                for (int e = e0; e < e0 + cg; ++e) { s += v[e]; q += v[e] * v[e]; }
-                const int g = (c8 * 8 + e0) / cg;
-                atomicAdd(&red[2 * g], s);
-                atomicAdd(&red[2 * g + 1], q);
-            }
-        }
+    for (int e = 0; e < 8; ++e) { sh[0][tid][e] = s[e]; sh[1][tid][e] = q[e]; }
+    __syncthreads();
+    for (int ch = tid; ch < C; ch += 256) {                 // channel sums: the threads of a channel in thread order
+        const int cc = ch >> 3, e = ch & 7;
+        float a = 0.f, b = 0.f;
+        for (int t = cc; t < 256; t += cpr) { a += sh[0][t][e]; b += sh[1][t][e]; }
+        chs[0][ch] = a; chs[1][ch] = b;
     }
     __syncthreads();
-    for (int i = tid; i < groups * 2; i += 256) atomicAdd(&sums[i], red[i]);
+    const int cg = C / groups;
+    for (int g = tid; g < groups; g += 256) {
+        float a = 0.f, b = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) { a += chs[0][c]; b += chs[1][c]; }
+        partial[((long long)blockIdx.x * groups + g) * 2] = a;
+        partial[((long long)blockIdx.x * groups + g) * 2 + 1] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void vae_gn_final_kernel(const float* __restrict__ partial, float* __restrict__ sums, int nblocks,
+                                                           int groups) {
+    __shared__ float red[256];
+    const int gm = blockIdx.x, tid = threadIdx.x;            // gm = group * 2 + moment
+    float a = 0.f;
+    for (int b = tid; b < nblocks; b += 256) a += partial[(long long)b * groups * 2 + gm];
+    red[tid] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) sums[gm] = red[0];
 }
 
 struct NormArgs {
@@ -217,15 +234,15 @@ extern "C" int bya_vae_patches(const void* x, const void* cache, void* out, int3
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
-extern "C" int bya_vae_groupnorm_stats(const void* x, float* sums, int64_t rows, int32_t C, int32_t groups, hipStream_t stream) {
-    if (!x || !sums || rows <= 0 || C <= 0 || groups <= 0 || C % groups || C % 8) return BYA_ERR_SHAPE;
-    const int cg = C / groups;
-    if (!(cg >= 8 ? cg % 8 == 0 : (cg == 1 || cg == 2 || cg == 4))) return BYA_ERR_UNSUPPORTED;
+extern "C" int bya_vae_groupnorm_stats(const void* x, float* sums, float* partial, int64_t rows, int32_t C, int32_t groups,
+                                       hipStream_t stream) {
+    if (!x || !sums || !partial || rows <= 0 || C <= 0 || groups <= 0 || C % groups || C % 8) return BYA_ERR_SHAPE;
+    const int cpr = C / 8;
+    if (C > 512 || (cpr & (cpr - 1)) || cpr > 64) return BYA_ERR_UNSUPPORTED;      // C / 8 a power of two <= 64
     if ((uintptr_t)x & 15) return BYA_ERR_ALIGN;
-    if (hipMemsetAsync(sums, 0, (size_t)groups * 2 * sizeof(float), stream) != hipSuccess) return BYA_ERR_LAUNCH;
-    const long long blocks = (rows + 511) / 512;
-    BYA_LAUNCH(vae_gn_stats_kernel, dim3((unsigned)blocks), dim3(256), (size_t)groups * 2 * sizeof(float), stream,
-               (const bf16_t*)x, sums, (long long)rows, C, groups);
+    const long long blocks = (rows + GN_ROWS - 1) / GN_ROWS;
+    BYA_LAUNCH(vae_gn_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x, partial, (long long)rows, C, groups);
+    BYA_LAUNCH(vae_gn_final_kernel, dim3((unsigned)(groups * 2)), dim3(256), 0, stream, (const float*)partial, sums, (int)blocks, groups);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 

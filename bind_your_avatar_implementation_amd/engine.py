@@ -73,6 +73,9 @@ class DenoiseEngine:
         # route-then-project (exact by linearity of to_out; halves those GEMMs and drops the [2,N,D] round trip).
         # False = the reference's order of operations (project each identity, then combine).
         self.mix_before_projection = os.environ.get("BYA_MIX_BEFORE_PROJECTION", "1") != "0"
+        # ... and mix inside the cross-attention kernel's epilogue (bya_attn_kv_mix): the per-identity attention outputs never
+        # reach HBM.  "0" = attention, then bya_routed_mix (the round-2 path; kept for the exact-row-selection tests)
+        self.fused_attn_mix = self.mix_before_projection and os.environ.get("BYA_FUSED_ATTN_MIX", "1") != "0"
         # BASELINE configs[4]: the four big Linears of every DiT block on e4m3 operands (per-channel weight scales taken at
         # pack time, per-row activation scales on the fly; fp32 accumulation, bf16 everywhere else)
         self.fp8_weights = bool(getattr(model, "_fp8_weights", False)) or os.environ.get("BYA_FP8_WEIGHTS") == "1"
@@ -575,9 +578,12 @@ class DenoiseEngine:
                 qp = self._ln_linear("pq", ca, xv, lat, pc.norm2, pc.to_q.weight, buf("qp", B, N_loc, inner_p))
                 kv_l = face_kv[ca]
                 ntok = kv_l.shape[2]
-                pout = buf("pout", B, n_id, N_loc, inner_p)
+                fuse_face = self.fused_attn_mix and taps is None
+                pout = None if fuse_face else buf("pout", B, n_id, N_loc, inner_p)
 
                 def perceiver_attention():
+                    if fuse_face:
+                        return                       # runs behind the router, with the mix in its epilogue (below)
                     ops.attention(qp, kv_l, kv_l[..., inner_p:], pout, head_dim=hd_p, heads=16, nb1=B, nb2=n_id, Sq=N_loc,
                                   Skv=ntok, q_strides=(N_loc * inner_p, 0, inner_p),
                                   k_strides=(n_id * ntok * 2 * inner_p, ntok * 2 * inner_p, 2 * inner_p),
@@ -590,7 +596,17 @@ class DenoiseEngine:
                 else:
                     perceiver_attention()
                     r_logits = forced
-                if self.mix_before_projection:
+                if fuse_face:
+                    # Perceiver attention with the masked combine in its epilogue: z = sum_id r[n, id] * attention_id
+                    z = buf("zmix_p", B, N_loc, inner_p)
+                    kvs_p = (ntok * 2 * inner_p, 0, 2 * inner_p)
+                    for b in range(B):
+                        rb = r_logits[b if r_logits.shape[0] > 1 else 0]
+                        ops.attn_kv_mix(qp[b], kv_l[b], kv_l[b][..., inner_p:], rb, None, z[b], head_dim=hd_p, heads=16,
+                                        n_id=n_id, n_grp=1, Sq=N_loc, Skv=ntok, q_strides=(0, inner_p), k_strides=kvs_p,
+                                        v_strides=kvs_p, z_strides=(0, inner_p), scale=hd_p ** -0.5)
+                    ops.gemm(z, pc.to_out.weight, xv, res=xv, alpha=m.local_face_scale)
+                elif self.mix_before_projection:
                     # to_out is linear and bias-free: route first, project once (half the GEMM, no feat round trip)
                     z = ops.routed_mix(pout, r_logits, None, "face", buf("zmix_p", B, N_loc, inner_p))
                     ops.gemm(z, pc.to_out.weight, xv, res=xv, alpha=m.local_face_scale)
@@ -612,8 +628,29 @@ class DenoiseEngine:
                                      buf("qa", B, N_loc, D), bias=at.to_q.bias)
                 ka, va = audio_k[i // m.audio_attn_interval], audio_v[i // m.audio_attn_interval]
                 ntok = ka.shape[3]
-                ao = buf("ao", B, n_id, N_loc, D)
+                fuse_audio = self.fused_attn_mix and taps is None
                 kvs = (T * ntok * D, ntok * D, D)
+                if fuse_audio:
+                    # audio cross-attention with the masked combine in its epilogue (per sample: af differs per sample)
+                    wsum = self._ws.get("wsum")
+                    if wsum is None or wsum.numel() != B * N_loc:
+                        wsum = self._ws["wsum"] = torch.empty(B, N_loc, dtype=torch.float32, device=self.dev)
+                    z = buf("zmix_a", B, N_loc, D)
+                    for b in range(B):
+                        rb = r_logits[b if r_logits.shape[0] > 1 else 0]
+                        if not sh.active:
+                            ops.attn_kv_mix(qa[b], ka[b], va[b], rb, af[b], z[b], wsum[b], head_dim=64, heads=H, n_id=n_id,
+                                            n_grp=T, Sq=per_frame, Skv=ntok, q_strides=(per_frame * D, D), k_strides=kvs,
+                                            v_strides=kvs, z_strides=(per_frame * D, D), scale=64 ** -0.5)
+                        else:           # shard boundaries cut frames: one launch per (partial) frame of this rank
+                            for f, start, length in sh.frame_segments(per_frame):
+                                ops.attn_kv_mix(qa[b, start:], ka[b, :, f], va[b, :, f], rb[start:start + length], af[b],
+                                                z[b, start:], wsum[b, start:], head_dim=64, heads=H, n_id=n_id, n_grp=1,
+                                                Sq=length, Skv=ntok, q_strides=(0, D), k_strides=(kvs[0], 0, D),
+                                                v_strides=(kvs[0], 0, D), z_strides=(0, D), scale=64 ** -0.5)
+                    ops.gemm(z, at.to_out[0].weight, xv, bias=at.to_out[0].bias, res=xv, bias_rowscale=wsum)
+                    continue
+                ao = buf("ao", B, n_id, N_loc, D)
                 for b in range(B):      # (id, frame) batch of one sample; q rows shared by both ids
                     if not sh.active:
                         ops.attention(qa[b], ka[b], va[b], ao[b], head_dim=64, heads=H, nb1=n_id, nb2=T, Sq=per_frame,

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _hip
-from ._hip import AttnDesc, GemmDesc, check
+from ._hip import AttnDesc, AttnMixDesc, GemmDesc, check
 
 ACT = {None: 0, "none": 0, "gelu_tanh": 1, "gelu_erf": 2, "relu": 3, "silu": 4, "leaky_relu": 5,
        "gelu_tanh_ieee": 6}        # 6: round-1 GELU form (expf + IEEE division), GEMM epilogue only, kept for A/B
@@ -359,6 +359,30 @@ def self_attention(q, k, v, out, heads, head_dim=64, scale=None, tag="other", pr
                      o_strides=(o_bs, 0, o_ld), scale=scale, tag=tag, prescaled=prescaled, score_bound=score_bound)
 
 
+def attn_kv_mix(q, k, v, r, af, z, wsum=None, *, head_dim, heads, n_id, n_grp, Sq, Skv, q_strides, k_strides, v_strides,
+                z_strides, scale):
+    """z[g, n] = sum_id w[g n, id] * softmax(q[g, n] . K[id, g]^T * scale) V[id, g]: cross-attention onto <= 64 keys per identity
+    with the router's masked combine in its epilogue (bya_attn_kv_mix).  q_strides = (group, row), k / v_strides = (identity,
+    group, row), z_strides = (group, row), in elements; r: bf16 [n_grp * Sq, n_id]; af: None (face) or bf16 [n_id, n_id]."""
+    lib = _hip.load()
+    d = AttnMixDesc()
+    d.head_dim, d.heads, d.n_id, d.n_grp, d.Sq, d.Skv = head_dim, heads, n_id, n_grp, Sq, Skv
+    d.q_grp, d.q_row = q_strides
+    d.k_id, d.k_grp, d.k_row = k_strides
+    d.v_id, d.v_grp, d.v_row = v_strides
+    d.z_grp, d.z_row = z_strides
+    d.scale = float(scale)
+    for t in (q, k, v, z, r):
+        assert t.dtype == torch.bfloat16 and t.is_cuda
+    assert r.is_contiguous() and r.numel() == n_grp * Sq * n_id
+    assert af is None or (af.is_contiguous() and af.dtype == torch.bfloat16 and af.numel() == n_id * n_id)
+    assert wsum is None or (wsum.dtype == torch.float32 and wsum.is_contiguous() and wsum.numel() >= n_grp * Sq)
+    tok = _begin("bya_attn_kv_mix", 4.0 * n_id * n_grp * heads * Sq * Skv * head_dim)
+    check(lib.bya_attn_kv_mix(_p(q), _p(k), _p(v), _p(r), _p(af), _p(z), _p(wsum), ctypes.byref(d), _stream()), "bya_attn_kv_mix")
+    _end(tok)
+    return z
+
+
 def attn_tiny(q, k, v, out, L, heads, n_outer, n_inner, outer_stride, seq_stride, ld_qkv, ld_o, scale):
     lib = _hip.load()
     tok = _begin("bya_attn_tiny")
@@ -539,12 +563,16 @@ def vae_patches(x, cache, out, KT, stride, pad, up, tmode, Ho, Wo, t0, nt):
     return out
 
 
-def vae_groupnorm_stats(x2d, sums, groups):
+def vae_groupnorm_stats(x2d, sums, groups, partial=None):
     lib = _hip.load()
     rows, C = x2d.shape
     assert x2d.is_contiguous() and sums.dtype == torch.float32 and sums.numel() == 2 * groups
+    need = (rows + 511) // 512 * groups * 2
+    if partial is None:
+        partial = torch.empty(need, dtype=torch.float32, device=x2d.device)
+    assert partial.dtype == torch.float32 and partial.numel() >= need and partial.is_contiguous()
     tok = _begin("bya_vae_groupnorm_stats")
-    check(lib.bya_vae_groupnorm_stats(_p(x2d), _p(sums), rows, C, groups, _stream()), "bya_vae_groupnorm_stats")
+    check(lib.bya_vae_groupnorm_stats(_p(x2d), _p(sums), _p(partial), rows, C, groups, _stream()), "bya_vae_groupnorm_stats")
     _end(tok)
     return sums
 

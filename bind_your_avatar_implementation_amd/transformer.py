@@ -10,6 +10,7 @@ There is no CPU / eager fallback: calling ``forward`` without a GPU or without t
 from types import SimpleNamespace
 from typing import Any, Dict, Optional, Tuple, Union
 
+import os
 import torch
 from torch import nn
 
@@ -446,11 +447,16 @@ class BindyouravatarTransformer3DModel(nn.Module):
         return (out, None, None, None, None)
 
     def _graph_capturable(self):
-        """The sharded step is capturable when its exchanges are RCCL collectives (stream-ordered, capturable); the gloo
-        path of the functional tests stages through host memory and is not."""
+        """Only the unsharded step is replayed from a hipGraph.  Capturing the sharded step needs RCCL collectives inside a
+        stream capture, and on this stack (PyTorch 2.10-ROCm 7.0, RCCL of ROCm 7.2) even a lone ``all_to_all_single`` under
+        ``torch.cuda.graph`` never returns (tools/rccl_graph_probe.py, profiles/r3_rccl_graph_probe.txt): the sharded
+        step stays eager, its exchanges stream-ordered on the communicator's stream.  BYA_GRAPH_SHARDED=1 lifts the guard for
+        a stack where the probe passes."""
         group = getattr(self, "_seq_group", None)
         if getattr(self, "_seq_world", 1) == 1 and group is None:
             return True
+        if os.environ.get("BYA_GRAPH_SHARDED") != "1":
+            return False
         import torch.distributed as dist
         return dist.is_initialized() and dist.get_backend(group) == "nccl"
 

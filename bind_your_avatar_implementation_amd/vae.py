@@ -247,7 +247,8 @@ class BindyouravatarVAE(nn.Module):
         T, H, W, C = x.shape
         gn = norm.norm_layer if hasattr(norm, "norm_layer") else norm
         sums = self._buf("gn_sums", 2 * gn.num_groups, dtype=torch.float32)
-        ops.vae_groupnorm_stats(x.view(-1, C), sums, gn.num_groups)
+        part = self._buf("gn_partial", (T * H * W + 511) // 512 * gn.num_groups * 2, dtype=torch.float32)
+        ops.vae_groupnorm_stats(x.view(-1, C), sums, gn.num_groups, part)
         y = torch.empty_like(x)
         if hasattr(norm, "norm_layer"):
             z64, lat = zctx

@@ -186,6 +186,22 @@ int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya
 #define BYA_ATTN_D64_STATIC_BOUND_W4 4  /* the same arithmetic on the one-wave-per-SIMD hand-placed kernel (csrc/attn_w4.hip) */
 int bya_attn_variant(const bya_attn_desc* desc);
 
+/* Cross-attention onto at most 64 keys per identity with the router's masked combine in its epilogue:
+ *   z[g, n, :] = sum_id w[g n, id] * softmax(q[g, n] . K[id, g]^T * scale) V[id, g]      (fp32 mix, one rounding to bf16)
+ * The audio cross-attention (models/audio_model.py:247-258: 32 audio tokens per latent frame g and identity) and the face
+ * Perceiver cross-attention (models/router.py:255-270: 32 face tokens per identity), each followed in the reference by the
+ * masked combine of models/transformer.py:821-832 / 895-936 AFTER the (linear) output projection: the engine mixes first
+ * and projects once.  r: routing logits bf16 [n_grp * Sq, n_id]; af: NULL = face weights (w = r), else the audio-to-face
+ * matrix bf16 [n_id, n_id] (w as in bya_masked_combine mode 1).  wsum (optional, fp32 [n_grp * Sq]) = sum_id w, the row scale
+ * of the projection's bias.  q rows are shared by all identities.  Element strides; head h of a row starts at h * head_dim. */
+typedef struct bya_attn_mix_desc {
+    int32_t head_dim, heads, n_id, n_grp, Sq, Skv;
+    int64_t q_grp, q_row, k_id, k_grp, k_row, v_id, v_grp, v_row, z_grp, z_row;
+    float scale;
+} bya_attn_mix_desc;
+int bya_attn_kv_mix(const void* q, const void* k, const void* v, const void* r, const void* af, void* z, float* wsum,
+                    const bya_attn_mix_desc* desc, hipStream_t stream);
+
 /* Tiny-sequence self-attention (sequence length L <= 16, head_dim 64) used by the router's temporal
  * (L = frames) and multi-ID (L = ids) attentions (models/router.py:482,488).  Element e of sequence
  * `g` lives at row  g_outer(g)*outer_stride + e*seq_stride + g_inner(g)  of the [rows, ld] matrices,
@@ -302,8 +318,11 @@ int bya_masks_to_routing_logits(const void* masks, void* logits, int32_t n_id, i
 int bya_vae_patches(const void* x, const void* cache, void* out, int32_t Ts, int32_t Hs, int32_t Ws, int32_t C, int32_t KT,
                     int32_t stride, int32_t pad, int32_t up, int32_t tmode, int32_t Ho, int32_t Wo, int32_t t0, int32_t nt,
                     int32_t Kpad, hipStream_t stream);
-/* GroupNorm statistics of one chunk: sums [groups][2] fp32 = (sum, sum of squares) over x [rows, C] (zeroed here). */
-int bya_vae_groupnorm_stats(const void* x, float* sums, int64_t rows, int32_t C, int32_t groups, hipStream_t stream);
+/* GroupNorm statistics of one chunk: sums [groups][2] fp32 = (sum, sum of squares) over x [rows, C], summed in a FIXED order
+ * (no atomics: the same chunk gives the same bits every run).  partial: caller's scratch, ceil(rows / 512) * groups * 2 floats.
+ * C <= 512 with C / 8 a power of two. */
+int bya_vae_groupnorm_stats(const void* x, float* sums, float* partial, int64_t rows, int32_t C, int32_t groups,
+                            hipStream_t stream);
 /* y = act( GroupNorm(x; sums, gamma, beta, eps) [ * zy[z(row)] + zb[z(row)] ] ), act 0 = none, 1 = SiLU.  zy / zb (both or
  * neither): conv_y / conv_b of CogVideoXSpatialNorm3D evaluated at LATENT resolution [Tz * hz * wz rows, row stride ldz]; row
  * (t, h, w) of x [T, H, W, C] reads latent position (frame by tmode, h >> log2(H / hz), w >> log2(W / wz)): tmode 0 = same

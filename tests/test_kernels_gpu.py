@@ -763,6 +763,76 @@ def test_attn_static_bound_softmax(ops, dev, S, kernel, monkeypatch):
     check(out2.view(1, S, H, D).transpose(1, 2), ref, tol=ATTN_TOL, what="unusable bound -> running-max kernel")
 
 
+@pytest.mark.parametrize("mode,D,H,n_id,grp,Sq", [("audio", 64, 48, 2, 13, 150), ("audio", 64, 6, 3, 4, 333),
+                                                  ("face", 128, 16, 2, 1, 1000), ("face", 128, 16, 3, 1, 130)])
+def test_attn_kv_mix_equals_attention_then_routed_mix(ops, dev, mode, D, H, n_id, grp, Sq):
+    """bya_attn_kv_mix (cross-attention onto 32 keys per identity with the masked combine in its epilogue) against the two
+    launches it replaces, bya_attn_fwd + bya_routed_mix, and against fp32 torch; with ONE-HOT routing masks the fused kernel
+    must return exactly the selected identity's attention output, bit for bit with the unfused attention (the mix is
+    1.0 * o + 0.0 * o': row selection is index work)."""
+    g = torch.Generator().manual_seed(D + H + n_id)
+    Skv, E = 32, H * D
+    q = rnd((grp, Sq, E), dev, 1)
+    k = rnd((n_id, grp, Skv, E), dev, 2)
+    v = rnd((n_id, grp, Skv, E), dev, 3)
+    N = grp * Sq
+    r_soft = torch.sigmoid(torch.randn(N, n_id, generator=g)).to(torch.bfloat16).to(dev)
+    lab = torch.randint(-1, n_id, (N,), generator=g)
+    r_hard = torch.zeros(N, n_id)
+    for i in range(n_id):
+        r_hard[lab == i, i] = 1
+    r_hard = r_hard.to(torch.bfloat16).to(dev)
+    af = None if mode == "face" else torch.roll(torch.eye(n_id), 1, dims=1).to(torch.bfloat16).to(dev)
+    scale = D ** -0.5
+    # unfused: attention per identity (q shared), then the routed mix
+    ao = torch.empty(1, n_id, N, E, dtype=torch.bfloat16, device=dev)
+    ops.attention(q, k, v, ao[0], head_dim=D, heads=H, nb1=n_id, nb2=grp, Sq=Sq, Skv=Skv, q_strides=(0, Sq * E, E),
+                  k_strides=(grp * Skv * E, Skv * E, E), v_strides=(grp * Skv * E, Skv * E, E),
+                  o_strides=(N * E, Sq * E, E), scale=scale)
+    for r in (r_soft, r_hard):
+        z_ref, ws_ref = torch.empty(1, N, E, dtype=torch.bfloat16, device=dev), torch.empty(1, N, dtype=torch.float32, device=dev)
+        ops.routed_mix(ao, r[None], None if af is None else af[None], mode, z_ref, ws_ref)
+        z, ws = torch.empty(grp, Sq, E, dtype=torch.bfloat16, device=dev), torch.full((N,), -1.0, dtype=torch.float32, device=dev)
+        ops.attn_kv_mix(q, k, v, r, af, z, ws, head_dim=D, heads=H, n_id=n_id, n_grp=grp, Sq=Sq, Skv=Skv,
+                        q_strides=(Sq * E, E), k_strides=(grp * Skv * E, Skv * E, E), v_strides=(grp * Skv * E, Skv * E, E),
+                        z_strides=(Sq * E, E), scale=scale)
+        assert torch.equal(ws, ws_ref[0])
+        e = rel_fro(z.view(N, E).float(), z_ref[0].float())
+        print(f"attn_kv_mix {mode} d{D} n_id {n_id}: vs attention + routed_mix {e:.3e}")
+        assert e < 4e-3                                        # one rounding instead of two
+    if mode == "face":                                         # hard masks: exactly the selected identity's rows
+        zv = z.view(N, E)
+        for i in range(n_id):
+            assert torch.equal(zv[(lab == i).to(dev)], ao[0, i][(lab == i).to(dev)])
+        assert bool((zv[(lab == -1).to(dev)] == 0).all())
+    # fp32 reference of the whole thing (soft masks)
+    qf = q.float().view(grp, Sq, H, D).permute(0, 2, 1, 3)
+    outs = []
+    for i in range(n_id):
+        kf = k[i].float().view(grp, Skv, H, D).permute(0, 2, 1, 3)
+        vf = v[i].float().view(grp, Skv, H, D).permute(0, 2, 1, 3)
+        outs.append((torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1) @ vf).permute(0, 2, 1, 3).reshape(N, E))
+    if mode == "face":
+        w = r_soft.float()
+    else:
+        av = (r_soft.float() @ af.float().T).to(torch.bfloat16).float()
+        comp = (1 - av).to(torch.bfloat16).float()
+        cols = []
+        for a in range(n_id):
+            t_ = torch.ones(N, device=dev)
+            for b_ in range(n_id):
+                if b_ != a:
+                    t_ = (t_ * comp[:, b_]).to(torch.bfloat16).float()
+            cols.append(t_)
+        w = torch.stack(cols, -1)
+    ref = sum(w[:, i:i + 1] * outs[i] for i in range(n_id))
+    z2 = torch.empty(grp, Sq, E, dtype=torch.bfloat16, device=dev)
+    ops.attn_kv_mix(q, k, v, r_soft, af, z2, None, head_dim=D, heads=H, n_id=n_id, n_grp=grp, Sq=Sq, Skv=Skv,
+                    q_strides=(Sq * E, E), k_strides=(grp * Skv * E, Skv * E, E), v_strides=(grp * Skv * E, Skv * E, E),
+                    z_strides=(Sq * E, E), scale=scale)
+    check(z2.view(N, E), ref, tol=ATTN_TOL, what=f"attn_kv_mix {mode} vs fp32")
+
+
 # ----------------------------------------------------------------------------------------------- CFG + scheduler step
 @pytest.mark.parametrize("cfg", [False, True])
 def test_cfg_ddim_step_bit_exact(ops, dev, cfg):

@@ -43,19 +43,14 @@ def _engine_worker(rank, port, ret, mode):
         torch.cuda.synchronize()
         ret["equal"] = bool(torch.equal(part, full)) and bool(torch.equal(again, full))
         if mode == "graph":
-            # the sharded step -- RCCL collectives on the communicator's stream, event waits on the compute stream --
-            # captured into ONE hipGraph and replayed (at 8 ranks a rank's step is ~70 ms of GPU time behind ~360
-            # torch.distributed calls and ~2000 ctypes launches: replay removes the host from the critical path)
+            # use_hip_graph on a SHARDED model: RCCL collectives cannot be captured on this stack (even a lone
+            # all_to_all_single under torch.cuda.graph never returns: tools/rccl_graph_probe.py), so the model must notice
+            # and run the sharded step eagerly instead of hanging in a capture
             model.use_hip_graph = True
-            assert model._graph_capturable()
+            assert not model._graph_capturable()
             g1 = model(**inp)[0].clone()
-            g2 = model(**inp)[0].clone()
-            inp2 = dict(inp, hidden_states=inp["hidden_states"] * 0.5)
-            g3 = model(**inp2)[0].clone()
-            model.use_hip_graph = False
-            e3 = model(**inp2)[0]
             torch.cuda.synchronize()
-            ret["graph_equal"] = bool(torch.equal(g1, full) and torch.equal(g2, full) and torch.equal(g3, e3))
+            ret["graph_equal"] = bool(torch.equal(g1, full))
             ret["graphs"] = len(model._graphs)
         ret["maxdiff"] = float((part.float() - full.float()).abs().max())
         ret["counters"] = dict(parallel.COLLECTIVE_CALLS)
@@ -78,7 +73,7 @@ def test_engine_collective_paths_on_a_one_rank_rccl_group(dev, mode):
         # + the 7 repartitions of the one routing layer's four blocks; the logits and the output are all-gathered
         assert c.get("all_to_all_async", 0) >= 15 and c.get("all_to_all", 0) == 0 and c.get("all_gather", 0) > 0
     if mode == "graph":
-        assert ret["graph_equal"] and ret["graphs"] == 1, dict(ret)
+        assert ret["graph_equal"] and ret["graphs"] == 0, dict(ret)
 
 
 def _load_rccl():
