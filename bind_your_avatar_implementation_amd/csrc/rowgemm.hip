@@ -13,7 +13,12 @@
 // output stores compiled out (1180 of 2000 TFLOP/s).  The two build-time alternatives kept below were measured and lost:
 // BYA_ROWGEMM_CH=32 (two independent 4-wave workgroups per CU: same LDS bytes, -7 % on N = 1536, +2 % on N = 512) and
 // BYA_ROWGEMM_HB=4 (64 rows per wave, X in 256 registers, one wave per SIMD: half the LDS bytes, but hipcc's schedule of
-// the single wave loses 17 %; it would need a hand-placed loop like gemm_v4's).
+// the single wave loses 17 %; it would need a hand-placed loop like gemm_v4's).  Round 3 re-tried that form with 32 x 32 x 16
+// MFMAs (half the MFMA issue slots), X in AGPRs and the previous chunk's epilogue written between the MFMAs of the next
+// chunk, still compiler-scheduled: bit-identical results, 13-19 % SLOWER on all four launch shapes
+// (profiles/r3_rowgemm_w4_compiler_scheduled_probe.json; hipcc triplicated the chunk loop and put 223 s_waitcnt and 117 s_nop
+// into it) -- removed again.  What the attention kernel taught this round (csrc/attn_w4.hip) applies here too: the
+// one-wave-per-SIMD form pays only with every instruction of the loop placed by hand.
 // The product is computed transposed (W fragment = A operand, X fragment = B operand), so a lane ends up with 16
 // consecutive output columns of one token: 16-byte stores, no LDS transpose.
 //
