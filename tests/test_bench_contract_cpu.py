@@ -1,6 +1,6 @@
 """The bench.py contract (one JSON line; metric / config of BASELINE.json; roofline and cpu_baseline objects) checked on the
-committed output of the end-of-round run (the newest profiles/r2_v*_bench.json = stdout of ``python bench.py --steps 5 --warmup 2`` on
-an MI355X) and on the script's command line, without a GPU."""
+committed output of the end-of-round run (the newest profiles/r3_*_bench.json = stdout of ``python bench.py --steps 10 --warmup 3``
+on an MI355X) and on the script's command line, without a GPU."""
 import json
 import os
 import subprocess
@@ -17,14 +17,14 @@ def _line(path):
 
 def test_committed_bench_line_meets_the_contract():
     import glob
-    d = _line(sorted(glob.glob(os.path.join(ROOT, "profiles", "r2_v*_bench.json")))[-1])      # the newest end-of-round line
+    d = _line(sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_*_bench.json")))[-1])      # the newest end-of-round line
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     # BASELINE.json: "denoise-steps/sec + latent frames/sec, 49x480x720 bf16, 1/2/4/8 MI355X"
     assert base["metric"].startswith(d["metric"]) and d["unit"] == "steps/s" and "latent_frames_per_sec" in d
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] >= 5 and d["warmup"] >= 2 and d["higher_is_better"] is True
     assert d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["layers"] == 42
