@@ -59,6 +59,16 @@ __device__ __forceinline__ void dma_piece(uint32_t lds_base, uint32_t voff, cons
                  : "memory");
 }
 
+#ifdef BYA_GEMM_TIMELINE
+// Ablation builds only (tools/gemm_epilogue_timeline.py; never the shipped library): wall-clock stamps (100 MHz) of every
+// unit of an UNSPLIT launch, written by thread 0 to the last slab of the workspace -- [blockIdx][seq & 1][8] x u64: unit start,
+// K-loop end, -, -, unit end, -, K-tiles, valid.  The split instance is not instrumented: the stamps cost it 130 spilled
+// registers and what they then measure is scratch traffic.
+#define TL_STAMP(K) do { if (!SPLIT && tid == 0 && p.ws_slabs) tl[K] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TL_STAMP(K) do {} while (0)
+#endif
+
 // One unit of work: K-tiles [k0, k0 + nkk) of output tile (z, m0, n0).  role 0: the whole tile (ordinary epilogue);
 // 1: a partial sum, written to slab `slab`; 2: the finisher of a tile split into `parts` K-ranges (adds slabs
 // slab, slab + slab_step, ... then the ordinary epilogue; counter `ctr` says when they are complete).
@@ -293,6 +303,12 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
     bf16x8 fa[2][8], fw[2][8];
 
     for (;;) {
+#ifdef BYA_GEMM_TIMELINE
+        unsigned long long* const tl = reinterpret_cast<unsigned long long*>(p.ws_slabs + (size_t)(GEMM_WS_SLABS - 1) * (GEMM_WS_SLAB_BYTES / 4)) +
+                                       ((size_t)blockIdx.x * 2 + (seq & 1)) * 8;
+        TL_STAMP(0);
+        if (!SPLIT && tid == 0 && p.ws_slabs) { tl[6] = (unsigned long long)cur.nkk; tl[7] = cur.valid ? 1ull : 0ull; }
+#endif
         // ---- K-tile 0 of this output tile has landed for this wave (prologue wait / the wait in front of the previous
         // epilogue); make that true for everybody, then fetch its k-step-0 fragments
         asm volatile("s_barrier" ::: "memory");
@@ -871,6 +887,7 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         // K-tile 0 of the next output tile (16 pieces, requested during variant C) has landed once all but the 16 younger
         // pieces of its K-tile 1 have; the MFMAs are inline asm, so pad their last results before the epilogue reads them
         asm volatile("s_waitcnt vmcnt(16)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        TL_STAMP(1);
 
         if (SPLIT && cur.role == 2) {
             // ---- finisher of a split tile: the other K-ranges were started together with this one; wait for their slabs
@@ -981,6 +998,7 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
             }
         }
 
+        TL_STAMP(4);
         if (!nxt.valid) break;
         ++seq;
         cur = nxt;

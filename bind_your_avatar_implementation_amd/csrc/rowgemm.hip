@@ -17,8 +17,14 @@
 // MFMAs (half the MFMA issue slots), X in AGPRs and the previous chunk's epilogue written between the MFMAs of the next
 // chunk, still compiler-scheduled: bit-identical results, 13-19 % SLOWER on all four launch shapes
 // (profiles/r3_rowgemm_w4_compiler_scheduled_probe.json; hipcc triplicated the chunk loop and put 223 s_waitcnt and 117 s_nop
-// into it) -- removed again.  What the attention kernel taught this round (csrc/attn_w4.hip) applies here too: the
-// one-wave-per-SIMD form pays only with every instruction of the loop placed by hand.
+// into it) -- removed again.  A second attempt placed the chunk's 128 MFMAs and 64 fragment reads by hand (eight inline-asm
+// groups of 16 MFMAs with counted lgkmcnt waits, the previous chunk's epilogue in eight compiler-scheduled pieces between
+// them; clean code: no scratch in the loop, no compiler waits beyond the epilogue's LDS reads): bit-identical again and STILL
+// 12-27 % slower (profiles/r3_rowgemm_w4_hand_placed_probe.json: 83 vs 68 us on N = 1536).  A single wave issues in order,
+// so the epilogue's VALU work between two MFMA groups runs with the matrix pipe idle, where the 8-wave kernel's second wave
+// per SIMD fills it -- and, the larger term, neither form overlaps the X-fragment load of a row block (all 256 workgroups
+// request theirs at the same moment: 64 MB at launch, ~15 us of a 68 us launch) with MFMAs.  The kernel is bound by that and
+// by HBM bytes (N = 512 launches: 108 MB algorithmic in 37 us), not by LDS reads alone; see DESIGN.md section 9.
 // The product is computed transposed (W fragment = A operand, X fragment = B operand), so a lane ends up with 16
 // consecutive output columns of one token: 16-byte stores, no LDS transpose.
 //
