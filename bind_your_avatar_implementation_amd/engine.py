@@ -30,6 +30,16 @@ def _key(tensors):
     return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
 
 
+# the Linears that can run on e4m3 operands: attn1 q|k|v, attn1.to_out, ff.net.0, ff.net.2 of every DiT block, and the
+# perceiver / audio query projections
+FP8_LINEARS = ("qkv", "out", "ff1", "ff2", "pq", "aq")
+# ... and the ones that do by default: the four DiT Linears.  The two query projections feed the Embedding Router and the
+# cross-attentions, whose sigmoid routing amplifies their error: in e4m3 the perceiver to_q ALONE doubles the 42-layer output
+# error (3.7e-2 against the bf16 engine's 1.8e-2; any one DiT Linear: 1.9-2.0e-2) for 1 % of the step time
+# (tools/fp8_error_by_linear.py, profiles/r3_fp8_error_by_linear.json).
+FP8_DEFAULT = ("qkv", "out", "ff1", "ff2")
+
+
 class DenoiseEngine:
     # Identities / audio streams per sample.  The reference forward dereferences exactly id_cond[0], id_cond[1]
     # (models/transformer.py:638-639) and repeats the video twice (:784, :881); everything else in it (router, perceiver,
@@ -144,16 +154,25 @@ class DenoiseEngine:
                       for b in m.transformer_blocks]
         self.w8 = None
         if self.fp8_weights:
+            # which Linears run in e4m3 (enable_fp8_weights(linears=...) / BYA_FP8_LINEARS; "all" = every kind): the rest stays bf16
+            keep = getattr(m, "_fp8_linears", None) or os.environ.get("BYA_FP8_LINEARS") or FP8_DEFAULT
+            keep = set(FP8_LINEARS if keep == "all" else keep.split(",")) if isinstance(keep, str) else set(keep)
+            unknown = keep - set(FP8_LINEARS)
+            if unknown:
+                raise ValueError(f"fp8 linears {sorted(unknown)}: expected a subset of {FP8_LINEARS}")
             blocks = m.transformer_blocks
-            self.w8 = {"qkv": [ops.quantize_rows_fp8(w) for w in self.qkv_w],
-                       "out": [ops.quantize_rows_fp8(b.attn1.to_out[0].weight) for b in blocks],
-                       "ff1": [ops.quantize_rows_fp8(b.ff.net[0].proj.weight) for b in blocks],
-                       "ff2": [ops.quantize_rows_fp8(b.ff.net[2].weight) for b in blocks]}
-            # ... and the two 3072-wide query projections that sit directly behind a LayerNorm of the video rows
-            if m.is_train_face:
-                self.w8["pq"] = [ops.quantize_rows_fp8(pc.to_q.weight) for pc in m.perceiver_cross_attention]
-            if m.is_train_audio:
-                self.w8["aq"] = [ops.quantize_rows_fp8(al["attn"].to_q.weight) for al in m.audio_model.layers]
+            source = {"qkv": lambda: self.qkv_w,
+                      "out": lambda: [b.attn1.to_out[0].weight for b in blocks],
+                      "ff1": lambda: [b.ff.net[0].proj.weight for b in blocks],
+                      "ff2": lambda: [b.ff.net[2].weight for b in blocks],
+                      # ... and the two 3072-wide query projections that sit directly behind a LayerNorm of the video rows
+                      "pq": lambda: [pc.to_q.weight for pc in m.perceiver_cross_attention] if m.is_train_face else None,
+                      "aq": lambda: [al["attn"].to_q.weight for al in m.audio_model.layers] if m.is_train_audio else None}
+            self.w8 = {}
+            for k in FP8_LINEARS:
+                ws = source[k]() if k in keep else None
+                if ws is not None:
+                    self.w8[k] = [ops.quantize_rows_fp8(w) for w in ws]
         pe = getattr(m.patch_embed, "pos_embedding", None)
         use_pe = (not self.cfg.use_rotary_positional_embeddings) or self.cfg.use_learned_positional_embeddings
         self.pos_embedding = pe[0] if (pe is not None and use_pe) else None
@@ -513,7 +532,7 @@ class DenoiseEngine:
                 ln_kw = dict(eps=nz.norm.eps, shift0=mo[:, 3 * D:], scale0=mo[:, 4 * D:], shift1=mo, scale1=mo[:, D:],
                              split=Tt_loc, mod_batch_stride=mbs)
                 xq = None
-                if self.w8 is not None and self.fuse_ln_quant:
+                if self.w8 is not None and ("qkv", "ff1")[half] in self.w8 and self.fuse_ln_quant:
                     # the AdaLN output feeds exactly one Linear (q|k|v, or the MLP's first): emit it in e4m3 directly
                     xq = ops.layernorm_fp8(x, *self._a8(xn.shape), nz.norm.weight, nz.norm.bias, **ln_kw)
                 else:

@@ -364,11 +364,15 @@ class BindyouravatarTransformer3DModel(nn.Module):
         self._pending_lora = []
         return n
 
-    def enable_fp8_weights(self, enabled: bool = True):
+    def enable_fp8_weights(self, enabled: bool = True, linears=None):
         """BASELINE configs[4]: run attn1.to_q|k|v / to_out and the MLP of every DiT block on OCP e4m3 operands (weights
         quantised per output channel when the engine packs them, activations per row on the fly; everything else stays
-        bf16).  No reference counterpart (the reference is bf16/fp16 only); returns self."""
+        bf16).  ``linears``: which of engine.FP8_LINEARS ("qkv", "out", "ff1", "ff2", "pq", "aq") to quantise, a subset or "all";
+        default engine.FP8_DEFAULT = the four DiT Linears -- the perceiver / audio query projections stay bf16 because the
+        routing amplifies their error (tools/fp8_error_by_linear.py measures what each costs).  No reference counterpart (the
+        reference is bf16/fp16 only); returns self."""
         self._fp8_weights = bool(enabled)
+        self._fp8_linears = (linears if isinstance(linears, str) else tuple(linears)) if linears else None
         self.invalidate_engine()
         return self
 

@@ -111,13 +111,16 @@ class FakeQuantLinear(torch.nn.Module):
         return y.to(x.dtype)
 
 
-def with_fp8_dit_linears(orc):
+def with_fp8_dit_linears(orc, query_projections=False):
+    """The engine's default set (engine.FP8_DEFAULT: the four DiT Linears); query_projections=True = linears="all"."""
     for blk in orc.transformer_blocks:
         at = blk.attn1
         at.to_q, at.to_k, at.to_v = FakeQuantLinear(at.to_q), FakeQuantLinear(at.to_k), FakeQuantLinear(at.to_v)
         at.to_out[0] = FakeQuantLinear(at.to_out[0])
         blk.ff.net[0].proj = FakeQuantLinear(blk.ff.net[0].proj)
         blk.ff.net[2] = FakeQuantLinear(blk.ff.net[2])
+    if not query_projections:
+        return orc
     for pc in orc.perceiver_cross_attention:                 # the query projections behind a LayerNorm of the video rows
         pc.to_q = FakeQuantLinear(pc.to_q)
     for layer in orc.audio_model.layers:
@@ -127,8 +130,8 @@ def with_fp8_dit_linears(orc):
 
 def test_forward_with_fp8_weights_vs_fake_quantised_oracle(dev):
     """Small geometry (3 x 8 x 12 video tokens + 226 text rows, full 3072-wide model, 2 layers, 2 identities, CFG batch of
-    2): the engine with fp8 weights against the CPU oracle whose six DiT Linears per block (and the perceiver / audio query projections) are replaced by
-    the fp8 definition above.  Bar, stage by stage, as for the bf16 engine: err(engine, fp32 oracle) <= 1.5 x err(oracle run in
+    2): the engine with fp8 weights -- all six kinds, linears="all" -- against the CPU oracle whose DiT Linears and perceiver / audio
+    query projections are replaced by the fp8 definition above.  Bar, stage by stage, as for the bf16 engine: err(engine, fp32 oracle) <= 1.5 x err(oracle run in
     bf16, fp32 oracle) + 1e-3 (both carry the same e4m3 operands; what differs is bf16 rounding around them -- which also
     moves a few e4m3 roundings by one step, on both sides).  The distance to the unquantised model is printed and bounded
     loosely: that is the price of e4m3, not an implementation property."""
@@ -149,16 +152,16 @@ def test_forward_with_fp8_weights_vs_fake_quantised_oracle(dev):
     taps32, taps16, tapsg = {}, {}, {}
     with torch.no_grad():
         plain = orc(**inp)[0]
-        orc = with_fp8_dit_linears(orc)
+        orc = with_fp8_dit_linears(orc, query_projections=True)
         ref = orc(taps=taps32, **inp)[0]
         orc16 = orc.to(torch.bfloat16)
         inp16 = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
         inp16["id_cond"] = [t.to(torch.bfloat16) for t in inp["id_cond"]]
         inp16["id_vit_hidden"] = [[t.to(torch.bfloat16) for t in l] for l in inp["id_vit_hidden"]]
         ref16 = orc16(taps=taps16, **inp16)[0]
-    model.enable_fp8_weights()
+    model.enable_fp8_weights(linears="all")                  # all six kinds (the default leaves the query projections in bf16)
     out = model(**gi)[0]
-    assert model._engine.w8 is not None
+    assert model._engine.w8 is not None and set(model._engine.w8) == {"qkv", "out", "ff1", "ff2", "pq", "aq"}
     model._engine.step(gi["hidden_states"], gi["encoder_hidden_states"], gi["timestep"], gi["image_rotary_emb"],
                        gi["id_cond"], gi["id_vit_hidden"], gi["audio_embeds"], gi["af_matrix"], None, taps=tapsg)
     for name in ["block0", "face0", "audio0", "block1", "audio1"]:
@@ -180,8 +183,8 @@ def test_config4_fp8_weights_three_identities_97_frames_vs_fake_quantised_oracle
     """BASELINE configs[4] with ALL THREE of its elements in one forward: fp8 weights + 3 identities / audio streams + a
     97-frame clip (25 latent frames), at a small spatial size (25 x 6 x 10 video tokens + 226 text rows, full 3072-wide
     model, 2 layers, cyclic audio-to-face matrix).  Oracle: oracle/model.py (whose n-identity audio weights are the
-    build-defined generalisation of the reference's two-stream swap) with its DiT Linears and the two
-    query projections replaced by the fp8 definition of include/bya.h -- no reference counterpart exists for either
+    build-defined generalisation of the reference's two-stream swap) with its four DiT Linears (the
+    engine's default fp8 set) replaced by the fp8 definition of include/bya.h -- no reference counterpart exists for either
     (models/transformer.py:638-639,784,881 hard-code two identities; nothing in the reference is fp8).  Usual stage bar:
     err(engine, fp32 oracle) <= 1.5 x err(oracle in bf16, fp32 oracle) + 1e-3."""
     from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel
@@ -210,7 +213,7 @@ def test_config4_fp8_weights_three_identities_97_frames_vs_fake_quantised_oracle
     model.enable_fp8_weights()
     out = model(**gi)[0]
     eng = model._engine
-    assert eng.w8 is not None and eng.n_id == 3
+    assert eng.w8 is not None and set(eng.w8) == {"qkv", "out", "ff1", "ff2"} and eng.n_id == 3
     eng.step(gi["hidden_states"], gi["encoder_hidden_states"], gi["timestep"], gi["image_rotary_emb"], gi["id_cond"],
              gi["id_vit_hidden"], gi["audio_embeds"], gi["af_matrix"], None, taps=tapsg)
     assert tapsg["router0_b0"].shape[-1] == 3
@@ -270,7 +273,7 @@ def test_fused_and_unfused_fp8_engine_are_bit_identical(dev, monkeypatch):
     from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel
     from bind_your_avatar_implementation_amd.synth import synth_inputs
     from test_forward_gpu import SMALL_KW, to_dev
-    model = BindyouravatarTransformer3DModel(**SMALL_KW, device=dev).init_synthetic(seed=1, fast=True).enable_fp8_weights()
+    model = BindyouravatarTransformer3DModel(**SMALL_KW, device=dev).init_synthetic(seed=1, fast=True).enable_fp8_weights(linears="all")
     gi = to_dev(synth_inputs(batch=2, frames=3, height=16, width=24, seed=3, uncond_first=True), dev)
     fused = model(**gi)[0].clone()
     assert model._engine.fuse_ln_quant
@@ -287,7 +290,7 @@ def test_fp8_engine_hip_graph_replay_matches_eager(dev):
     from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel
     from bind_your_avatar_implementation_amd.synth import synth_inputs
     from test_forward_gpu import SMALL_KW, to_dev
-    model = BindyouravatarTransformer3DModel(**SMALL_KW, device=dev).init_synthetic(seed=1, fast=True).enable_fp8_weights()
+    model = BindyouravatarTransformer3DModel(**SMALL_KW, device=dev).init_synthetic(seed=1, fast=True).enable_fp8_weights(linears="all")
     outs = {}
     for mode in ("eager", "graph"):
         model.use_hip_graph = mode == "graph"
