@@ -345,7 +345,7 @@ def main():
                 torch.cuda.synchronize()
                 sec8 = (time.perf_counter() - t1) / 3
                 res["fp8_weights_variant"] = {"value": 1.0 / sec8, "unit": "steps/s", "ms_per_step": sec8 * 1e3, "steps": 3,
-                                              "dtype": "fp8 (e4m3 operands, fp32 accumulate) in the DiT Linears, bf16 elsewhere",
+                                              "dtype": "fp8 (e4m3 operands, fp32 accumulate) in the four DiT Linears of every block, bf16 elsewhere",
                                               "note": "not the headline metric (which is bf16); parity: tests/test_fp8_gpu.py"}
                 if not args.no_kernel_timers:
                     ops.enable_kernel_timers()
@@ -355,7 +355,7 @@ def main():
                     t8 = sum(kt8.get("bya_gemm_fp8", []))
                     if t8 > 0:
                         res["fp8_weights_variant"]["gemm_fp8_roofline"] = {
-                            "kernel": "bya_gemm_fp8 (gemm_fp8_kernel<128,128>: v_mfma_scale_f32_16x16x128_f8f6f4, e4m3)",
+                            "kernel": "bya_gemm_fp8 (gemm256p_fp8_kernel, persistent 256x256 tiles, one wave per SIMD: v_mfma_f32_16x16x128_f8f6f4, e4m3; the four DiT Linears)",
                             "bound": "mfma", "achieved": fl8 / t8 / 1e12, "peak": 5000.0, "unit": "TFLOP/s",
                             "frac": fl8 / t8 / 1e12 / 5000.0, "launches": len(kt8["bya_gemm_fp8"]), "ms_per_step": t8 * 1e3,
                             "quantiser_ms_per_step": (sum(kt8.get("bya_quantize_rows_fp8", [])) +

@@ -13,6 +13,9 @@
 // Same epilogue as every other GEMM here (bias, activation, gate, residual, q|k|v split): gemm_common.h.
 #include "gemm_fp8_kernel.h"
 
+bool bya_gemm256p_fp8_eligible(const void* args);                                                       // gemm_fp8_v4.hip
+int bya_launch_gemm256p_fp8(const void* args, const float* sa, const float* sw, int batch, int gm, hipStream_t s);
+
 namespace {
 
 // ---- row quantiser: one workgroup per row.  scale[m] = max|x[m,:]| / 448 (1 for an all-zero row),
@@ -98,7 +101,16 @@ extern "C" int bya_gemm_fp8(const void* A8, const float* a_scale, const void* W8
     // 256 x 256 form (8 waves, 128 KiB ring, one workgroup per CU, half the L2 -> LDS bytes per FLOP) measured 4-16 %
     // slower on the four DiT shapes with this simple two-barrier loop, a one-wave-per-SIMD instantiation 8-20 % slower under
     // hipcc's schedule (profiles/r2_fp8_probe.txt; both removed from the tree in round 3).
+    // ... until the loop was placed by hand: gemm_fp8_v4.hip (one wave per SIMD, persistent) takes every launch that is big
+    // enough to fill its 256 x 256 tiles; BYA_FP8_KERNEL=128 (read per call: A/B runs) keeps everything on the kernel above.
+    const char* kv = getenv("BYA_FP8_KERNEL");
+    const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch;
+    const bool big = !(kv && kv[0] == '1') && tiles256 >= 200;        // (about a round of its 256 workgroups, or more)
+    const char* gm_env = getenv("BYA_FP8_GM");
+    const int gm = gm_env ? atoi(gm_env) : 4;
     return gemm_row_chunks(a, d->batch, 1, [&](const GemmArgs& piece, int batch, long long row0) {
+        if (big && bya_gemm256p_fp8_eligible(&piece))
+            return bya_launch_gemm256p_fp8(&piece, a_scale + row0, w_scale, batch, gm, stream);
         return launch_fp8<128, 128, 2, 2>(piece, a_scale + row0, w_scale, batch, stream);
     });
 }

@@ -55,6 +55,12 @@ def test_quantize_rows_matches_the_definition_byte_for_byte(dev, M, K):
     (1000, 768, 3072, {"bias": True, "act": "gelu_tanh"}),
     (777, 1024, 512, {"bias": True, "gate_res": True}),
     (640, 1536, 1024, {"bias": True, "split": True}),
+    # >= 200 tiles of 256 x 256: the persistent one-wave-per-SIMD kernel (csrc/gemm_fp8_v4.hip), ragged in M and N,
+    # its shortest K (four K-tiles), every epilogue kind
+    (4000, 3592, 512, {"bias": True, "act": "gelu_tanh"}),
+    (4100, 3328, 1536, {"bias": True, "gate_res": True}),
+    (3900, 3840, 1024, {"bias": True, "split": True}),
+    (3700, 3848, 3072, {}),
 ])
 def test_gemm_fp8_vs_exact_product_of_the_same_bytes(dev, M, N, K, kw):
     from bind_your_avatar_implementation_amd import ops
@@ -91,6 +97,26 @@ def test_gemm_fp8_vs_exact_product_of_the_same_bytes(dev, M, N, K, kw):
         full = a.double() @ w.double().T
         print(f"   vs the unquantised product: {rel_fro(got.float().cpu(), full.float()):.3e}")
         assert rel_fro(got.float().cpu(), full.float()) < 6e-2
+
+
+def test_gemm_fp8_persistent_kernel_equals_the_128_tile_kernel(dev, monkeypatch):
+    """The two e4m3 GEMM kernels differ only in how they walk K and the output tiles: same bytes in, same bf16 out up to
+    the order of fp32 additions inside a K-tile (a last-bit flip on a handful of elements of a long K)."""
+    from bind_your_avatar_implementation_amd import ops
+    M, N, K = 4500, 3200, 2048
+    a, w = rnd((M, K), 12), rnd((N, K), 13, std=K ** -0.5)
+    bias, res = rnd((N,), 14).to(dev), rnd((M, N), 15).to(dev)
+    a8, sa = ops.quantize_rows_fp8(a.to(dev))
+    w8, sw = ops.quantize_rows_fp8(w.to(dev))
+    outs = {}
+    for kern in ("128", "v4"):
+        monkeypatch.setenv("BYA_FP8_KERNEL", kern)
+        outs[kern] = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm_fp8(a8, sa, w8, sw, outs[kern], bias=bias, res=res)
+    diff = (outs["v4"].float() - outs["128"].float()).abs()
+    frac = float((diff > 0).float().mean())
+    print(f"elements that differ: {frac:.2e}, max abs {float(diff.max()):.3e}")
+    assert torch.isfinite(outs["v4"].float()).all() and frac < 1e-4 and float(diff.max()) <= 0.0625
 
 
 # ------------------------------------------------------------------------------------------ forward level
