@@ -105,11 +105,11 @@ def test_product_path_fails_loudly_without_gpu():
 
 
 def test_generated_gemm_schedules_match_their_tables():
-    """The hand-placed instruction streams of gemm_v4.hip and attn_w4.hip are emitted by tools/gen_*_schedule.py from
-    placement tables; the committed sources must be exactly what the tables generate."""
+    """The hand-placed instruction streams of gemm_v4.hip, gemm_fp8_v4.hip and attn_w4.hip are emitted by
+    tools/gen_*_schedule.py from placement tables; the committed sources must be exactly what the tables generate."""
     import subprocess
     import sys
-    for gen in ("gen_gemm_v4_schedule.py", "gen_attn_w4_schedule.py"):
+    for gen in ("gen_gemm_v4_schedule.py", "gen_gemm_fp8_schedule.py", "gen_attn_w4_schedule.py"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), "--check"], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
 
@@ -153,7 +153,7 @@ def test_valu_only_kernels_hold_no_packed_fp32(lib_path):
         # unnoticed.
         import json
         rec_path = os.path.join(ROOT, "profiles", "r3_packed_fp32_counts.json")
-        counts = {src: len(packed.findall(device_asm(src, tmp))) for src in ("gemm.hip", "gemm_v4.hip", "attn.hip", "rowgemm.hip")}
+        counts = {src: len(packed.findall(device_asm(src, tmp))) for src in ("gemm.hip", "gemm_v4.hip", "gemm_fp8_v4.hip", "attn.hip", "rowgemm.hip")}
         print("packed-fp32 instructions in the MFMA translation units:", counts)
         if os.environ.get("BYA_RECORD_PACKED_COUNTS") == "1":
             with open(rec_path, "w") as f:
