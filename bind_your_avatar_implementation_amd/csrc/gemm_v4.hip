@@ -36,6 +36,10 @@
 // explicit s_nops.  This translation unit is compiled WITHOUT -amdgpu-mfma-vgpr-form (accumulators in AGPRs).
 #include "gemm_common.h"
 
+#ifndef BYA_GEMM_ABLATE
+#define BYA_GEMM_ABLATE 0
+#endif
+
 namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -325,20 +329,29 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         // One K-tile, variant V (see the top); t = its index inside the output tile.
         auto ktile = [&](int t, auto v_c) {
             constexpr char V = decltype(v_c)::value;
-            const uint32_t soff = (uint32_t)((t + 2) * (BK * 2));
+            const uint32_t soff = (BYA_GEMM_ABLATE & 4) ? 0u : (uint32_t)((t + 2) * (BK * 2));     // (ablation 4: every K-tile re-reads K-tile 0)
 #define MF(S, I, J) \
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(fw[S][I]), "v"(fa[S][J]))
 #define MFZ(S, I, J) \
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[I][J]) : "v"(fw[S][I]), "v"(fa[S][J]))
+#if BYA_GEMM_ABLATE & 1                 // timing-only ablation builds (tools/): no LDS-DMA inside the K-loop
+#define DA(Q) do {} while (0)
+#define DW(Q) do {} while (0)
+#else
 #define DA(Q) DMA_A(Q, fill, voA, rsA, soff)
 #define DW(Q) DMA_W(Q, fill, voW, rsW, soff)
+#endif
 #define PA(Q) DMA_A(Q, fill, voA, rsAn, 0u)
 #define PW(Q) DMA_W(Q, fill, voW, rsWn, 0u)
 #define QA(Q) DMA_A(Q, fill, voA, rsAn, (uint32_t)(BK * 2))
 #define QW(Q) DMA_W(Q, fill, voW, rsWn, (uint32_t)(BK * 2))
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#if BYA_GEMM_ABLATE & 2                 // ... no barriers inside the K-loop
+#define BAR() do {} while (0)
+#else
 #define BAR() asm volatile("s_barrier" ::: "memory")
+#endif
 #define FLIP0() do { cA0 ^= STAGE; cW0 ^= STAGE; } while (0)
 #define FLIP1() do { cA1 ^= STAGE; cW1 ^= STAGE; fill ^= STAGE; } while (0)
             // GENERATED-BEGIN (tools/gen_gemm_v4_schedule.py)
