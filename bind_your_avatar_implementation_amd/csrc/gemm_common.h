@@ -22,6 +22,13 @@ struct GemmArgs {
     // 1024 counters; null = the last, partial round of tiles is not split
     float* ws_slabs;
     unsigned* ws_counters;
+    // Implicit-GEMM 3 x 3 x 3 convolution on the persistent kernel (bya_vae_conv3d; gemm_v4.hip, CONV instance): A is the
+    // zero-padded channels-last input [To + 2, Hp, Wp, C] seen as a matrix of pixels x C (lda = C), row m of the product is
+    // the padded pixel m of the OUTPUT grid [To, Hp, Wp] (rows with h >= H or w >= W are computed and dropped), K-tile t is
+    // the 64-channel group t % cpg of tap t / cpg = (dt, dh, dw): the same rows, ((dt Hp + dh) Wp + dw) pixels further on.
+    int conv_cpg_log2 = -1;            // log2(C / 64); < 0: plain GEMM
+    int conv_Hp = 0, conv_Wp = 0, conv_H = 0, conv_W = 0, conv_To = 0;
+    long long conv_a_bytes = 0;        // bytes of the padded input from A on (reads past it return zeros)
 };
 
 constexpr size_t GEMM_WS_COUNTER_BYTES = 4096, GEMM_WS_SLAB_BYTES = 256 * 256 * 4, GEMM_WS_SLABS = 256;

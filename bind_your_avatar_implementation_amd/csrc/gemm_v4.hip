@@ -90,7 +90,7 @@ constexpr int DEFAULT_MIN_SPLIT_KTILES = 40;
 // nothing else happens.  Same call site as the ordinary epilogue and through one VALU multiply: a second kind of consumer
 // of the asm-owned accumulators (a plain store of them) made hipcc put the store's data tuples into AGPRs too and evict
 // accumulators to scratch right behind their last MFMA, inside the K-loop -- 250 registers of scratch traffic per tile.
-template <int ACT, int JB, bool SPLIT>
+template <int ACT, int JB, bool SPLIT, bool CONV = false>
 __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wave, int n_wave, int fr, int fq,
                                               const f32x4 (&acc)[8][8], int wave, int lane, float* raw_out = nullptr) {
     const bool has_res = p.res != nullptr, has_gate = p.gate0 != nullptr, has_bias = p.bias != nullptr;
@@ -127,7 +127,16 @@ __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wa
         for (int jj = 0; jj < JB; ++jj) {
             const int m = m_wave + 16 * (jb + jj) + fr;
             mok[jj] = m < p.M;
-            const uint32_t mc = mok[jj] ? (uint32_t)m : 0u;
+            uint32_t mc = mok[jj] ? (uint32_t)m : 0u;
+            if constexpr (CONV) {
+                // row m = padded pixel (t, h, w) of the output grid [To, Hp, Wp]: kept if it is a real pixel, and then stored
+                // (and its residual read) at row (t H + h) W + w of the unpadded output
+                const uint32_t plane = (uint32_t)(p.conv_Hp * p.conv_Wp);
+                const uint32_t t = mc / plane, rem = mc - t * plane;
+                const uint32_t h = rem / (uint32_t)p.conv_Wp, w = rem - h * (uint32_t)p.conv_Wp;
+                mok[jj] = mok[jj] && h < (uint32_t)p.conv_H && w < (uint32_t)p.conv_W && t < (uint32_t)p.conv_To;
+                mc = mok[jj] ? (t * (uint32_t)p.conv_H + h) * (uint32_t)p.conv_W + w : 0u;
+            }
             rs[jj] = has_rs ? p.bias_rowscale[(long long)z * p.M + mc] : 1.0f;
             roff[jj] = mc * (uint32_t)(p.ldres * 2);
             coff[jj] = mc * (uint32_t)(p.ldc * 2);
@@ -185,9 +194,10 @@ __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wa
 // SPLIT = false: the instance for launches that will not split a tile (no workspace, short K, or nothing left over): its
 // epilogue has no slab branch -- that branch alone costs the ordinary path 1.5-2.5 % on K = 3072 shapes (same-box A/B,
 // profiles/r2_gemm_epilogue_variants_same_box.txt) because it cuts the unrolled epilogue into blocks.
-template <bool SPLIT>
+template <bool SPLIT, bool CONV = false>
 __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_m, int tiles_n, int batch, int split_arg,
                                                           int min_seg, unsigned epoch) {
+    static_assert(!(SPLIT && CONV), "the convolution instance does not split K");
     const int split = SPLIT ? split_arg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 256, BN = 256, STAGE = (BM + BN) * BK * 2, TILE_A = BM * BK * 2;
@@ -282,7 +292,9 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         voW[q] = (uint32_t)wcol * (uint32_t)(p.ldw * 2) + chunk16;
     }
     auto a_rsrc = [&](const TileCoord& c) {
-        const long long left = ((long long)(p.M - 1 - c.m0) * p.lda + p.K - c.k0 * BK) * 2;
+        long long left = CONV ? p.conv_a_bytes - (long long)c.m0 * p.lda * 2
+                              : ((long long)(p.M - 1 - c.m0) * p.lda + p.K - c.k0 * BK) * 2;
+        if (CONV && left > 0xffffffffLL) left = 0xffffffffLL;          // (a tile reaches < 2^31 bytes past its first row)
         return raw_rsrc(p.A + (long long)c.z * p.a_bs + (long long)c.m0 * p.lda + c.k0 * BK,
                         c.valid && left > 0 ? (uint32_t)left : 0u);
     };
@@ -330,6 +342,13 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         auto ktile = [&](int t, auto v_c) {
             constexpr char V = decltype(v_c)::value;
             const uint32_t soff = (BYA_GEMM_ABLATE & 4) ? 0u : (uint32_t)((t + 2) * (BK * 2));     // (ablation 4: every K-tile re-reads K-tile 0)
+            uint32_t soffA = soff;                            // (W's K-tiles are plain columns in either case)
+            if constexpr (CONV) {
+                // K-tile t + 2 = channel group cg of tap (dt, dh, dw): the tile's rows, shifted by the tap (scalar arithmetic)
+                const uint32_t kt = (uint32_t)(t + 2), tap = kt >> p.conv_cpg_log2, cg = kt - (tap << p.conv_cpg_log2);
+                const uint32_t dt = tap / 9u, r9 = tap - dt * 9u, dh = r9 / 3u, dw = r9 - dh * 3u;
+                soffA = (((dt * (uint32_t)p.conv_Hp + dh) * (uint32_t)p.conv_Wp + dw) * (uint32_t)p.lda + cg * 64u) * 2u;
+            }
 #define MF(S, I, J) \
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(fw[S][I]), "v"(fa[S][J]))
 #define MFZ(S, I, J) \
@@ -338,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
 #define DA(Q) do {} while (0)
 #define DW(Q) do {} while (0)
 #else
-#define DA(Q) DMA_A(Q, fill, voA, rsA, soff)
+#define DA(Q) DMA_A(Q, fill, voA, rsA, soffA)
 #define DW(Q) DMA_W(Q, fill, voW, rsW, soff)
 #endif
 #define PA(Q) DMA_A(Q, fill, voA, rsAn, 0u)
@@ -972,7 +991,7 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
                 }
             }
             auto run = [&](auto act_tag) {
-                epilogue_wide<decltype(act_tag)::value, 2, SPLIT>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc, wave, lane);
+                epilogue_wide<decltype(act_tag)::value, 2, SPLIT, CONV>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc, wave, lane);
             };
             dispatch_act_big(p.act, run);
             asm volatile("s_barrier" ::: "memory");          // every wave has read the slabs: arrivals back to 0 (same epoch:
@@ -982,8 +1001,8 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
             // ---- whole tile (ordinary epilogue), or (role 1) a split tile's partial sums -> slab, then drained and counted
             float* const raw_out = (SPLIT && cur.role == 1) ? p.ws_slabs + (size_t)cur.slab * (GEMM_WS_SLAB_BYTES / 4) : nullptr;
             auto run = [&](auto act_tag) {
-                epilogue_wide<decltype(act_tag)::value, 2, SPLIT>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc, wave,
-                                                                  lane, raw_out);
+                epilogue_wide<decltype(act_tag)::value, 2, SPLIT, CONV>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc,
+                                                                        wave, lane, raw_out);
             };
             dispatch_act_big(p.act, run);
             if (SPLIT && cur.role == 1) {
@@ -1022,6 +1041,19 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
 }
 
 }  // namespace
+
+// Implicit-GEMM convolution launch (bya_vae_conv3d, vae.hip): the CONV instance, no K-split.
+int bya_launch_conv256p(const void* args, hipStream_t s) {
+    const GemmArgs& a = *static_cast<const GemmArgs*>(args);
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+    const long long total = (long long)tiles_m * tiles_n;
+    const int blocks = (int)(total < 256 ? (total + 7) / 8 * 8 : 256);
+    const size_t lds = 2 * 512 * BK * 2;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256p_kernel<false, true>), (int)lds, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
+    BYA_LAUNCH((gemm256p_kernel<false, true>), dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, 1, 0, 1 << 30, 0u);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
 
 int bya_gemm_split_min_ktiles() {
     const char* e = getenv("BYA_GEMM_SPLITK_MIN");           // test / tuning switch, read per call

@@ -20,8 +20,21 @@
 // bya_vae_norm_act: y = act( (x - mean_g) rstd_g gamma_c + beta_c ) with, for the decoder,
 //   ... * Y[z(row)][c] + B[z(row)][c]  (CogVideoXSpatialNorm3D: conv_y / conv_b of the latent are 1x1x1, hence commute
 //   with its nearest resize: they are evaluated at latent resolution by a GEMM and indexed here).
+//
+// bya_vae_conv3d (round 3): the 3 x 3 x 3 stride-1 convolutions of the resnet blocks (C = 128 / 256 / 512: > 95 % of the
+//   decoder's FLOPs) WITHOUT a patch matrix -- an implicit GEMM on the persistent MFMA kernel (gemm_v4.hip, CONV instance).
+//   The producer (bya_vae_norm_act, out_pad = 1) writes the conv input zero-padded, [To + 2, H + 2, W + 2, C]: two context
+//   frames in front (the conv cache or the first frame again), one pixel of zeros around every frame.  With the output grid
+//   padded the same way, tap (dt, dh, dw) of output pixel m is input pixel m + (dt Hp + dh) Wp + dw: every K-tile of the GEMM
+//   is the SAME 256 rows of the pixel matrix at a scalar offset, which is exactly what the kernel's LDS-DMA staging takes
+//   (per-lane row offsets + one scalar per K-tile).  Rows that are padding are computed and dropped by the epilogue (0.7 %
+//   of the rows at 480 x 720, 5 % at 60 x 90).  The patch path wrote and re-read 27 x the activation (117 GB per convolution
+//   at the top level: HBM-bound at ~500 TFLOP/s by construction); this one reads it from the L2.
 #include "bya_common.h"
+#include "gemm_common.h"
 #include "../../include/bya.h"
+
+int bya_launch_conv256p(const void* args, hipStream_t s);      // gemm_v4.hip
 
 namespace {
 
@@ -168,6 +181,7 @@ struct NormArgs {
     float count, eps;                        // elements per group of the chunk
     int T, H, W, Tz, hz, wz, shift, tmode;   // row -> (t, h, w) -> latent position (h >> shift, w >> shift, frame by tmode)
     int ldz;                                 // row stride of zy / zb (they may be the two halves of one GEMM output)
+    int out_pad;                             // 1: y is the zero-padded conv input [T + 2, H + 2, W + 2, C] (bya_vae_conv3d)
 };
 
 __global__ __launch_bounds__(256) void vae_norm_act_kernel(NormArgs p) {
@@ -208,7 +222,15 @@ __global__ __launch_bounds__(256) void vae_norm_act_kernel(NormArgs p) {
         if (p.act == 1) y = y / (1.0f + __expf(-y));      // SiLU
         o[e] = y;
     }
-    *reinterpret_cast<u32x4*>(p.y + r * p.C + c0) = pack8(o);
+    long long ro = r;
+    if (p.out_pad) {
+        long long rr = r;
+        const int w = (int)(rr % p.W); rr /= p.W;
+        const int h = (int)(rr % p.H);
+        const int t = (int)(rr / p.H);
+        ro = ((long long)(t + 2) * (p.H + 2) + h + 1) * (p.W + 2) + w + 1;
+    }
+    *reinterpret_cast<u32x4*>(p.y + ro * p.C + c0) = pack8(o);
 }
 
 }  // namespace
@@ -249,7 +271,7 @@ extern "C" int bya_vae_groupnorm_stats(const void* x, float* sums, float* partia
 extern "C" int bya_vae_norm_act(const void* x, void* y, const float* sums, const void* gamma, const void* beta, const void* zy,
                                 const void* zb, int64_t rows, int32_t C, int32_t groups, int32_t act, float eps, int32_t T,
                                 int32_t H, int32_t W, int32_t Tz, int32_t hz, int32_t wz, int32_t tmode, int64_t ldz,
-                                hipStream_t stream) {
+                                int32_t out_pad, hipStream_t stream) {
     if (!x || !y || !sums || !gamma || !beta || rows <= 0 || C <= 0 || groups <= 0 || C % groups || C % 8) return BYA_ERR_SHAPE;
     if ((zy == nullptr) != (zb == nullptr)) return BYA_ERR_SHAPE;
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)zy | (uintptr_t)zb) & 15) return BYA_ERR_ALIGN;
@@ -258,6 +280,8 @@ extern "C" int bya_vae_norm_act(const void* x, void* y, const float* sums, const
     p.zy = (const bf16_t*)zy; p.zb = (const bf16_t*)zb; p.rows = rows; p.C = C; p.groups = groups; p.act = act;
     p.count = (float)((double)rows * (C / groups)); p.eps = eps;
     p.T = T; p.H = H; p.W = W; p.Tz = Tz; p.hz = hz; p.wz = wz; p.tmode = tmode; p.ldz = (int)ldz;
+    p.out_pad = out_pad ? 1 : 0;
+    if (out_pad && (T <= 0 || H <= 0 || W <= 0 || (long long)T * H * W != rows)) return BYA_ERR_SHAPE;
     if (zy) {
         if ((long long)T * H * W != rows || hz <= 0 || wz <= 0 || H % hz || W % wz || H / hz != W / wz || ldz % 8) return BYA_ERR_SHAPE;
         int sh = 0;
@@ -270,4 +294,30 @@ extern "C" int bya_vae_norm_act(const void* x, void* y, const float* sums, const
     const long long total = rows * (C >> 3);
     BYA_LAUNCH(vae_norm_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+extern "C" int bya_vae_conv3d(const void* xpad, const void* w, const void* bias, const void* res, void* out, int32_t To,
+                              int32_t H, int32_t W, int32_t C, int32_t Cout, int64_t ldw, int64_t ldc, int64_t ldres,
+                              hipStream_t stream) {
+    if (!xpad || !w || !out || To <= 0 || H <= 0 || W <= 0 || Cout <= 0) return BYA_ERR_SHAPE;
+    if (C != 128 && C != 256 && C != 512) return BYA_ERR_UNSUPPORTED;           // whole 64-channel groups, a power of two of them
+    if (Cout % 8 || ldc < Cout || ldc % 8 || (res && (ldres < Cout || ldres % 8)) || ldw < 27LL * C || ldw % 8) return BYA_ERR_ALIGN;
+    if (((uintptr_t)xpad | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)res | (uintptr_t)out) & 15) return BYA_ERR_ALIGN;
+    const long long Hp = H + 2, Wp = W + 2, M = (long long)To * Hp * Wp;
+    // 32-bit reach of the epilogue's offsets and of a tile's LDS-DMA offsets (two frames + two rows ahead of its rows)
+    if (M >= (1LL << 31) || (long long)To * H * W * ldc * 2 >= (1LL << 31) || (res && (long long)To * H * W * ldres * 2 >= (1LL << 31)) ||
+        ((2 * Hp + 2) * Wp + 258) * C * 2 >= (1LL << 31))
+        return BYA_ERR_SHAPE;
+    GemmArgs a{};
+    a.A = (const bf16_t*)xpad; a.W = (const bf16_t*)w; a.bias = (const bf16_t*)bias; a.C = (bf16_t*)out; a.res = (const bf16_t*)res;
+    a.gate0 = nullptr; a.gate1 = nullptr;
+    a.M = (int)M; a.N = Cout; a.K = 27 * C;
+    a.lda = C; a.ldw = (int)ldw; a.ldc = (int)ldc; a.ldres = (int)(res ? ldres : ldc);
+    a.a_bs = 0; a.c_bs = 0; a.res_bs = 0; a.gate_bs = 0; a.gate_split = 0; a.act = BYA_ACT_NONE; a.leaky = 0.01f;
+    a.n_split = 0; a.c_split_stride = 0; a.bias_rowscale = nullptr; a.alpha = 1.0f;
+    a.ws_slabs = nullptr; a.ws_counters = nullptr;
+    a.conv_cpg_log2 = C == 128 ? 1 : C == 256 ? 2 : 3;
+    a.conv_Hp = (int)Hp; a.conv_Wp = (int)Wp; a.conv_H = H; a.conv_W = W; a.conv_To = To;
+    a.conv_a_bytes = (long long)(To + 2) * Hp * Wp * C * 2;
+    return bya_launch_conv256p(&a, stream);
 }

@@ -577,16 +577,40 @@ def vae_groupnorm_stats(x2d, sums, groups, partial=None):
     return sums
 
 
-def vae_norm_act(x, y, sums, gamma, beta, groups, act="silu", eps=1e-6, zy=None, zb=None, latent_shape=None, tmode=1):
-    """x, y: [T, H, W, C] channels-last; zy / zb: [Tz * hz * wz, C] views (row stride = their .stride(0))."""
+def vae_norm_act(x, y, sums, gamma, beta, groups, act="silu", eps=1e-6, zy=None, zb=None, latent_shape=None, tmode=1,
+                 out_pad=False):
+    """x: [T, H, W, C] channels-last; y: the same, or (out_pad) the zero-padded conv input [T + 2, H + 2, W + 2, C] whose
+    interior frames 2.. are written; zy / zb: [Tz * hz * wz, C] views (row stride = their .stride(0))."""
     lib = _hip.load()
     T, H, W, C = x.shape
     assert x.is_contiguous() and y.is_contiguous()
+    assert tuple(y.shape) == ((T + 2, H + 2, W + 2, C) if out_pad else (T, H, W, C))
     Tz, hz, wz = latent_shape if latent_shape is not None else (T, H, W)
     ldz = zy.stride(0) if zy is not None else 0
     tok = _begin("bya_vae_norm_act")
     check(lib.bya_vae_norm_act(_p(x), _p(y), _p(sums), _p(gamma), _p(beta), _p(zy), _p(zb), T * H * W, C, groups,
                                {None: 0, "none": 0, "silu": 1}[act], float(eps), T, H, W, Tz, hz, wz, tmode, ldz,
-                               _stream()), "bya_vae_norm_act")
+                               int(bool(out_pad)), _stream()), "bya_vae_norm_act")
     _end(tok)
     return y
+
+
+def vae_conv3d(xpad, w, bias, out, res=None):
+    """Causal 3 x 3 x 3 convolution as an implicit GEMM (bya_vae_conv3d): xpad [To + 2, H + 2, W + 2, C] zero-padded with its two
+    context frames in front, w [Cout, >= 27 C] (tap-major columns), out / res [To, H, W, Cout] (out = res + bias + conv)."""
+    lib = _hip.load()
+    Tp, Hp, Wp, C = xpad.shape
+    To, H, W, Cout = out.shape
+    assert (Tp, Hp, Wp) == (To + 2, H + 2, W + 2) and xpad.is_contiguous() and w.is_contiguous() and w.shape[0] >= Cout
+    assert out.stride(3) == 1
+    ldc = out.stride(2)
+    assert out.stride(1) == W * ldc and out.stride(0) == H * W * ldc
+    ldres = 0
+    if res is not None:
+        ldres = res.stride(2)
+        assert res.shape == out.shape and res.stride(1) == W * ldres and res.stride(0) == H * W * ldres and res.stride(3) == 1
+    tok = _begin("bya_vae_conv3d", 2.0 * To * H * W * Cout * 27 * C)
+    check(lib.bya_vae_conv3d(_p(xpad), _p(w), _p(bias), _p(res), _p(out), To, H, W, C, Cout, w.stride(0), ldc, ldres, _stream()),
+          "bya_vae_conv3d")
+    _end(tok)
+    return out

@@ -20,6 +20,7 @@ The patch matrix of a slab of frames is materialised in HBM (a first version: an
 patches in LDS is the next step -- DESIGN.md); 288 GB of HBM make slabs of whole frames affordable.  No torch math on the
 activations: torch holds memory, views and the final layout copy.
 """
+import os
 from types import SimpleNamespace
 
 import torch
@@ -137,6 +138,8 @@ class BindyouravatarVAE(nn.Module):
         self.to(torch.bfloat16)
         self._packed = {}
         self._ws = {}
+        # 3 x 3 x 3 resnet convolutions as implicit GEMMs (bya_vae_conv3d); "0" = patch matrix + bya_gemm_bf16 (A/B, tests)
+        self.implicit_conv = os.environ.get("BYA_VAE_IMPLICIT_CONV", "1") != "0"
 
     def forward(self, *a, **k):
         raise RuntimeError("use decode() / encode()")
@@ -242,14 +245,16 @@ class BindyouravatarVAE(nn.Module):
             y = y[..., :cout]
         return y, new_cache
 
-    def _norm(self, key, norm, x, zctx, act="silu"):
-        """GroupNorm (+ spatial modulation from the latent chunk ``zctx`` = (z64 rows, (Tz, hz, wz))) + activation."""
+    def _norm(self, key, norm, x, zctx, act="silu", out_pad=None):
+        """GroupNorm (+ spatial modulation from the latent chunk ``zctx`` = (z64 rows, (Tz, hz, wz))) + activation.
+        ``out_pad``: write into this zero-padded conv input [T + 2, H + 2, W + 2, C] instead of a fresh tensor."""
         T, H, W, C = x.shape
         gn = norm.norm_layer if hasattr(norm, "norm_layer") else norm
         sums = self._buf("gn_sums", 2 * gn.num_groups, dtype=torch.float32)
         part = self._buf("gn_partial", (T * H * W + 511) // 512 * gn.num_groups * 2, dtype=torch.float32)
         ops.vae_groupnorm_stats(x.view(-1, C), sums, gn.num_groups, part)
-        y = torch.empty_like(x)
+        y = out_pad if out_pad is not None else torch.empty_like(x)
+        pad = out_pad is not None
         if hasattr(norm, "norm_layer"):
             z64, lat = zctx
             wp, bp = self._pack_yb(key, norm)
@@ -257,17 +262,52 @@ class BindyouravatarVAE(nn.Module):
             ops.gemm(z64, wp, zyb, bias=bp)
             tmode = 2 if (T > 1 and T % 2 == 1) else 1
             ops.vae_norm_act(x, y, sums, gn.weight, gn.bias, gn.num_groups, act=act, eps=gn.eps, zy=zyb[:, :C], zb=zyb[:, C:],
-                             latent_shape=lat, tmode=tmode)
+                             latent_shape=lat, tmode=tmode, out_pad=pad)
         else:
-            ops.vae_norm_act(x, y, sums, gn.weight, gn.bias, gn.num_groups, act=act, eps=gn.eps)
+            ops.vae_norm_act(x, y, sums, gn.weight, gn.bias, gn.num_groups, act=act, eps=gn.eps, out_pad=pad)
         return y
+
+    def _pad_buf(self, T, H, W, C):
+        """Zero-padded conv input [T + 2, H + 2, W + 2, C] (bya_vae_conv3d): one buffer per shape, zero-filled when it is
+        created -- the border is never written afterwards (the norm kernel fills the interior, the context frames are
+        whole padded frames)."""
+        key = ("pad", T, H, W, C)
+        t = self._ws.get(key)
+        if t is None:
+            t = self._ws[key] = torch.zeros(T + 2, H + 2, W + 2, C, dtype=torch.bfloat16, device=self._dev)
+        return t
+
+    def _norm_conv(self, key, norm, conv_mod, x, zctx, cache, res=None):
+        """GroupNorm (+ modulation) + SiLU -> causal 3 x 3 x 3 convolution (+ res), the convolution as an implicit GEMM: the
+        norm kernel writes the zero-padded conv input, no patch matrix exists.  ``cache``: the two context frames in PADDED
+        form [2, H + 2, W + 2, C] (or None: the first frame twice).  Returns (y, new_cache)."""
+        T, H, W, C = x.shape
+        conv = conv_mod.conv if hasattr(conv_mod, "conv") else conv_mod
+        cout = conv.weight.shape[0]
+        if not self.implicit_conv or C not in (128, 256, 512) or cout % 8 or conv.weight.shape[2:] != (3, 3, 3):
+            h = self._norm(key + ".n", norm, x, zctx)
+            if cache is not None and cache.shape[1] == H + 2:                 # (a padded cache from the other path)
+                cache = cache[:, 1:-1, 1:-1].contiguous()
+            return self._conv(key + ".c", conv_mod, h, cache, res=res)
+        xpad = self._pad_buf(T, H, W, C)
+        self._norm(key + ".n", norm, x, zctx, out_pad=xpad)
+        if cache is None:
+            xpad[0].copy_(xpad[2])
+            xpad[1].copy_(xpad[2])
+        else:
+            if cache.shape[1] == H:                                           # (an unpadded cache from the other path)
+                xpad[:2, 1:-1, 1:-1].copy_(cache)
+            else:
+                xpad[:2].copy_(cache)
+        wp, bp = self._pack_conv(key + ".c", conv.weight, conv.bias)
+        y = torch.empty(T, H, W, cout, dtype=torch.bfloat16, device=x.device)
+        ops.vae_conv3d(xpad, wp, bp, y, res=res)
+        return y, xpad[T:T + 2].clone()
 
     def _resnet(self, key, blk, x, zctx, cache):
         cache = cache or {}
         new = {}
-        h = self._norm(key + ".norm1", blk.norm1, x, zctx)
-        h, new["conv1"] = self._conv(key + ".conv1", blk.conv1, h, cache.get("conv1"))
-        h = self._norm(key + ".norm2", blk.norm2, h, zctx)
+        h, new["conv1"] = self._norm_conv(key + ".1", blk.norm1, blk.conv1, x, zctx, cache.get("conv1"))
         if blk.cin != blk.cout:
             wp, bp = self._pack_conv(key + ".sc", blk.conv_shortcut.weight, blk.conv_shortcut.bias)
             sc = torch.empty(*x.shape[:3], blk.cout, dtype=torch.bfloat16, device=x.device)
@@ -280,7 +320,7 @@ class BindyouravatarVAE(nn.Module):
                 ops.gemm(x.view(-1, blk.cin), wp, sc.view(-1, blk.cout), bias=bp)
         else:
             sc = x
-        h, new["conv2"] = self._conv(key + ".conv2", blk.conv2, h, cache.get("conv2"), res=sc)
+        h, new["conv2"] = self._norm_conv(key + ".2", blk.norm2, blk.conv2, h, zctx, cache.get("conv2"), res=sc)
         return h, new
 
     # ------------------------------------------------------------------------------------------ decode

@@ -328,9 +328,21 @@ int bya_vae_groupnorm_stats(const void* x, float* sums, float* partial, int64_t 
  * (t, h, w) of x [T, H, W, C] reads latent position (frame by tmode, h >> log2(H / hz), w >> log2(W / wz)): tmode 0 = same
  * frame, 1 = floor(t Tz / T), 2 = first frame apart (0 -> 0, t -> 1 + floor((t - 1)(Tz - 1) / (T - 1))): torch's nearest
  * F.interpolate, first frame and the rest resized separately when T is odd and > 1. */
+/* out_pad = 1: y is the zero-padded input of bya_vae_conv3d, [T + 2, H + 2, W + 2, C] (the caller zero-fills it once and
+ * writes the two context frames; this call writes pixel (t, h, w) at (t + 2, h + 1, w + 1)); rows must be T H W. */
 int bya_vae_norm_act(const void* x, void* y, const float* sums, const void* gamma, const void* beta, const void* zy,
                      const void* zb, int64_t rows, int32_t C, int32_t groups, int32_t act, float eps, int32_t T, int32_t H,
-                     int32_t W, int32_t Tz, int32_t hz, int32_t wz, int32_t tmode, int64_t ldz, hipStream_t stream);
+                     int32_t W, int32_t Tz, int32_t hz, int32_t wz, int32_t tmode, int64_t ldz, int32_t out_pad,
+                     hipStream_t stream);
+
+/* Causal 3 x 3 x 3 convolution, stride 1 (diffusers CogVideoXCausalConv3d inside CogVideoXResnetBlock3D; reached from
+ * models/pipeline_bindyouravatar.py:461-466 / :406-424), as an IMPLICIT GEMM on the persistent MFMA kernel: no patch matrix.
+ * xpad: bf16 [To + 2, H + 2, W + 2, C], channels-last, zero border of one pixel around every frame, frames 0 and 1 = the
+ * causal context (last two input frames of the previous chunk, or the first frame twice); w: [Cout, ldw] bf16 with column
+ * ((dt 3 + dh) 3 + dw) C + c; bias [Cout] or NULL; res [To, H, W, ldres] or NULL; out [To, H, W, ldc] (may alias res).
+ * C in {128, 256, 512}; Cout, ldc, ldres multiples of 8.  out = res + bias + conv(x). */
+int bya_vae_conv3d(const void* xpad, const void* w, const void* bias, const void* res, void* out, int32_t To, int32_t H,
+                   int32_t W, int32_t C, int32_t Cout, int64_t ldw, int64_t ldc, int64_t ldres, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU exchanges of the sharded step over RCCL.  ``comm`` is the caller's ncclComm_t (one

@@ -145,6 +145,46 @@ def test_encode_conditioning_frame_vs_oracle(dev):
         vae.encode(torch.zeros(1, 3, 5, 48, 64, device=dev))
 
 
+@pytest.mark.parametrize("C,Cout,T,H,W,with_res,with_cache", [
+    (128, 128, 3, 20, 28, True, True),
+    (256, 128, 2, 17, 23, False, False),          # odd sizes: rows of the padded grid that are dropped sit everywhere
+    (512, 512, 1, 9, 13, True, False),            # a single frame (the encoder's case): the first frame is its own context
+    (128, 256, 5, 33, 31, False, True),
+])
+def test_conv3d_implicit_gemm_equals_patch_gemm(dev, C, Cout, T, H, W, with_res, with_cache):
+    """bya_vae_conv3d (no patch matrix: the K-tiles of the persistent GEMM are shifted views of the zero-padded input) against
+    the same convolution through bya_vae_patches + bya_gemm_bf16, and against torch's conv3d in fp32."""
+    from bind_your_avatar_implementation_amd import ops
+    g = torch.Generator().manual_seed(C + Cout + T)
+    x = torch.randn(T, H, W, C, generator=g).to(torch.bfloat16).to(dev)
+    cache = torch.randn(2, H, W, C, generator=g).to(torch.bfloat16).to(dev) if with_cache else None
+    w = (torch.randn(Cout, C, 3, 3, 3, generator=g) * (27 * C) ** -0.5).to(torch.bfloat16).to(dev)
+    b = torch.randn(Cout, generator=g).to(torch.bfloat16).to(dev)
+    res = torch.randn(T, H, W, Cout, generator=g).to(torch.bfloat16).to(dev) if with_res else None
+    wp = w.permute(0, 2, 3, 4, 1).reshape(Cout, 27 * C).contiguous()
+    # implicit
+    xpad = torch.zeros(T + 2, H + 2, W + 2, C, dtype=torch.bfloat16, device=dev)
+    xpad[2:, 1:-1, 1:-1] = x
+    ctx = cache if cache is not None else x[:1].expand(2, H, W, C)
+    xpad[:2, 1:-1, 1:-1] = ctx
+    y = torch.full((T, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.vae_conv3d(xpad, wp, b, y, res=res)
+    # patches + GEMM
+    patches = torch.empty(T * H * W, 27 * C, dtype=torch.bfloat16, device=dev)
+    ops.vae_patches(x, cache, patches, 3, 1, 1, False, 0, H, W, 0, T)
+    y2 = torch.empty(T * H * W, Cout, dtype=torch.bfloat16, device=dev)
+    ops.gemm(patches, wp, y2, bias=b, res=None if res is None else res.view(-1, Cout))
+    # torch fp32
+    xin = torch.cat([ctx, x], 0).float().permute(3, 0, 1, 2)[None]
+    ref = torch.nn.functional.conv3d(torch.nn.functional.pad(xin, (1, 1, 1, 1, 0, 0)), w.float(), b.float())[0].permute(1, 2, 3, 0)
+    if res is not None:
+        ref = ref + res.float()
+    e1, e2 = rel_fro(y.float(), ref), rel_fro(y2.view(T, H, W, Cout).float(), ref)
+    d = rel_fro(y.float(), y2.view(T, H, W, Cout).float())
+    print(f"C={C} Cout={Cout} {T}x{H}x{W}: implicit-vs-fp32 {e1:.3e}  patches-vs-fp32 {e2:.3e}  implicit-vs-patches {d:.3e}")
+    assert torch.isfinite(y.float()).all() and e1 <= 3e-3 and d <= 3e-3
+
+
 def test_full_size_decode_timed(dev):
     """The real architecture (128-256-256-512, three resnets per block) on a full 13 x 60 x 90 latent: 49 frames of 480 x 720
     come out finite; the time is printed (profiles/: a first version, the patch matrices go through HBM)."""
