@@ -76,7 +76,8 @@ SIGNATURES = {
     "bya_vae_groupnorm_stats": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "bya_vae_norm_act": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32, _i32,
                          _i32, _i64, _i32, _vp],
-    "bya_vae_conv3d": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp],
+    "bya_vae_conv3d": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp],
+    "bya_vae_upsample_pad": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "bya_allgather_kv": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "bya_alltoall_router": [_vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "bya_cfg_scheduler_step": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _c.POINTER(SchedCoef), _vp],

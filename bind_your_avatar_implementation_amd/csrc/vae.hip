@@ -233,6 +233,23 @@ __global__ __launch_bounds__(256) void vae_norm_act_kernel(NormArgs p) {
     *reinterpret_cast<u32x4*>(p.y + ro * p.C + c0) = pack8(o);
 }
 
+// Nearest-neighbour up-sampling (space x 2; time by tmode, see bya_vae_patches) of x [T, H, W, C] INTO the interior of the
+// zero-padded conv input [To, 2 H + 2, 2 W + 2, C] of the up-sampler's per-frame 3 x 3 convolution (bya_vae_conv3d, KT = 1):
+// one thread per 16-byte piece of an output pixel.  4 x (8 x) the stored tensor instead of 9 x that as a patch matrix.
+__global__ __launch_bounds__(256) void vae_upsample_pad_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int To, int H,
+                                                               int W, int C, int tmode) {
+    const int cpr = C >> 3, W2 = 2 * W, H2 = 2 * H;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)To * H2 * W2 * cpr) return;
+    const int c8 = (int)(idx % cpr);
+    long long r = idx / cpr;
+    const int w = (int)(r % W2); r /= W2;
+    const int h = (int)(r % H2);
+    const int t = (int)(r / H2);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((long long)src_frame(t, tmode) * H + (h >> 1)) * W + (w >> 1)) * C + c8 * 8);
+    *reinterpret_cast<u32x4*>(y + (((long long)t * (H2 + 2) + h + 1) * (W2 + 2) + w + 1) * C + c8 * 8) = v;
+}
+
 }  // namespace
 
 extern "C" int bya_vae_patches(const void* x, const void* cache, void* out, int32_t Ts, int32_t Hs, int32_t Ws, int32_t C,
@@ -296,12 +313,23 @@ extern "C" int bya_vae_norm_act(const void* x, void* y, const float* sums, const
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
+extern "C" int bya_vae_upsample_pad(const void* x, void* ypad, int32_t T, int32_t H, int32_t W, int32_t C, int32_t tmode,
+                                    hipStream_t stream) {
+    if (!x || !ypad || T <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || tmode < 0 || tmode > 2) return BYA_ERR_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)ypad) & 15) return BYA_ERR_ALIGN;
+    const int To = tmode == 0 ? T : tmode == 1 ? 2 * T : 2 * T - 1;
+    const long long total = (long long)To * 4 * H * W * (C >> 3);
+    BYA_LAUNCH(vae_upsample_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)ypad,
+               To, H, W, C, tmode);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
 extern "C" int bya_vae_conv3d(const void* xpad, const void* w, const void* bias, const void* res, void* out, int32_t To,
-                              int32_t H, int32_t W, int32_t C, int32_t Cout, int64_t ldw, int64_t ldc, int64_t ldres,
-                              hipStream_t stream) {
-    if (!xpad || !w || !out || To <= 0 || H <= 0 || W <= 0 || Cout <= 0) return BYA_ERR_SHAPE;
+                              int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t KT, int64_t ldw, int64_t ldc,
+                              int64_t ldres, hipStream_t stream) {
+    if (!xpad || !w || !out || To <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (KT != 1 && KT != 3)) return BYA_ERR_SHAPE;
     if (C != 128 && C != 256 && C != 512) return BYA_ERR_UNSUPPORTED;           // whole 64-channel groups, a power of two of them
-    if (Cout % 8 || ldc < Cout || ldc % 8 || (res && (ldres < Cout || ldres % 8)) || ldw < 27LL * C || ldw % 8) return BYA_ERR_ALIGN;
+    if (Cout % 8 || ldc < Cout || ldc % 8 || (res && (ldres < Cout || ldres % 8)) || ldw < 9LL * KT * C || ldw % 8) return BYA_ERR_ALIGN;
     if (((uintptr_t)xpad | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)res | (uintptr_t)out) & 15) return BYA_ERR_ALIGN;
     const long long Hp = H + 2, Wp = W + 2, M = (long long)To * Hp * Wp;
     // 32-bit reach of the epilogue's offsets and of a tile's LDS-DMA offsets (two frames + two rows ahead of its rows)
@@ -311,13 +339,13 @@ extern "C" int bya_vae_conv3d(const void* xpad, const void* w, const void* bias,
     GemmArgs a{};
     a.A = (const bf16_t*)xpad; a.W = (const bf16_t*)w; a.bias = (const bf16_t*)bias; a.C = (bf16_t*)out; a.res = (const bf16_t*)res;
     a.gate0 = nullptr; a.gate1 = nullptr;
-    a.M = (int)M; a.N = Cout; a.K = 27 * C;
+    a.M = (int)M; a.N = Cout; a.K = 9 * KT * C;
     a.lda = C; a.ldw = (int)ldw; a.ldc = (int)ldc; a.ldres = (int)(res ? ldres : ldc);
     a.a_bs = 0; a.c_bs = 0; a.res_bs = 0; a.gate_bs = 0; a.gate_split = 0; a.act = BYA_ACT_NONE; a.leaky = 0.01f;
     a.n_split = 0; a.c_split_stride = 0; a.bias_rowscale = nullptr; a.alpha = 1.0f;
     a.ws_slabs = nullptr; a.ws_counters = nullptr;
     a.conv_cpg_log2 = C == 128 ? 1 : C == 256 ? 2 : 3;
     a.conv_Hp = (int)Hp; a.conv_Wp = (int)Wp; a.conv_H = H; a.conv_W = W; a.conv_To = To;
-    a.conv_a_bytes = (long long)(To + 2) * Hp * Wp * C * 2;
+    a.conv_a_bytes = (long long)(To + KT - 1) * Hp * Wp * C * 2;
     return bya_launch_conv256p(&a, stream);
 }

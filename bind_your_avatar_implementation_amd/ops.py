@@ -595,13 +595,13 @@ def vae_norm_act(x, y, sums, gamma, beta, groups, act="silu", eps=1e-6, zy=None,
     return y
 
 
-def vae_conv3d(xpad, w, bias, out, res=None):
-    """Causal 3 x 3 x 3 convolution as an implicit GEMM (bya_vae_conv3d): xpad [To + 2, H + 2, W + 2, C] zero-padded with its two
-    context frames in front, w [Cout, >= 27 C] (tap-major columns), out / res [To, H, W, Cout] (out = res + bias + conv)."""
+def vae_conv3d(xpad, w, bias, out, res=None, KT=3):
+    """Causal KT x 3 x 3 convolution as an implicit GEMM (bya_vae_conv3d): xpad [To + KT - 1, H + 2, W + 2, C] zero-padded (KT = 3:
+    its two context frames in front), w [Cout, >= 9 KT C] (tap-major columns), out / res [To, H, W, Cout] (out = res + bias + conv)."""
     lib = _hip.load()
     Tp, Hp, Wp, C = xpad.shape
     To, H, W, Cout = out.shape
-    assert (Tp, Hp, Wp) == (To + 2, H + 2, W + 2) and xpad.is_contiguous() and w.is_contiguous() and w.shape[0] >= Cout
+    assert (Tp, Hp, Wp) == (To + KT - 1, H + 2, W + 2) and xpad.is_contiguous() and w.is_contiguous() and w.shape[0] >= Cout
     assert out.stride(3) == 1
     ldc = out.stride(2)
     assert out.stride(1) == W * ldc and out.stride(0) == H * W * ldc
@@ -609,8 +609,20 @@ def vae_conv3d(xpad, w, bias, out, res=None):
     if res is not None:
         ldres = res.stride(2)
         assert res.shape == out.shape and res.stride(1) == W * ldres and res.stride(0) == H * W * ldres and res.stride(3) == 1
-    tok = _begin("bya_vae_conv3d", 2.0 * To * H * W * Cout * 27 * C)
-    check(lib.bya_vae_conv3d(_p(xpad), _p(w), _p(bias), _p(res), _p(out), To, H, W, C, Cout, w.stride(0), ldc, ldres, _stream()),
-          "bya_vae_conv3d")
+    tok = _begin("bya_vae_conv3d", 2.0 * To * H * W * Cout * 9 * KT * C)
+    check(lib.bya_vae_conv3d(_p(xpad), _p(w), _p(bias), _p(res), _p(out), To, H, W, C, Cout, KT, w.stride(0), ldc, ldres,
+                             _stream()), "bya_vae_conv3d")
     _end(tok)
     return out
+
+
+def vae_upsample_pad(x, ypad, tmode):
+    """Nearest up-sampling of x [T, H, W, C] into the interior of the zero-padded ypad [To, 2 H + 2, 2 W + 2, C]."""
+    lib = _hip.load()
+    T, H, W, C = x.shape
+    To = T if tmode == 0 else (2 * T if tmode == 1 else 2 * T - 1)
+    assert x.is_contiguous() and ypad.is_contiguous() and tuple(ypad.shape) == (To, 2 * H + 2, 2 * W + 2, C)
+    tok = _begin("bya_vae_upsample_pad")
+    check(lib.bya_vae_upsample_pad(_p(x), _p(ypad), T, H, W, C, tmode, _stream()), "bya_vae_upsample_pad")
+    _end(tok)
+    return ypad

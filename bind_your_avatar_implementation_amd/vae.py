@@ -169,7 +169,7 @@ class BindyouravatarVAE(nn.Module):
         return (k + 63) // 64 * 64
 
     def _pack_conv(self, key, weight, bias):
-        """[Cout, Cin, (kt,) kh, kw] -> bf16 [Cout4, Kpad] with columns (kt, kh, kw, cin); Cout padded to a multiple of 4."""
+        """[Cout, Cin, (kt,) kh, kw] -> bf16 [Cout8, Kpad] with columns (kt, kh, kw, cin); Cout padded to a multiple of 8."""
         hit = self._packed.get(key)
         if hit is not None and hit[2] == (weight.data_ptr(), weight._version):
             return hit[0], hit[1]
@@ -178,7 +178,7 @@ class BindyouravatarVAE(nn.Module):
             w = w[:, :, None]
         cout, cin = w.shape[:2]
         w2 = w.permute(0, 2, 3, 4, 1).reshape(cout, -1)
-        K, cout4 = w2.shape[1], (cout + 3) // 4 * 4
+        K, cout4 = w2.shape[1], (cout + 7) // 8 * 8
         wp = torch.zeros(cout4, self._pad_k(K), dtype=torch.bfloat16, device=w.device)
         wp[:cout, :K] = w2
         bp = torch.zeros(cout4, dtype=torch.bfloat16, device=w.device)
@@ -277,6 +277,25 @@ class BindyouravatarVAE(nn.Module):
             t = self._ws[key] = torch.zeros(T + 2, H + 2, W + 2, C, dtype=torch.bfloat16, device=self._dev)
         return t
 
+    def _upsample_conv(self, key, mod, x, tmode):
+        """CogVideoXUpsample3D: nearest up-sampling (never kept at 9x as patches: written once, zero-padded) + its per-frame
+        3 x 3 convolution as an implicit GEMM."""
+        T, H, W, C = x.shape
+        conv = mod.conv if hasattr(mod, "conv") else mod
+        if not self.implicit_conv or C not in (128, 256, 512):
+            return self._conv(key, mod, x, KT=1, up=True, tmode=tmode)[0]
+        To = T if tmode == 0 else (2 * T if tmode == 1 else 2 * T - 1)
+        kb = ("pad1", To, 2 * H, 2 * W, C)
+        ypad = self._ws.get(kb)
+        if ypad is None:
+            ypad = self._ws[kb] = torch.zeros(To, 2 * H + 2, 2 * W + 2, C, dtype=torch.bfloat16, device=self._dev)
+        ops.vae_upsample_pad(x, ypad, tmode)
+        wp, bp = self._pack_conv(key, conv.weight, conv.bias)
+        cout = conv.weight.shape[0]
+        y = torch.empty(To, 2 * H, 2 * W, wp.shape[0], dtype=torch.bfloat16, device=x.device)
+        ops.vae_conv3d(ypad, wp, bp, y, KT=1)
+        return y if wp.shape[0] == cout else y[..., :cout]
+
     def _norm_conv(self, key, norm, conv_mod, x, zctx, cache, res=None):
         """GroupNorm (+ modulation) + SiLU -> causal 3 x 3 x 3 convolution (+ res), the convolution as an implicit GEMM: the
         norm kernel writes the zero-padded conv input, no patch matrix exists.  ``cache``: the two context frames in PADDED
@@ -284,7 +303,7 @@ class BindyouravatarVAE(nn.Module):
         T, H, W, C = x.shape
         conv = conv_mod.conv if hasattr(conv_mod, "conv") else conv_mod
         cout = conv.weight.shape[0]
-        if not self.implicit_conv or C not in (128, 256, 512) or cout % 8 or conv.weight.shape[2:] != (3, 3, 3):
+        if not self.implicit_conv or C not in (128, 256, 512) or conv.weight.shape[2:] != (3, 3, 3):
             h = self._norm(key + ".n", norm, x, zctx)
             if cache is not None and cache.shape[1] == H + 2:                 # (a padded cache from the other path)
                 cache = cache[:, 1:-1, 1:-1].contiguous()
@@ -300,9 +319,10 @@ class BindyouravatarVAE(nn.Module):
             else:
                 xpad[:2].copy_(cache)
         wp, bp = self._pack_conv(key + ".c", conv.weight, conv.bias)
-        y = torch.empty(T, H, W, cout, dtype=torch.bfloat16, device=x.device)
+        cout8 = wp.shape[0]                                   # (conv_out: 3 channels computed as 8)
+        y = torch.empty(T, H, W, cout8, dtype=torch.bfloat16, device=x.device)
         ops.vae_conv3d(xpad, wp, bp, y, res=res)
-        return y, xpad[T:T + 2].clone()
+        return (y if cout8 == cout else y[..., :cout]), xpad[T:T + 2].clone()
 
     def _resnet(self, key, blk, x, zctx, cache):
         cache = cache or {}
@@ -343,9 +363,8 @@ class BindyouravatarVAE(nn.Module):
             if hasattr(ub, "upsamplers"):
                 T = h.shape[0]
                 tmode = 0 if (i >= self.n_time or T == 1) else (2 if T % 2 == 1 else 1)
-                h, _ = self._conv(f"d.up{i}.us", ub.upsamplers[0], h, KT=1, up=True, tmode=tmode)
-        h = self._norm("d.norm_out", d.norm_out, h, zctx)
-        y, new["conv_out"] = self._conv("d.conv_out", d.conv_out, h, cache.get("conv_out"))
+                h = self._upsample_conv(f"d.up{i}.us", ub.upsamplers[0], h, tmode)
+        y, new["conv_out"] = self._norm_conv("d.out", d.norm_out, d.conv_out, h, zctx, cache.get("conv_out"))
         return y, new
 
     @torch.no_grad()

@@ -335,14 +335,22 @@ int bya_vae_norm_act(const void* x, void* y, const float* sums, const void* gamm
                      int32_t W, int32_t Tz, int32_t hz, int32_t wz, int32_t tmode, int64_t ldz, int32_t out_pad,
                      hipStream_t stream);
 
-/* Causal 3 x 3 x 3 convolution, stride 1 (diffusers CogVideoXCausalConv3d inside CogVideoXResnetBlock3D; reached from
- * models/pipeline_bindyouravatar.py:461-466 / :406-424), as an IMPLICIT GEMM on the persistent MFMA kernel: no patch matrix.
- * xpad: bf16 [To + 2, H + 2, W + 2, C], channels-last, zero border of one pixel around every frame, frames 0 and 1 = the
- * causal context (last two input frames of the previous chunk, or the first frame twice); w: [Cout, ldw] bf16 with column
- * ((dt 3 + dh) 3 + dw) C + c; bias [Cout] or NULL; res [To, H, W, ldres] or NULL; out [To, H, W, ldc] (may alias res).
- * C in {128, 256, 512}; Cout, ldc, ldres multiples of 8.  out = res + bias + conv(x). */
+/* Causal KT x 3 x 3 convolution, stride 1 (KT = 3: diffusers CogVideoXCausalConv3d inside CogVideoXResnetBlock3D and conv_out;
+ * KT = 1: the per-frame 3 x 3 convolution of CogVideoXUpsample3D; reached from models/pipeline_bindyouravatar.py:461-466 /
+ * :406-424), as an IMPLICIT GEMM on the persistent MFMA kernel: no patch matrix.
+ * xpad: bf16 [To + KT - 1, H + 2, W + 2, C], channels-last, zero border of one pixel around every frame; for KT = 3 frames 0
+ * and 1 are the causal context (last two input frames of the previous chunk, or the first frame twice); w: [Cout, ldw] bf16
+ * with column ((dt 3 + dh) 3 + dw) C + c; bias [Cout] or NULL; res [To, H, W, ldres] or NULL; out [To, H, W, ldc] (may alias
+ * res).  C in {128, 256, 512}; Cout, ldc, ldres multiples of 8.  out = res + bias + conv(x). */
 int bya_vae_conv3d(const void* xpad, const void* w, const void* bias, const void* res, void* out, int32_t To, int32_t H,
-                   int32_t W, int32_t C, int32_t Cout, int64_t ldw, int64_t ldc, int64_t ldres, hipStream_t stream);
+                   int32_t W, int32_t C, int32_t Cout, int32_t KT, int64_t ldw, int64_t ldc, int64_t ldres,
+                   hipStream_t stream);
+
+/* Nearest-neighbour up-sampling of x [T, H, W, C] (space x 2; time by tmode as in bya_vae_patches: 0 = frames as they are,
+ * 1 = every frame doubled, 2 = first frame single and the rest doubled) into the interior of ypad [To, 2 H + 2, 2 W + 2, C],
+ * the zero-padded input of the up-sampler's convolution (bya_vae_conv3d, KT = 1); the caller zero-fills ypad once. */
+int bya_vae_upsample_pad(const void* x, void* ypad, int32_t T, int32_t H, int32_t W, int32_t C, int32_t tmode,
+                         hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU exchanges of the sharded step over RCCL.  ``comm`` is the caller's ncclComm_t (one

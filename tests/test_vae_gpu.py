@@ -185,6 +185,30 @@ def test_conv3d_implicit_gemm_equals_patch_gemm(dev, C, Cout, T, H, W, with_res,
     assert torch.isfinite(y.float()).all() and e1 <= 3e-3 and d <= 3e-3
 
 
+@pytest.mark.parametrize("tmode", [0, 1, 2])
+def test_upsampler_conv_implicit_gemm_equals_patch_gemm(dev, tmode):
+    """CogVideoXUpsample3D without a patch matrix: bya_vae_upsample_pad (nearest, into the zero-padded conv input) +
+    bya_vae_conv3d with KT = 1 against bya_vae_patches(up=True) + bya_gemm_bf16: the same bits."""
+    from bind_your_avatar_implementation_amd import ops
+    T, H, W, C, Cout = 3, 11, 14, 256, 256
+    g = torch.Generator().manual_seed(50 + tmode)
+    x = torch.randn(T, H, W, C, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(torch.bfloat16).to(dev)
+    b = torch.randn(Cout, generator=g).to(torch.bfloat16).to(dev)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * C).contiguous()
+    To = T if tmode == 0 else (2 * T if tmode == 1 else 2 * T - 1)
+    ypad = torch.zeros(To, 2 * H + 2, 2 * W + 2, C, dtype=torch.bfloat16, device=dev)
+    ops.vae_upsample_pad(x, ypad, tmode)
+    y = torch.full((To, 2 * H, 2 * W, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.vae_conv3d(ypad, wp, b, y, KT=1)
+    patches = torch.empty(To * 4 * H * W, 9 * C, dtype=torch.bfloat16, device=dev)
+    ops.vae_patches(x, None, patches, 1, 1, 1, True, tmode, 2 * H, 2 * W, 0, To)
+    y2 = torch.empty(To * 4 * H * W, Cout, dtype=torch.bfloat16, device=dev)
+    ops.gemm(patches, wp, y2, bias=b)
+    assert torch.isfinite(y.float()).all() and torch.equal(y.view(-1, Cout), y2)
+    assert torch.count_nonzero(ypad[:, 0]) == 0 and torch.count_nonzero(ypad[:, :, 0]) == 0          # the border stays zero
+
+
 def test_full_size_decode_timed(dev):
     """The real architecture (128-256-256-512, three resnets per block) on a full 13 x 60 x 90 latent: 49 frames of 480 x 720
     come out finite; the time is printed (profiles/: a first version, the patch matrices go through HBM)."""
