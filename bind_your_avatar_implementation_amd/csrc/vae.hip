@@ -182,54 +182,69 @@ struct NormArgs {
     int T, H, W, Tz, hz, wz, shift, tmode;   // row -> (t, h, w) -> latent position (h >> shift, w >> shift, frame by tmode)
     int ldz;                                 // row stride of zy / zb (they may be the two halves of one GEMM output)
     int out_pad;                             // 1: y is the zero-padded conv input [T + 2, H + 2, W + 2, C] (bya_vae_conv3d)
+    int cpr_shift;                           // log2(C / 8) when that is a power of two, else -1
 };
 
+// One thread = one 16-byte piece (8 channels) of one row.  32-bit index arithmetic (a chunk has < 2^31 pieces: checked by the
+// launcher), the channel-piece count a power of two: the 64-bit divisions of the first version cost more than its HBM bytes.
 __global__ __launch_bounds__(256) void vae_norm_act_kernel(NormArgs p) {
-    const int cpr = p.C >> 3;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= p.rows * cpr) return;
-    const long long r = idx / cpr;
-    const int c0 = (int)(idx % cpr) * 8;
+    const uint32_t cpr = (uint32_t)p.C >> 3;
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (uint32_t)p.rows * cpr) return;
+    const uint32_t r = p.cpr_shift >= 0 ? idx >> p.cpr_shift : idx / cpr;
+    const int c0 = (int)(idx - r * cpr) * 8;
     float v[8], gm[8], bt[8];
-    unpack8(*reinterpret_cast<const u32x4*>(p.x + r * p.C + c0), v);
+    unpack8(*reinterpret_cast<const u32x4*>(p.x + (long long)r * p.C + c0), v);
     unpack8(*reinterpret_cast<const u32x4*>(p.gamma + c0), gm);
     unpack8(*reinterpret_cast<const u32x4*>(p.beta + c0), bt);
     const int cg = p.C / p.groups;
     float zy[8], zb[8];
+    uint32_t t = 0, h = 0, w = 0;
+    if (p.zy || p.out_pad) {
+        const uint32_t rr = r / (uint32_t)p.W;
+        w = r - rr * (uint32_t)p.W;
+        t = rr / (uint32_t)p.H;
+        h = rr - t * (uint32_t)p.H;
+    }
     if (p.zy) {
-        long long rr = r;
-        const int w = (int)(rr % p.W); rr /= p.W;
-        const int h = (int)(rr % p.H);
-        const int t = (int)(rr / p.H);
         // latent frame of frame t: tmode 0: same count; 1: t * Tz / T (even resize); 2: first frame apart
         int tz;
-        if (p.tmode == 0) tz = t;
-        else if (p.tmode == 1) tz = (int)(((long long)t * p.Tz) / p.T);
-        else tz = t == 0 ? 0 : 1 + (int)(((long long)(t - 1) * (p.Tz - 1)) / (p.T - 1));
+        if (p.tmode == 0) tz = (int)t;
+        else if (p.tmode == 1) tz = (int)((t * (uint32_t)p.Tz) / (uint32_t)p.T);
+        else tz = t == 0 ? 0 : 1 + (int)(((t - 1) * (uint32_t)(p.Tz - 1)) / (uint32_t)(p.T - 1));
         const long long zr = ((long long)tz * p.hz + (h >> p.shift)) * p.wz + (w >> p.shift);
         unpack8(*reinterpret_cast<const u32x4*>(p.zy + zr * p.ldz + c0), zy);
         unpack8(*reinterpret_cast<const u32x4*>(p.zb + zr * p.ldz + c0), zb);
     }
+    // the group of these 8 channels (a piece never straddles two groups when the group size is a multiple of 8)
     float o[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int g = (c0 + e) / cg;
+    if ((cg & 7) == 0) {
+        const int g = c0 / cg;
         const float mean = p.sums[2 * g] / p.count;
         const float var = fmaxf(p.sums[2 * g + 1] / p.count - mean * mean, 0.f);
         const float rstd = rsqrtf(var + p.eps);
-        float y = (v[e] - mean) * rstd * gm[e] + bt[e];
-        if (p.zy) y = y * zy[e] + zb[e];
-        if (p.act == 1) y = y / (1.0f + __expf(-y));      // SiLU
-        o[e] = y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = (v[e] - mean) * rstd * gm[e] + bt[e];
+            if (p.zy) y = y * zy[e] + zb[e];
+            if (p.act == 1) y = y / (1.0f + __expf(-y));      // SiLU
+            o[e] = y;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c0 + e) / cg;
+            const float mean = p.sums[2 * g] / p.count;
+            const float var = fmaxf(p.sums[2 * g + 1] / p.count - mean * mean, 0.f);
+            const float rstd = rsqrtf(var + p.eps);
+            float y = (v[e] - mean) * rstd * gm[e] + bt[e];
+            if (p.zy) y = y * zy[e] + zb[e];
+            if (p.act == 1) y = y / (1.0f + __expf(-y));      // SiLU
+            o[e] = y;
+        }
     }
     long long ro = r;
-    if (p.out_pad) {
-        long long rr = r;
-        const int w = (int)(rr % p.W); rr /= p.W;
-        const int h = (int)(rr % p.H);
-        const int t = (int)(rr / p.H);
-        ro = ((long long)(t + 2) * (p.H + 2) + h + 1) * (p.W + 2) + w + 1;
-    }
+    if (p.out_pad) ro = ((long long)(t + 2) * (p.H + 2) + h + 1) * (p.W + 2) + w + 1;
     *reinterpret_cast<u32x4*>(p.y + ro * p.C + c0) = pack8(o);
 }
 
@@ -309,6 +324,10 @@ extern "C" int bya_vae_norm_act(const void* x, void* y, const float* sums, const
         if (tmode == 2 && (T < 2 || Tz < 2)) return BYA_ERR_SHAPE;
     }
     const long long total = rows * (C >> 3);
+    if (total >= (1LL << 31) - 256) return BYA_ERR_SHAPE;                      // 32-bit piece index (a chunk of frames, not a clip)
+    p.cpr_shift = -1;
+    for (int sft = 0; sft < 16; ++sft)
+        if ((C >> 3) == (1 << sft)) p.cpr_shift = sft;
     BYA_LAUNCH(vae_norm_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
