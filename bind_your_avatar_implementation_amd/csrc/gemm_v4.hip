@@ -253,7 +253,11 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         const int idz = c.valid ? id : base;
         c.z = idz / per_z;
         const int idt = idz - c.z * per_z;
-        constexpr int GM = 4;                      // group-M order: 4 row tiles sweep a column tile before moving on
+#ifndef BYA_GEMM_GM
+#define BYA_GEMM_GM 4
+#endif
+        constexpr int GM = BYA_GEMM_GM;            // group-M order: 4 row tiles sweep a column tile before moving on (A/B, round 3:
+                                                   // 2 gains 1.5 % on K = 12288 and loses 2-3 % on QKV / FF1; 8 the reverse; 16 loses)
         const int per_group = GM * tiles_n;
         const int group = idt / per_group, first_m = group * GM;
         const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
