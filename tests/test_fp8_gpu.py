@@ -119,6 +119,28 @@ def test_gemm_fp8_persistent_kernel_equals_the_128_tile_kernel(dev, monkeypatch)
     assert torch.isfinite(outs["v4"].float()).all() and frac < 1e-4 and float(diff.max()) <= 0.0625
 
 
+def test_fp8_linear_selection(dev):
+    """enable_fp8_weights(linears=...): the default is the four DiT Linears, "all" adds the two query projections, an unknown
+    name is refused when the engine packs."""
+    from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel
+    from bind_your_avatar_implementation_amd.synth import synth_inputs
+    from test_forward_gpu import SMALL_KW, to_dev
+    model = BindyouravatarTransformer3DModel(**SMALL_KW, device=dev).init_synthetic(seed=2, fast=True)
+    gi = to_dev(synth_inputs(batch=1, frames=3, height=16, width=24, seed=3), dev)
+    model.enable_fp8_weights()
+    model(**gi)
+    assert set(model._engine.w8) == {"qkv", "out", "ff1", "ff2"}
+    model.enable_fp8_weights(linears=("ff1", "aq"))
+    model(**gi)
+    assert set(model._engine.w8) == {"ff1", "aq"}
+    model.enable_fp8_weights(linears="all")
+    model(**gi)
+    assert set(model._engine.w8) == {"qkv", "out", "ff1", "ff2", "pq", "aq"}
+    model.enable_fp8_weights(linears=("qkv", "nope"))
+    with pytest.raises(ValueError):
+        model(**gi)
+
+
 # ------------------------------------------------------------------------------------------ forward level
 class FakeQuantLinear(torch.nn.Module):
     """The definition of bya_gemm_fp8 applied to one nn.Linear of the CPU oracle: e4m3 rows of x, e4m3 rows of W,

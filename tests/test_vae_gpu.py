@@ -209,6 +209,25 @@ def test_upsampler_conv_implicit_gemm_equals_patch_gemm(dev, tmode):
     assert torch.count_nonzero(ypad[:, 0]) == 0 and torch.count_nonzero(ypad[:, :, 0]) == 0          # the border stays zero
 
 
+def test_conv3d_rejects_what_it_does_not_implement(dev):
+    """bya_vae_conv3d takes whole 64-channel groups (C = 128 / 256 / 512), KT in {1, 3}, 16-byte aligned operands and output rows
+    of whole 16-byte pieces; anything else is an error code, never a silent wrong answer."""
+    from bind_your_avatar_implementation_amd import ops, _hip
+    def call(C=128, Cout=128, KT=3, ldc=None, misalign=0):
+        xpad = torch.zeros(2 + KT - 1, 6, 6, C, dtype=torch.bfloat16, device=dev)
+        w = torch.zeros(Cout, 9 * KT * C, dtype=torch.bfloat16, device=dev)
+        y = torch.zeros(2, 4, 4, ldc or Cout, dtype=torch.bfloat16, device=dev)
+        lib = _hip.load()
+        wp = w.data_ptr() + misalign
+        return lib.bya_vae_conv3d(xpad.data_ptr(), wp, None, None, y.data_ptr(), 2, 4, 4, C, Cout, KT, 9 * KT * C, y.stride(2), 0,
+                                  torch.cuda.current_stream().cuda_stream)
+    assert call() == 0
+    assert call(C=64) == -4 and call(C=192) == -4                   # BYA_ERR_UNSUPPORTED
+    assert call(KT=2) == -1                                          # BYA_ERR_SHAPE
+    assert call(Cout=12) == -2 and call(misalign=2) == -2            # BYA_ERR_ALIGN
+    torch.cuda.synchronize()
+
+
 def test_full_size_decode_timed(dev):
     """The real architecture (128-256-256-512, three resnets per block) on a full 13 x 60 x 90 latent: 49 frames of 480 x 720
     come out finite; the time is printed (profiles/: a first version, the patch matrices go through HBM)."""
