@@ -354,138 +354,6 @@ __global__ __launch_bounds__(256, 1) void gemm256p_fp8_kernel(GemmArgs p, const 
             MF8(5, 7);
             MF8(6, 7);
             MF8(7, 7); REREAD_A(7);
-#elif BYA_F8_PLACE == 1
-            RWF(4, cWl, cWh); RWF(5, cWl, cWh); RWF(6, cWl, cWh); RWF(7, cWl, cWh);
-            MF8(0, 0);
-            MF8(1, 0);
-            MF8(2, 0);
-            MF8(3, 0); B1();
-            MF8(0, 1); PIECE(0, false);
-            MF8(1, 1);
-            MF8(2, 1); PIECE(1, false);
-            MF8(3, 1);
-            MF8(0, 2); PIECE(2, false);
-            MF8(1, 2);
-            MF8(2, 2); PIECE(3, false);
-            MF8(3, 2);
-            MF8(0, 3); PIECE(4, false);
-            MF8(1, 3);
-            MF8(2, 3); PIECE(5, false);
-            MF8(3, 3);
-            MF8(0, 4); PIECE(6, false);
-            MF8(1, 4);
-            MF8(2, 4); PIECE(7, false);
-            MF8(3, 4);
-            MF8(0, 5); PIECE(0, true);
-            MF8(1, 5);
-            MF8(2, 5); PIECE(1, true);
-            MF8(3, 5);
-            MF8(0, 6); PIECE(2, true);
-            MF8(1, 6);
-            MF8(2, 6); PIECE(3, true);
-            MF8(3, 6);
-            MF8(0, 7); PIECE(4, true);
-            MF8(1, 7);
-            MF8(2, 7); PIECE(5, true); B2(14);
-            MF8(3, 7); REREAD_W();
-            MF8(4, 0); PIECE(6, true);
-            MF8(5, 0);
-            MF8(6, 0); PIECE(7, true);
-            MF8(7, 0); REREAD_A(0);
-            MF8(4, 1);
-            MF8(5, 1);
-            MF8(6, 1);
-            MF8(7, 1); REREAD_A(1);
-            MF8(4, 2);
-            MF8(5, 2);
-            MF8(6, 2);
-            MF8(7, 2); REREAD_A(2);
-            MF8(4, 3);
-            MF8(5, 3);
-            MF8(6, 3);
-            MF8(7, 3); REREAD_A(3);
-            MF8(4, 4);
-            MF8(5, 4);
-            MF8(6, 4);
-            MF8(7, 4); REREAD_A(4);
-            MF8(4, 5);
-            MF8(5, 5);
-            MF8(6, 5);
-            MF8(7, 5); REREAD_A(5);
-            MF8(4, 6);
-            MF8(5, 6);
-            MF8(6, 6);
-            MF8(7, 6); REREAD_A(6);
-            MF8(4, 7);
-            MF8(5, 7);
-            MF8(6, 7);
-            MF8(7, 7); REREAD_A(7);
-#elif BYA_F8_PLACE == 2
-            RWF(4, cWl, cWh); RWF(5, cWl, cWh); RWF(6, cWl, cWh); RWF(7, cWl, cWh);
-            MF8(0, 0);
-            MF8(1, 0);
-            MF8(2, 0);
-            MF8(3, 0); B1();
-            MF8(0, 1); PIECE(0, false);
-            MF8(1, 1);
-            MF8(2, 1);
-            MF8(3, 1); PIECE(1, false);
-            MF8(0, 2);
-            MF8(1, 2);
-            MF8(2, 2); PIECE(2, false);
-            MF8(3, 2);
-            MF8(0, 3);
-            MF8(1, 3); PIECE(3, false);
-            MF8(2, 3);
-            MF8(3, 3);
-            MF8(0, 4); PIECE(4, false);
-            MF8(1, 4);
-            MF8(2, 4);
-            MF8(3, 4); PIECE(5, false);
-            MF8(0, 5);
-            MF8(1, 5);
-            MF8(2, 5); PIECE(6, false);
-            MF8(3, 5);
-            MF8(0, 6);
-            MF8(1, 6); PIECE(7, false);
-            MF8(2, 6);
-            MF8(3, 6);
-            MF8(0, 7); PIECE(0, true);
-            MF8(1, 7);
-            MF8(2, 7); B2(9);
-            MF8(3, 7); PIECE(1, true); REREAD_W();
-            MF8(4, 0);
-            MF8(5, 0);
-            MF8(6, 0); PIECE(2, true);
-            MF8(7, 0); REREAD_A(0);
-            MF8(4, 1);
-            MF8(5, 1); PIECE(3, true);
-            MF8(6, 1);
-            MF8(7, 1); REREAD_A(1);
-            MF8(4, 2); PIECE(4, true);
-            MF8(5, 2);
-            MF8(6, 2);
-            MF8(7, 2); PIECE(5, true); REREAD_A(2);
-            MF8(4, 3);
-            MF8(5, 3);
-            MF8(6, 3); PIECE(6, true);
-            MF8(7, 3); REREAD_A(3);
-            MF8(4, 4);
-            MF8(5, 4); PIECE(7, true);
-            MF8(6, 4);
-            MF8(7, 4); REREAD_A(4);
-            MF8(4, 5);
-            MF8(5, 5);
-            MF8(6, 5);
-            MF8(7, 5); REREAD_A(5);
-            MF8(4, 6);
-            MF8(5, 6);
-            MF8(6, 6);
-            MF8(7, 6); REREAD_A(6);
-            MF8(4, 7);
-            MF8(5, 7);
-            MF8(6, 7);
-            MF8(7, 7); REREAD_A(7);
 #elif BYA_F8_PLACE == 3
             RWF(4, cWl, cWh); RWF(5, cWl, cWh); RWF(6, cWl, cWh); RWF(7, cWl, cWh);
             MF8(0, 0);
@@ -618,138 +486,6 @@ __global__ __launch_bounds__(256, 1) void gemm256p_fp8_kernel(GemmArgs p, const 
             MF8(5, 7);
             MF8(6, 7);
             MF8(7, 7); REREAD_A(7);
-#elif BYA_F8_PLACE == 5
-            RWF(4, cWl, cWh); RWF(5, cWl, cWh); RWF(6, cWl, cWh); RWF(7, cWl, cWh);
-            MF8(0, 0);
-            MF8(1, 0);
-            MF8(2, 0);
-            MF8(3, 0); B1();
-            MF8(0, 1); PIECE(0, false); PIECE(1, false);
-            MF8(1, 1);
-            MF8(2, 1);
-            MF8(3, 1);
-            MF8(0, 2); PIECE(2, false); PIECE(3, false);
-            MF8(1, 2);
-            MF8(2, 2);
-            MF8(3, 2);
-            MF8(0, 3); PIECE(4, false); PIECE(5, false);
-            MF8(1, 3);
-            MF8(2, 3);
-            MF8(3, 3);
-            MF8(0, 4); PIECE(6, false); PIECE(7, false);
-            MF8(1, 4);
-            MF8(2, 4);
-            MF8(3, 4);
-            MF8(0, 5); PIECE(0, true); PIECE(1, true);
-            MF8(1, 5);
-            MF8(2, 5);
-            MF8(3, 5);
-            MF8(0, 6); PIECE(2, true); PIECE(3, true);
-            MF8(1, 6);
-            MF8(2, 6);
-            MF8(3, 6);
-            MF8(0, 7); PIECE(4, true); PIECE(5, true);
-            MF8(1, 7);
-            MF8(2, 7); B2(14);
-            MF8(3, 7); REREAD_W();
-            MF8(4, 0); PIECE(6, true); PIECE(7, true);
-            MF8(5, 0);
-            MF8(6, 0);
-            MF8(7, 0); REREAD_A(0);
-            MF8(4, 1);
-            MF8(5, 1);
-            MF8(6, 1);
-            MF8(7, 1); REREAD_A(1);
-            MF8(4, 2);
-            MF8(5, 2);
-            MF8(6, 2);
-            MF8(7, 2); REREAD_A(2);
-            MF8(4, 3);
-            MF8(5, 3);
-            MF8(6, 3);
-            MF8(7, 3); REREAD_A(3);
-            MF8(4, 4);
-            MF8(5, 4);
-            MF8(6, 4);
-            MF8(7, 4); REREAD_A(4);
-            MF8(4, 5);
-            MF8(5, 5);
-            MF8(6, 5);
-            MF8(7, 5); REREAD_A(5);
-            MF8(4, 6);
-            MF8(5, 6);
-            MF8(6, 6);
-            MF8(7, 6); REREAD_A(6);
-            MF8(4, 7);
-            MF8(5, 7);
-            MF8(6, 7);
-            MF8(7, 7); REREAD_A(7);
-#elif BYA_F8_PLACE == 6
-            RWF(4, cWl, cWh); RWF(5, cWl, cWh); RWF(6, cWl, cWh); RWF(7, cWl, cWh);
-            MF8(0, 0);
-            MF8(1, 0);
-            MF8(2, 0);
-            MF8(3, 0);
-            MF8(0, 1);
-            MF8(1, 1);
-            MF8(2, 1);
-            MF8(3, 1); B1();
-            MF8(0, 2); PIECE(0, false);
-            MF8(1, 2);
-            MF8(2, 2);
-            MF8(3, 2); PIECE(1, false);
-            MF8(0, 3);
-            MF8(1, 3);
-            MF8(2, 3); PIECE(2, false);
-            MF8(3, 3);
-            MF8(0, 4);
-            MF8(1, 4); PIECE(3, false);
-            MF8(2, 4);
-            MF8(3, 4);
-            MF8(0, 5); PIECE(4, false);
-            MF8(1, 5);
-            MF8(2, 5);
-            MF8(3, 5); PIECE(5, false);
-            MF8(0, 6);
-            MF8(1, 6);
-            MF8(2, 6); PIECE(6, false);
-            MF8(3, 6);
-            MF8(0, 7);
-            MF8(1, 7); PIECE(7, false);
-            MF8(2, 7); B2(8);
-            MF8(3, 7); REREAD_W();
-            MF8(4, 0);
-            MF8(5, 0); PIECE(0, true);
-            MF8(6, 0);
-            MF8(7, 0); REREAD_A(0);
-            MF8(4, 1); PIECE(1, true);
-            MF8(5, 1);
-            MF8(6, 1);
-            MF8(7, 1); PIECE(2, true); REREAD_A(1);
-            MF8(4, 2);
-            MF8(5, 2);
-            MF8(6, 2); PIECE(3, true);
-            MF8(7, 2); REREAD_A(2);
-            MF8(4, 3);
-            MF8(5, 3); PIECE(4, true);
-            MF8(6, 3);
-            MF8(7, 3); REREAD_A(3);
-            MF8(4, 4); PIECE(5, true);
-            MF8(5, 4);
-            MF8(6, 4);
-            MF8(7, 4); PIECE(6, true); REREAD_A(4);
-            MF8(4, 5);
-            MF8(5, 5);
-            MF8(6, 5); PIECE(7, true);
-            MF8(7, 5); REREAD_A(5);
-            MF8(4, 6);
-            MF8(5, 6);
-            MF8(6, 6);
-            MF8(7, 6); REREAD_A(6);
-            MF8(4, 7);
-            MF8(5, 7);
-            MF8(6, 7);
-            MF8(7, 7); REREAD_A(7);
 #elif BYA_F8_PLACE == 7
             RWF(4, cWl, cWh); RWF(5, cWl, cWh); RWF(6, cWl, cWh); RWF(7, cWl, cWh);
             MF8(0, 0);
@@ -804,138 +540,6 @@ __global__ __launch_bounds__(256, 1) void gemm256p_fp8_kernel(GemmArgs p, const 
             MF8(5, 4);
             MF8(6, 4);
             MF8(7, 4); PIECE(7, true); REREAD_A(4);
-            MF8(4, 5);
-            MF8(5, 5);
-            MF8(6, 5);
-            MF8(7, 5); REREAD_A(5);
-            MF8(4, 6);
-            MF8(5, 6);
-            MF8(6, 6);
-            MF8(7, 6); REREAD_A(6);
-            MF8(4, 7);
-            MF8(5, 7);
-            MF8(6, 7);
-            MF8(7, 7); REREAD_A(7);
-#elif BYA_F8_PLACE == 8
-            RWF(4, cWl, cWh); RWF(5, cWl, cWh); RWF(6, cWl, cWh); RWF(7, cWl, cWh);
-            MF8(0, 0);
-            MF8(1, 0);
-            MF8(2, 0);
-            MF8(3, 0); B1();
-            MF8(0, 1); PIECE(0, false);
-            MF8(1, 1);
-            MF8(2, 1);
-            MF8(3, 1); PIECE(1, false);
-            MF8(0, 2);
-            MF8(1, 2);
-            MF8(2, 2); PIECE(2, false);
-            MF8(3, 2);
-            MF8(0, 3);
-            MF8(1, 3); PIECE(3, false);
-            MF8(2, 3);
-            MF8(3, 3);
-            MF8(0, 4); PIECE(4, false);
-            MF8(1, 4);
-            MF8(2, 4);
-            MF8(3, 4); PIECE(5, false);
-            MF8(0, 5);
-            MF8(1, 5);
-            MF8(2, 5); PIECE(6, false);
-            MF8(3, 5);
-            MF8(0, 6);
-            MF8(1, 6); PIECE(7, false);
-            MF8(2, 6);
-            MF8(3, 6);
-            MF8(0, 7); PIECE(0, true);
-            MF8(1, 7);
-            MF8(2, 7); B2(9);
-            MF8(3, 7); REREAD_W();
-            MF8(4, 0); PIECE(1, true);
-            MF8(5, 0);
-            MF8(6, 0); PIECE(2, true);
-            MF8(7, 0); REREAD_A(0);
-            MF8(4, 1); PIECE(3, true);
-            MF8(5, 1);
-            MF8(6, 1); PIECE(4, true);
-            MF8(7, 1); REREAD_A(1);
-            MF8(4, 2); PIECE(5, true);
-            MF8(5, 2);
-            MF8(6, 2); PIECE(6, true);
-            MF8(7, 2); REREAD_A(2);
-            MF8(4, 3); PIECE(7, true);
-            MF8(5, 3);
-            MF8(6, 3);
-            MF8(7, 3); REREAD_A(3);
-            MF8(4, 4);
-            MF8(5, 4);
-            MF8(6, 4);
-            MF8(7, 4); REREAD_A(4);
-            MF8(4, 5);
-            MF8(5, 5);
-            MF8(6, 5);
-            MF8(7, 5); REREAD_A(5);
-            MF8(4, 6);
-            MF8(5, 6);
-            MF8(6, 6);
-            MF8(7, 6); REREAD_A(6);
-            MF8(4, 7);
-            MF8(5, 7);
-            MF8(6, 7);
-            MF8(7, 7); REREAD_A(7);
-#elif BYA_F8_PLACE == 9
-            RWF(4, cWl, cWh); RWF(5, cWl, cWh); RWF(6, cWl, cWh); RWF(7, cWl, cWh);
-            MF8(0, 0);
-            MF8(1, 0);
-            MF8(2, 0);
-            MF8(3, 0);
-            MF8(0, 1);
-            MF8(1, 1);
-            MF8(2, 1);
-            MF8(3, 1); B1();
-            MF8(0, 2); PIECE(0, false);
-            MF8(1, 2);
-            MF8(2, 2); PIECE(1, false);
-            MF8(3, 2);
-            MF8(0, 3); PIECE(2, false);
-            MF8(1, 3);
-            MF8(2, 3); PIECE(3, false);
-            MF8(3, 3);
-            MF8(0, 4); PIECE(4, false);
-            MF8(1, 4);
-            MF8(2, 4); PIECE(5, false);
-            MF8(3, 4);
-            MF8(0, 5); PIECE(6, false);
-            MF8(1, 5);
-            MF8(2, 5); PIECE(7, false);
-            MF8(3, 5);
-            MF8(0, 6); PIECE(0, true);
-            MF8(1, 6);
-            MF8(2, 6); PIECE(1, true);
-            MF8(3, 6);
-            MF8(0, 7); PIECE(2, true);
-            MF8(1, 7);
-            MF8(2, 7); PIECE(3, true); B2(12);
-            MF8(3, 7); REREAD_W();
-            MF8(4, 0); PIECE(4, true);
-            MF8(5, 0);
-            MF8(6, 0); PIECE(5, true);
-            MF8(7, 0); REREAD_A(0);
-            MF8(4, 1); PIECE(6, true);
-            MF8(5, 1);
-            MF8(6, 1); PIECE(7, true);
-            MF8(7, 1); REREAD_A(1);
-            MF8(4, 2);
-            MF8(5, 2);
-            MF8(6, 2);
-            MF8(7, 2); REREAD_A(2);
-            MF8(4, 3);
-            MF8(5, 3);
-            MF8(6, 3);
-            MF8(7, 3); REREAD_A(3);
-            MF8(4, 4);
-            MF8(5, 4);
-            MF8(6, 4);
-            MF8(7, 4); REREAD_A(4);
             MF8(4, 5);
             MF8(5, 5);
             MF8(6, 5);

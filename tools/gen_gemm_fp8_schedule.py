@@ -10,16 +10,12 @@ HIP = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 # time (A/B runs: tools/fp8_gemm_zeros_probe.py); PLACE_DEFAULT is what ships.
 # entry: (MFMA behind which barrier B1 sits, positions)
 PLACEMENTS = {
-    0: (3, list(range(4, 20))),                                    # one behind each of MFMAs 4..19
-    1: (3, list(range(4, 36, 2))),                                 # every 2nd MFMA
-    2: (3, list(range(4, 52, 3))),                                 # every 3rd
-    3: (3, list(range(3, 64, 4))[:16]),                            # every 4th, through the whole K-tile
-    4: (3, list(range(4, 30, 3)) + list(range(33, 54, 3))),        # 9 in phase 0, 7 in the first two thirds of phase 1
-    5: (3, [n for n in range(4, 36, 4) for _ in (0, 1)]),          # two behind every 4th MFMA
-    6: (7, list(range(8, 32, 3)) + list(range(33, 57, 3))),        # B1 four MFMAs later; 8 + 8
-    7: (5, list(range(6, 31, 3)) + list(range(33, 52, 3))),        # B1 two MFMAs later; 9 + 7
-    8: (3, list(range(4, 30, 3)) + list(range(32, 46, 2))),        # 9 in phase 0, 7 densely at the start of phase 1
-    9: (7, list(range(8, 31, 2)) + list(range(32, 40, 2))),        # B1 four MFMAs later; every 2nd MFMA
+    0: (3, list(range(4, 20))),                                    # one behind each of MFMAs 4..19 (the first version: 412 us on QKV)
+    3: (3, list(range(3, 64, 4))[:16]),                            # every 4th, through the whole K-tile (388 us)
+    4: (3, list(range(4, 30, 3)) + list(range(33, 54, 3))),        # 9 in phase 0, 7 in the first two thirds of phase 1 (369-383 us)
+    7: (5, list(range(6, 31, 3)) + list(range(33, 52, 3))),        # the same with B1 two MFMAs later (366 us): SHIPPED
+    # measured and dropped (profiles/r3_fp8_gemm_probe.json): every 2nd MFMA (385), every 3rd (386), two
+    # behind every 4th (396), B1 four MFMAs later (370), nine in phase 0 + seven densely at the start of phase 1 (367)
 }
 PLACE_DEFAULT = 7
 B2_AFTER = 30
