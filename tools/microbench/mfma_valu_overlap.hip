@@ -76,6 +76,67 @@ double run(unsigned long long* d, int iters) {
     return (double)h[0] / (2.0 * iters);        // s_memtime ticks (100 MHz) per MFMA + N VALU
 }
 
+
+// Mixed gaps: what the attention stream puts behind each MFMA (2 exp + 2 add + 1 convert) in several orders / splits.
+template <int MIX>
+__global__ __launch_bounds__(256, 1) void kmix(unsigned long long* out, int iters) {
+    f32x16 acc0, acc1;
+    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.5f + threadIdx.x * 1e-3f); b[i] = (__bf16)(0.25f + i * 1e-2f); }
+    float v[10];
+    for (int i = 0; i < 10; ++i) v[i] = 1.0f + i + threadIdx.x * 1e-3f;
+    unsigned w[5] = {0, 0, 0, 0, 0};
+    float s0 = 0.f, s1 = 0.f;
+#define MF(ACC) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(a), "v"(b))
+#define EXP(D, S) asm volatile("v_exp_f32 %0, %1" : "=v"(v[D]) : "v"(v[S]))
+#define ADD(ACC, S) asm volatile("v_add_f32 %0, %0, %1" : "+v"(ACC) : "v"(v[S]))
+#define CVT(D, A, B) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[D]) : "v"(v[A]), "v"(v[B]))
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (MIX == 0) {            // the shipped order: exp, add, exp, add, cvt behind every MFMA
+            MF(acc0); EXP(0, 5); ADD(s0, 2); EXP(1, 6); ADD(s1, 3); CVT(0, 2, 3);
+            MF(acc1); EXP(2, 7); ADD(s0, 0); EXP(3, 8); ADD(s1, 1); CVT(1, 0, 1);
+        } else if constexpr (MIX == 1) {     // exps first
+            MF(acc0); EXP(0, 5); EXP(1, 6); ADD(s0, 2); ADD(s1, 3); CVT(0, 2, 3);
+            MF(acc1); EXP(2, 7); EXP(3, 8); ADD(s0, 0); ADD(s1, 1); CVT(1, 0, 1);
+        } else if constexpr (MIX == 2) {     // plain first
+            MF(acc0); ADD(s0, 2); ADD(s1, 3); CVT(0, 2, 3); EXP(0, 5); EXP(1, 6);
+            MF(acc1); ADD(s0, 0); ADD(s1, 1); CVT(1, 0, 1); EXP(2, 7); EXP(3, 8);
+        } else if constexpr (MIX == 3) {     // exps only (2 per MFMA)
+            MF(acc0); EXP(0, 5); EXP(1, 6);
+            MF(acc1); EXP(2, 7); EXP(3, 8);
+        } else if constexpr (MIX == 4) {     // plain only (2 add + 1 cvt per MFMA)
+            MF(acc0); ADD(s0, 2); ADD(s1, 3); CVT(0, 2, 3);
+            MF(acc1); ADD(s0, 0); ADD(s1, 1); CVT(1, 0, 1);
+        } else if constexpr (MIX == 5) {     // uneven: all four exps behind one MFMA, all plain work behind the other
+            MF(acc0); EXP(0, 5); EXP(1, 6); EXP(2, 7); EXP(3, 8);
+            MF(acc1); ADD(s0, 2); ADD(s1, 3); CVT(0, 2, 3); ADD(s0, 0); ADD(s1, 1); CVT(1, 0, 1);
+        } else if constexpr (MIX == 6) {     // one exp per MFMA + plain work (half the exps: what a head_dim of 128 would need)
+            MF(acc0); EXP(0, 5); ADD(s0, 2); CVT(0, 2, 3);
+            MF(acc1); EXP(2, 7); ADD(s1, 0); CVT(1, 0, 1);
+        } else {                             // 2 exp + 1 add + 1 cvt (row sums elsewhere)
+            MF(acc0); EXP(0, 5); EXP(1, 6); CVT(0, 2, 3);
+            MF(acc1); EXP(2, 7); EXP(3, 8); CVT(1, 0, 1);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = s0 + s1;
+    for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+    for (int i = 0; i < 10; ++i) s += v[i];
+    for (int i = 0; i < 5; ++i) s += (float)w[i];
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)(s != 12345.f); }
+}
+
+template <int MIX>
+double runmix(unsigned long long* d, int iters) {
+    hipLaunchKernelGGL((kmix<MIX>), dim3(256), dim3(256), 0, 0, d, iters);
+    hipLaunchKernelGGL((kmix<MIX>), dim3(256), dim3(256), 0, 0, d, iters);
+    unsigned long long h[2];
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    return (double)h[0] / (2.0 * iters);
+}
+
 template <int KIND, bool AGPR>
 void sweep(unsigned long long* d, const char* name) {
     const int iters = 20000;
@@ -105,5 +166,11 @@ int main() {
     sweep<6, true>(d, "v_dot2_f32_bf16");
     sweep<10, true>(d, "v_ldexp_f32");
     sweep<13, true>(d, "v_lshl_add_u32");
+    const double base = run<0, 0, true>(d, 20000);
+    const char* names[8] = {"exp add exp add cvt (shipped)", "exp exp add add cvt", "add add cvt exp exp", "exp exp", "add add cvt",
+                            "4 exp | 4 add 2 cvt (alternating)", "exp add cvt (one exp per MFMA)", "exp exp cvt"};
+    double r[8] = {runmix<0>(d, 20000), runmix<1>(d, 20000), runmix<2>(d, 20000), runmix<3>(d, 20000), runmix<4>(d, 20000),
+                   runmix<5>(d, 20000), runmix<6>(d, 20000), runmix<7>(d, 20000)};
+    for (int i = 0; i < 8; ++i) printf("mixed gap: %-36s %6.2f cycles per MFMA\n", names[i], r[i] / base * 32.0);
     return 0;
 }
