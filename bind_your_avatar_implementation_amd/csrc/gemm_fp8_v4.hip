@@ -20,8 +20,9 @@
 //   * A(j) retires after its four MFMAs of phase 1 and is re-read right there (needed a full phase later);
 //   * W(4..7) retire with the last MFMAs of phase 1 and are re-read at the START of K-tile t + 1 (needed in its phase 1).
 //   128 fragment VGPRs, one K-tile body, no double buffering.  Two barriers per K-tile: B1 behind the W(4..7) reads (the
-//   last reads of stage t & 1: it is free, the LDS-DMA of K-tile t + 2 goes there, one 1-KiB piece behind each of the next 16
-//   MFMAs), B2 at the phase boundary behind s_waitcnt vmcnt(16) (K-tile t + 1 has landed for every wave; only the 16
+//   last reads of stage t & 1, one pair behind each of the first MFMAs; B1 sits behind MFMA 9, when they have long returned:
+//   the stage is free, the LDS-DMA of K-tile t + 2 goes there, one 1-KiB piece behind every third MFMA -- a vector-memory
+//   instruction costs its wave ~17 cycles of matrix time, 16 of them in a row stalled all four waves), B2 at the phase boundary behind s_waitcnt vmcnt(16) (K-tile t + 1 has landed for every wave; only the 16
 //   pieces just requested may still be in flight).
 //
 // K-tile variants: A first (accumulators start from the instruction's inline zero), B steady, C last-but-one (the DMA
@@ -34,7 +35,7 @@
 #include "gemm_common.h"
 
 #ifndef BYA_F8_PLACE
-#define BYA_F8_PLACE 7      // placement of the 16 LDS-DMA pieces inside a K-tile (tools/gen_gemm_fp8_schedule.py holds the tables)
+#define BYA_F8_PLACE 9      // placement of the 16 LDS-DMA pieces inside a K-tile (tools/gen_gemm_fp8_schedule.py holds the tables)
 #endif
 #ifndef BYA_F8_ABLATE
 #define BYA_F8_ABLATE 0     // timing-only ablations (tools/): 1 = no LDS-DMA in the K-loop, 2 = no K-loop barriers, 4 = no fragment re-reads
@@ -545,6 +546,204 @@ __global__ __launch_bounds__(256, 1) void gemm256p_fp8_kernel(GemmArgs p, const 
             MF8(6, 5);
             MF8(7, 5); REREAD_A(5);
             MF8(4, 6);
+            MF8(5, 6);
+            MF8(6, 6);
+            MF8(7, 6); REREAD_A(6);
+            MF8(4, 7);
+            MF8(5, 7);
+            MF8(6, 7);
+            MF8(7, 7); REREAD_A(7);
+#elif BYA_F8_PLACE == 8
+            RWF(4, cWl, cWh);
+            MF8(0, 0); RWF(5, cWl, cWh);
+            MF8(1, 0); RWF(6, cWl, cWh);
+            MF8(2, 0); RWF(7, cWl, cWh);
+            MF8(3, 0);
+            MF8(0, 1);
+            MF8(1, 1);
+            MF8(2, 1);
+            MF8(3, 1); B1();
+            MF8(0, 2); PIECE(0, false);
+            MF8(1, 2);
+            MF8(2, 2);
+            MF8(3, 2); PIECE(1, false);
+            MF8(0, 3);
+            MF8(1, 3);
+            MF8(2, 3); PIECE(2, false);
+            MF8(3, 3);
+            MF8(0, 4);
+            MF8(1, 4); PIECE(3, false);
+            MF8(2, 4);
+            MF8(3, 4);
+            MF8(0, 5); PIECE(4, false);
+            MF8(1, 5);
+            MF8(2, 5);
+            MF8(3, 5); PIECE(5, false);
+            MF8(0, 6);
+            MF8(1, 6);
+            MF8(2, 6); PIECE(6, false);
+            MF8(3, 6);
+            MF8(0, 7);
+            MF8(1, 7); PIECE(7, false);
+            MF8(2, 7); B2(8);
+            MF8(3, 7); REREAD_W();
+            MF8(4, 0);
+            MF8(5, 0); PIECE(0, true);
+            MF8(6, 0);
+            MF8(7, 0); REREAD_A(0);
+            MF8(4, 1); PIECE(1, true);
+            MF8(5, 1);
+            MF8(6, 1);
+            MF8(7, 1); PIECE(2, true); REREAD_A(1);
+            MF8(4, 2);
+            MF8(5, 2);
+            MF8(6, 2); PIECE(3, true);
+            MF8(7, 2); REREAD_A(2);
+            MF8(4, 3);
+            MF8(5, 3); PIECE(4, true);
+            MF8(6, 3);
+            MF8(7, 3); REREAD_A(3);
+            MF8(4, 4); PIECE(5, true);
+            MF8(5, 4);
+            MF8(6, 4);
+            MF8(7, 4); PIECE(6, true); REREAD_A(4);
+            MF8(4, 5);
+            MF8(5, 5);
+            MF8(6, 5); PIECE(7, true);
+            MF8(7, 5); REREAD_A(5);
+            MF8(4, 6);
+            MF8(5, 6);
+            MF8(6, 6);
+            MF8(7, 6); REREAD_A(6);
+            MF8(4, 7);
+            MF8(5, 7);
+            MF8(6, 7);
+            MF8(7, 7); REREAD_A(7);
+#elif BYA_F8_PLACE == 9
+            RWF(4, cWl, cWh);
+            MF8(0, 0); RWF(5, cWl, cWh);
+            MF8(1, 0); RWF(6, cWl, cWh);
+            MF8(2, 0); RWF(7, cWl, cWh);
+            MF8(3, 0);
+            MF8(0, 1);
+            MF8(1, 1);
+            MF8(2, 1);
+            MF8(3, 1);
+            MF8(0, 2);
+            MF8(1, 2); B1();
+            MF8(2, 2); PIECE(0, false);
+            MF8(3, 2);
+            MF8(0, 3);
+            MF8(1, 3); PIECE(1, false);
+            MF8(2, 3);
+            MF8(3, 3);
+            MF8(0, 4); PIECE(2, false);
+            MF8(1, 4);
+            MF8(2, 4);
+            MF8(3, 4); PIECE(3, false);
+            MF8(0, 5);
+            MF8(1, 5);
+            MF8(2, 5); PIECE(4, false);
+            MF8(3, 5);
+            MF8(0, 6);
+            MF8(1, 6); PIECE(5, false);
+            MF8(2, 6);
+            MF8(3, 6);
+            MF8(0, 7); PIECE(6, false);
+            MF8(1, 7);
+            MF8(2, 7); B2(7);
+            MF8(3, 7); REREAD_W();
+            MF8(4, 0); PIECE(7, false);
+            MF8(5, 0);
+            MF8(6, 0);
+            MF8(7, 0); PIECE(0, true); REREAD_A(0);
+            MF8(4, 1);
+            MF8(5, 1);
+            MF8(6, 1); PIECE(1, true);
+            MF8(7, 1); REREAD_A(1);
+            MF8(4, 2);
+            MF8(5, 2); PIECE(2, true);
+            MF8(6, 2);
+            MF8(7, 2); REREAD_A(2);
+            MF8(4, 3); PIECE(3, true);
+            MF8(5, 3);
+            MF8(6, 3);
+            MF8(7, 3); PIECE(4, true); REREAD_A(3);
+            MF8(4, 4);
+            MF8(5, 4);
+            MF8(6, 4); PIECE(5, true);
+            MF8(7, 4); REREAD_A(4);
+            MF8(4, 5);
+            MF8(5, 5); PIECE(6, true);
+            MF8(6, 5);
+            MF8(7, 5); REREAD_A(5);
+            MF8(4, 6); PIECE(7, true);
+            MF8(5, 6);
+            MF8(6, 6);
+            MF8(7, 6); REREAD_A(6);
+            MF8(4, 7);
+            MF8(5, 7);
+            MF8(6, 7);
+            MF8(7, 7); REREAD_A(7);
+#elif BYA_F8_PLACE == 10
+            RWF(4, cWl, cWh);
+            MF8(0, 0); RWF(5, cWl, cWh);
+            MF8(1, 0); RWF(6, cWl, cWh);
+            MF8(2, 0); RWF(7, cWl, cWh);
+            MF8(3, 0);
+            MF8(0, 1);
+            MF8(1, 1);
+            MF8(2, 1);
+            MF8(3, 1);
+            MF8(0, 2);
+            MF8(1, 2);
+            MF8(2, 2);
+            MF8(3, 2); B1();
+            MF8(0, 3); PIECE(0, false);
+            MF8(1, 3);
+            MF8(2, 3);
+            MF8(3, 3); PIECE(1, false);
+            MF8(0, 4);
+            MF8(1, 4);
+            MF8(2, 4); PIECE(2, false);
+            MF8(3, 4);
+            MF8(0, 5);
+            MF8(1, 5); PIECE(3, false);
+            MF8(2, 5);
+            MF8(3, 5);
+            MF8(0, 6); PIECE(4, false);
+            MF8(1, 6);
+            MF8(2, 6);
+            MF8(3, 6); PIECE(5, false);
+            MF8(0, 7);
+            MF8(1, 7);
+            MF8(2, 7); PIECE(6, false); B2(7);
+            MF8(3, 7); REREAD_W();
+            MF8(4, 0); PIECE(7, false);
+            MF8(5, 0);
+            MF8(6, 0);
+            MF8(7, 0); PIECE(0, true); REREAD_A(0);
+            MF8(4, 1);
+            MF8(5, 1);
+            MF8(6, 1); PIECE(1, true);
+            MF8(7, 1); REREAD_A(1);
+            MF8(4, 2);
+            MF8(5, 2); PIECE(2, true);
+            MF8(6, 2);
+            MF8(7, 2); REREAD_A(2);
+            MF8(4, 3); PIECE(3, true);
+            MF8(5, 3);
+            MF8(6, 3);
+            MF8(7, 3); PIECE(4, true); REREAD_A(3);
+            MF8(4, 4);
+            MF8(5, 4);
+            MF8(6, 4); PIECE(5, true);
+            MF8(7, 4); REREAD_A(4);
+            MF8(4, 5);
+            MF8(5, 5); PIECE(6, true);
+            MF8(6, 5);
+            MF8(7, 5); REREAD_A(5);
+            MF8(4, 6); PIECE(7, true);
             MF8(5, 6);
             MF8(6, 6);
             MF8(7, 6); REREAD_A(6);

@@ -13,23 +13,32 @@ PLACEMENTS = {
     0: (3, list(range(4, 20))),                                    # one behind each of MFMAs 4..19 (the first version: 412 us on QKV)
     3: (3, list(range(3, 64, 4))[:16]),                            # every 4th, through the whole K-tile (388 us)
     4: (3, list(range(4, 30, 3)) + list(range(33, 54, 3))),        # 9 in phase 0, 7 in the first two thirds of phase 1 (369-383 us)
-    7: (5, list(range(6, 31, 3)) + list(range(33, 52, 3))),        # the same with B1 two MFMAs later (366 us): SHIPPED
+    7: (5, list(range(6, 31, 3)) + list(range(33, 52, 3))),        # the same with B1 two MFMAs later (366-379 us)
+    8: (7, list(range(8, 31, 3)) + list(range(33, 55, 3)), True),  # W(4..7) reads spread over MFMAs 0..3, B1 behind MFMA 7
+    9: (9, list(range(10, 31, 3)) + list(range(32, 57, 3)), True), # ... B1 behind MFMA 9 (368 us): SHIPPED
+    10: (11, list(range(12, 31, 3)) + list(range(32, 59, 3))[:9], True),   # ... B1 behind MFMA 11
     # measured and dropped (profiles/r3_fp8_gemm_probe.json): every 2nd MFMA (385), every 3rd (386), two
     # behind every 4th (396), B1 four MFMAs later (370), nine in phase 0 + seven densely at the start of phase 1 (367)
 }
-PLACE_DEFAULT = 7
+PLACE_DEFAULT = 9
 B2_AFTER = 30
 
 
 def body(entry):
-    B1_AFTER, pos = entry
+    B1_AFTER, pos = entry[0], entry[1]
+    spread = len(entry) > 2 and entry[2]
     assert len(pos) == 16 and all(B1_AFTER <= n < 64 for n in pos) and pos == sorted(pos), entry
     out = []
     emit = out.append
-    emit("            RWF(4, cWl, cWh); RWF(5, cWl, cWh); RWF(6, cWl, cWh); RWF(7, cWl, cWh);")
+    if spread:
+        emit("            RWF(4, cWl, cWh);")
+    else:
+        emit("            RWF(4, cWl, cWh); RWF(5, cWl, cWh); RWF(6, cWl, cWh); RWF(7, cWl, cWh);")
     for n in range(64):
         phase, j, i = n >> 5, (n >> 2) & 7, (n & 3) + 4 * (n >> 5)
         line = f"            MF8({i}, {j});"
+        if spread and n < 3:
+            line += f" RWF({5 + n}, cWl, cWh);"
         if n == B1_AFTER:
             line += " B1();"
         for k, at in enumerate(pos):
