@@ -918,6 +918,7 @@ extern "C" int bya_attn_kv_mix(const void* q, const void* k, const void* v, cons
     if (!q || !k || !v || !r || !z || !d) return BYA_ERR_SHAPE;
     if (d->head_dim != 64 && d->head_dim != 128) return BYA_ERR_UNSUPPORTED;
     if (d->heads <= 0 || d->n_id < 1 || d->n_id > 4 || d->n_grp <= 0 || d->Sq <= 0 || d->Skv <= 0 || d->Skv > KV_TILE) return BYA_ERR_SHAPE;
+    if (af && d->n_id < 2) return BYA_ERR_SHAPE;      // the audio mix (af . r) needs >= 2 streams; routing_weights_of has no 1-stream audio case
     if ((d->q_grp | d->q_row | d->k_id | d->k_grp | d->k_row | d->v_id | d->v_grp | d->v_row) % 8) return BYA_ERR_ALIGN;
     if ((d->z_grp | d->z_row) % 4) return BYA_ERR_ALIGN;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return BYA_ERR_ALIGN;

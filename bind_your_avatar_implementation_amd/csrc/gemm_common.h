@@ -205,7 +205,8 @@ int gemm_row_chunks(const GemmArgs& a, int batch, int a_elem_bytes, F&& run) {
                                                   ((long long)z * a.a_bs + (long long)m0 * a.lda) * a_elem_bytes);
             s.C = a.C + (long long)z * a.c_bs + (long long)m0 * a.ldc;
             if (a.res) s.res = a.res + (long long)z * a.res_bs + (long long)m0 * a.ldres;
-            if (a.gate0) { s.gate0 = a.gate0 + (long long)z * a.gate_bs; s.gate1 = a.gate1 + (long long)z * a.gate_bs; }
+            if (a.gate0) s.gate0 = a.gate0 + (long long)z * a.gate_bs;
+            if (a.gate1) s.gate1 = a.gate1 + (long long)z * a.gate_bs;      // a null gate1 stays null (one gate for every row)
             if (a.bias_rowscale) s.bias_rowscale = a.bias_rowscale + (long long)z * a.M + m0;
             s.gate_split = a.gate_split > m0 ? a.gate_split - m0 : 0;
             const int rc = run(s, 1, (long long)z * a.M + m0);

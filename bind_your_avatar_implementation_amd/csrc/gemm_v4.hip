@@ -1017,15 +1017,19 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
-                    // arrive: count within this launch's epoch; a word of an older epoch (or the zero-filled initial
-                    // state) is replaced, a word of a NEWER epoch means this writer is the stale one and must not touch it
+                    // arrive: count within this launch's epoch.  A word of another epoch is taken over when it is IDLE
+                    // (arrival count 0: every finisher leaves its word that way, and so does the zero-filled initial state)
+                    // or older.  Idle words must be claimable whatever their epoch: a hipGraph replays its launches with
+                    // the epochs baked in at capture, so the first split launch of a replay finds the words stamped by the
+                    // LAST launch of the previous replay (or by an eager launch in between) -- a "newer" epoch.  Only a
+                    // newer word with arrivals in it means this writer is the stale one (a timed-out launch) and must not touch it.
                     unsigned* const c = p.ws_counters + cur.ctr;
                     unsigned old = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     for (;;) {
                         const unsigned oe = old >> 8, age = (epoch - oe) & 0xffffffu;
                         unsigned want;
                         if (oe == epoch) want = old + 1u;
-                        else if (oe == 0u || age < 0x800000u) want = (epoch << 8) | 1u;
+                        else if ((old & 0xffu) == 0u || age < 0x800000u) want = (epoch << 8) | 1u;
                         else break;
                         if (__hip_atomic_compare_exchange_strong(c, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT)) break;

@@ -203,7 +203,8 @@ class BindyouravatarPipeline:
                  callback_on_step_end_tensor_inputs: List[str] = ["latents"], max_sequence_length: int = 226,
                  id_vit_hidden=None, id_cond=None, kps_cond=None, audio_embs=None, af_matrix=None,
                  zero2cond_cfg_flag: bool = False, routing_logits_zeros_flag: bool = False,
-                 routing_logits_forcing=None, image_bg=None, image_latents=None, image_bg_latents=None):
+                 routing_logits_forcing=None, image_bg=None, image_latents=None, image_bg_latents=None,
+                 kps_cond_latents=None):
         max_frames = int(getattr(self.transformer.config, "sample_frames", 49))
         if num_frames > max_frames:     # reference :739-742 with its constant 49 = the stock config's sample_frames
             raise ValueError(f"The number of frames must be less than {max_frames} for now due to static positional "
@@ -213,12 +214,18 @@ class BindyouravatarPipeline:
         if (image is not None or image_bg is not None or output_type != "latent") and self.vae is None:
             raise NotImplementedError("pass vae=BindyouravatarVAE(...) to the pipeline to encode `image` / `image_bg` and to "
                                       "decode frames; without it give image_latents and use output_type='latent'")
-        if image is not None and image_latents is None:        # reference prepare_latents: posterior SAMPLE of the frame
-            image_latents = self.encode_image(image, generator)
-        if image_bg is not None and image_bg_latents is None:
-            image_bg_latents = self.encode_image(image_bg, generator)
-        if prompt_embeds is None or image_latents is None:
-            raise ValueError("prompt_embeds and image_latents are required")
+        if num_videos_per_prompt != 1:
+            raise NotImplementedError("num_videos_per_prompt != 1: the reference repeats only the prompt embeddings "
+                                      "(pipeline_bindyouravatar.py:786-799), not the identity / audio conditioning; pass a batch")
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0: the built-in schedulers are the deterministic DDIM step and DPM-Solver++ "
+                                      "(which takes no eta); bring a diffusers scheduler object for stochastic DDIM")
+        if kps_cond is not None and not torch.is_tensor(kps_cond):
+            raise NotImplementedError("kps_cond must be the key-point IMAGE tensor [B, 3, H, W] in [-1, 1] (the reference "
+                                      "draws it with cv2, models/utils.py draw_kps + VideoProcessor.preprocess, :814-818: "
+                                      "image-side preprocessing outside the engine), or pass kps_cond_latents")
+        if prompt_embeds is None or (image is None and image_latents is None):
+            raise ValueError("prompt_embeds and image (or image_latents) are required")
         tr = self.transformer
         dev, dtype = tr.device, tr.dtype
         self._guidance_scale, self._interrupt = guidance_scale, False
@@ -229,25 +236,23 @@ class BindyouravatarPipeline:
             if negative_prompt_embeds is None:
                 raise ValueError("classifier-free guidance needs negative_prompt_embeds")
             prompt_embeds = torch.cat([negative_prompt_embeds.to(dev, dtype), prompt_embeds], dim=0)   # [uncond, cond]
-        lat_frames = (num_frames - 1) // self.vae_scale_factor_temporal + 1
-        ch = tr.config.in_channels // (3 if image_bg_latents is not None or tr.config.in_channels % 3 == 0 else 2)
-        shape = (batch, lat_frames, ch, height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
-        if latents is None:
-            latents = torch.randn(shape, generator=generator, device=dev if generator is None else generator.device)
-        latents = latents.to(dev, dtype)
-        assert tuple(latents.shape) == shape, (tuple(latents.shape), shape)
-        def pad_frames(lat):        # the encoded frame first, zeros for the frames to generate (reference :426-446)
-            lat = lat.to(dev, dtype)
-            if lat.shape[1] < lat_frames:
-                lat = torch.cat([lat, lat.new_zeros(lat.shape[0], lat_frames - lat.shape[1], *lat.shape[2:])], dim=1)
-            return lat
-        image_latents = pad_frames(image_latents)
-        if image_bg_latents is not None:
-            image_bg_latents = pad_frames(image_bg_latents)
-        if image_bg_latents is None or not use_inpaint:
-            image_bg_latents = torch.zeros_like(image_latents) if tr.config.in_channels == 3 * ch else None
-        elif image_bg_latents is not None:
-            image_bg_latents = image_bg_latents.to(dev, dtype)
+        # reference :827-830: the background stream decides how in_channels splits (noise | image [| background])
+        has_bg = image_bg is not None or image_bg_latents is not None
+        ch = tr.config.in_channels // (3 if has_bg else 2)
+        latents, image_latents = self.prepare_latents(image, batch, ch, num_frames, height, width, dtype, dev, generator,
+                                                      latents, kps_cond, image_latents, kps_cond_latents)
+        lat_frames = latents.shape[1]
+        if has_bg:                                           # :845-860 (the second call never draws new noise)
+            _, image_bg_latents = self.prepare_latents(image_bg, batch, ch, num_frames, height, width, dtype, dev, generator,
+                                                       latents, kps_cond, image_bg_latents, kps_cond_latents)
+            if not use_inpaint:
+                image_bg_latents = torch.zeros_like(image_latents)
+        got = latents.shape[2] + image_latents.shape[2] * (2 if has_bg else 1)
+        if got != tr.config.in_channels:
+            raise ValueError(f"noise ({latents.shape[2]}) + condition latents ({got - latents.shape[2]}) = {got} channels, but the "
+                             f"transformer takes in_channels = {tr.config.in_channels}: like the reference (:827-830) the "
+                             "pipeline gives the noise in_channels // 3 channels only when a background stream is passed "
+                             "(image_bg / image_bg_latents; with use_inpaint=False it is zero-filled), else in_channels // 2")
         ts = self.scheduler.set_timesteps(num_inference_steps, dev) if timesteps is None else torch.tensor(timesteps, device=dev)
         self._num_timesteps = len(ts)
         rope = self._rotary(height, width, lat_frames, dev) if tr.config.use_rotary_positional_embeddings else None
@@ -312,9 +317,54 @@ class BindyouravatarPipeline:
         return SimpleNamespace(frames=latents)
 
     def encode_image(self, image, generator=None):
-        """image [B, 3, H, W] in [-1, 1] -> scaled latents [B, 1, C, H / 8, W / 8] (reference :406-424, one frame)."""
-        dist = self.vae.encode(image.unsqueeze(2)).latent_dist
-        return self.vae_scaling_factor_image * dist.sample(generator).permute(0, 2, 1, 3, 4)
+        """image [B, 3, H, W] in [-1, 1] -> scaled latents [B, 1, C, H / 8, W / 8]: the posterior SAMPLE of every image on
+        its own, in batch order, from the caller's generator (reference :406-424: one ``vae.encode`` + one draw per image)."""
+        gens = generator if isinstance(generator, (list, tuple)) else [generator] * image.shape[0]
+        lat = [self.vae.encode(img[None, :, None]).latent_dist.sample(g) for img, g in zip(image, gens)]
+        return self.vae_scaling_factor_image * torch.cat(lat, dim=0).permute(0, 2, 1, 3, 4)
+
+    def prepare_latents(self, image, batch_size=1, num_channels_latents=16, num_frames=13, height=60, width=90, dtype=None,
+                        device=None, generator=None, latents=None, kps_cond=None, image_latents=None, kps_cond_latents=None):
+        """reference models/pipeline_bindyouravatar.py:376-458, draw for draw: encode the first frame (one posterior draw
+        per image), then the key-point image when given (one draw per image), then -- only when the caller passed no
+        ``latents`` -- the initial noise.  The encoded frame comes first, the key-point frame second, zeros for the
+        ``num_frames - 1`` (``- 2`` with key points) latent frames to generate.  ``image_latents`` / ``kps_cond_latents``
+        [B, 1, C, h, w] (already scaled) stand in for ``image`` / ``kps_cond`` when the pipeline has no VAE.
+        -> (latents [B, F, C, h, w], condition latents [B, F, C', h, w])."""
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
+                             f"batch size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if (image is not None or (kps_cond is not None and kps_cond_latents is None)) and self.vae is None:
+            raise NotImplementedError("pass vae=BindyouravatarVAE(...) to the pipeline to encode `image` / `image_bg` / `kps_cond`; "
+                                      "without it give image_latents (and kps_cond_latents)")
+        frames = (num_frames - 1) // self.vae_scale_factor_temporal + 1
+        h, w = height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial
+        shape = (batch_size, frames, num_channels_latents, h, w)
+        if image is not None and image_latents is None:
+            image_latents = self.encode_image(image.to(device, dtype), generator)
+            if kps_cond is not None and kps_cond_latents is None:
+                kps_cond_latents = self.encode_image(kps_cond.to(device, dtype), generator)
+        elif kps_cond is not None and kps_cond_latents is None:
+            kps_cond_latents = self.encode_image(kps_cond.to(device, dtype), generator)
+        parts = [image_latents.to(device, dtype)]
+        if kps_cond_latents is not None:
+            parts.append(kps_cond_latents.to(device, dtype))
+        have = sum(p.shape[1] for p in parts)
+        if have < frames:
+            parts.append(torch.zeros(batch_size, frames - have, *parts[0].shape[2:], device=device, dtype=dtype))
+        image_latents = torch.cat(parts, dim=1)
+        if latents is None:          # diffusers randn_tensor: drawn on the generator's device, in the target dtype
+            if isinstance(generator, (list, tuple)):
+                latents = torch.cat([torch.randn((1,) + shape[1:], generator=g, device=g.device, dtype=dtype).to(device)
+                                     for g in generator], dim=0)
+            else:
+                gdev = device if generator is None else generator.device
+                latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+        else:
+            latents = latents.to(device)
+        if tuple(latents.shape) != shape:
+            raise ValueError(f"latents {tuple(latents.shape)} != {shape}")
+        return latents.to(dtype) * getattr(self.scheduler, "init_noise_sigma", 1.0), image_latents
 
     def decode_latents(self, latents):
         """reference :461-466."""

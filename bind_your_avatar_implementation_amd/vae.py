@@ -101,17 +101,20 @@ class _Encoder(nn.Module):
 
 
 class DiagonalGaussian:
-    """``latent_dist`` of ``encode``: mean | logvar; ``sample`` draws with the caller's generator (diffusers'
-    DiagonalGaussianDistribution: logvar clamped to [-30, 20])."""
+    """``latent_dist`` of ``encode``: mean | logvar; ``sample`` draws with the caller's generator.  diffusers'
+    DiagonalGaussianDistribution, arithmetic included: logvar clamped to [-30, 20], ``std = exp(0.5 logvar)``, the noise
+    drawn in the PARAMETERS' dtype on the generator's device (randn_tensor) and ``mean + std * noise`` evaluated in that
+    dtype -- with the same seed the draw stream and the bf16 roundings are the reference pipeline's."""
 
     def __init__(self, moments):
         self.mean, logvar = moments.chunk(2, dim=1)
-        self.logvar = logvar.float().clamp(-30.0, 20.0)
+        self.logvar = logvar.clamp(-30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
 
     def sample(self, generator=None):
-        noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device if generator is None else generator.device,
-                            dtype=torch.float32).to(self.mean.device)
-        return (self.mean.float() + torch.exp(0.5 * self.logvar) * noise).to(self.mean.dtype)
+        gdev = self.mean.device if generator is None else generator.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=gdev, dtype=self.mean.dtype).to(self.mean.device)
+        return self.mean + self.std * noise
 
     def mode(self):
         return self.mean

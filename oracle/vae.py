@@ -268,3 +268,35 @@ class OracleVAE(nn.Module):
         mean, logvar = self.encode_moments(image.unsqueeze(2))
         z = mean if noise is None else mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise
         return self.scaling_factor * z.permute(0, 2, 1, 3, 4)
+
+
+class DiagonalGaussianDistribution:
+    """diffusers ``models/autoencoders/vae.py`` DiagonalGaussianDistribution as published (0.31 - 0.34), the object behind
+    ``vae.encode(x).latent_dist`` that the reference samples once per image (models/pipeline_bindyouravatar.py:177-181,
+    :409-420): ``mean | logvar = chunk(parameters, 2, dim=1)``, logvar clamped to [-30, 20], ``std = exp(0.5 logvar)``;
+    ``sample`` draws ``randn_tensor(mean.shape, generator, device=parameters.device, dtype=parameters.dtype)`` -- on the
+    generator's device when that is the CPU -- and returns ``mean + std * noise`` in the parameters' dtype.
+    diffusers-owned: parity unpinned (no diffusers in this image)."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None):
+        return self.mean + self.std * randn_tensor(self.mean.shape, generator, self.parameters.device, self.parameters.dtype)
+
+    def mode(self):
+        return self.mean
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None):
+    """diffusers ``utils/torch_utils.py`` randn_tensor for the cases the reference pipeline reaches: one generator (drawn
+    on ITS device, moved afterwards) or a list of per-sample generators."""
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    if isinstance(generator, (list, tuple)):
+        shape1 = (1,) + tuple(shape[1:])
+        return torch.cat([torch.randn(shape1, generator=g, device=g.device, dtype=dtype).to(device) for g in generator], dim=0)
+    rdev = device if generator is None else generator.device
+    return torch.randn(tuple(shape), generator=generator, device=rdev, dtype=dtype).to(device)

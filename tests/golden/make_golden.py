@@ -357,6 +357,67 @@ def run_deep(case, layers, seed, step, over, inp):
     np.savez_compressed(os.path.join(HERE, f"ref_forward_{case}_L{layers}_seed{seed}.npz"), **fx)
 
 
+def install_pipeline_standins():
+    """The extra ``diffusers`` names models/pipeline_bindyouravatar.py imports at module level (none of them is reached by
+    ``prepare_latents`` except ``randn_tensor``, restated in oracle/vae.py)."""
+    from oracle import vae as OV
+
+    def mod(name, **attrs):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+    mod("diffusers.callbacks", MultiPipelineCallbacks=_Any, PipelineCallback=_Any)
+    mod("diffusers.image_processor", PipelineImageInput=object)
+    mod("diffusers.models", AutoencoderKLCogVideoX=_Any, CogVideoXTransformer3DModel=_Any)
+    mod("diffusers.pipelines.pipeline_utils", DiffusionPipeline=_Any)
+    mod("diffusers.schedulers", CogVideoXDDIMScheduler=_Any, CogVideoXDPMScheduler=_Any)
+    sys.modules["diffusers.utils"].replace_example_docstring = lambda doc: (lambda f: f)
+    mod("diffusers.utils.torch_utils", randn_tensor=OV.randn_tensor)
+    mod("diffusers.video_processor", VideoProcessor=_Any)
+    mod("diffusers.pipelines.cogvideo.pipeline_output", CogVideoXPipelineOutput=_Any)
+    sys.modules["diffusers.loaders"].CogVideoXLoraLoaderMixin = type("CogVideoXLoraLoaderMixin", (), {})
+
+
+def run_prepare_latents():
+    """The REFERENCE's ``BindyouravatarPipeline.prepare_latents`` (models/pipeline_bindyouravatar.py:376-458), called the way
+    ``__call__`` calls it (:831-860: once for the image -- which draws the noise when the caller gave none -- and once
+    more for the background image with the latents of the first call), on the stub VAE of tests/golden/stub_vae.py."""
+    install_standins()
+    install_pipeline_standins()
+    from models import pipeline_bindyouravatar as P
+    from oracle.vae import DiagonalGaussianDistribution
+    sys.path.insert(0, HERE)
+    from stub_vae import StubVAE, prepare_latents_cases, prepare_latents_inputs
+    fx = {}
+    for name, dtype, batch, kps, bg, gk in prepare_latents_cases():
+        vae = StubVAE(DiagonalGaussianDistribution)
+        me = types.SimpleNamespace(vae=vae, vae_scale_factor_temporal=4, vae_scale_factor_spatial=8,
+                                   vae_scaling_factor_image=vae.config.scaling_factor,
+                                   scheduler=types.SimpleNamespace(init_noise_sigma=1.0))
+        inp = prepare_latents_inputs(name, dtype, batch)
+        gen = ([torch.Generator().manual_seed(100 + i) for i in range(batch)] if gk == "list"
+               else torch.Generator().manual_seed(100))
+        given = inp["latents"] if "given_latents" in name else None
+        kp = inp["kps"] if kps else None
+        lat, img = P.BindyouravatarPipeline.prepare_latents(me, inp["image"], batch, 16, 9, 32, 48, dtype, torch.device("cpu"),
+                                                            gen, given, kp)
+        fx[name + ".latents"], fx[name + ".image_latents"] = lat.float().numpy(), img.float().numpy()
+        if bg:
+            lat2, bgl = P.BindyouravatarPipeline.prepare_latents(me, inp["bg"], batch, 16, 9, 32, 48, dtype,
+                                                                 torch.device("cpu"), gen, lat, kp)
+            assert torch.equal(lat2, lat)
+            fx[name + ".image_bg_latents"] = bgl.float().numpy()
+        print(name, tuple(lat.shape), tuple(img.shape), "vae.encode calls:", vae.calls)
+        fx[name + ".encode_calls"] = np.array(vae.calls)
+    np.savez_compressed(os.path.join(HERE, "ref_prepare_latents.npz"), **fx)
+
+
 def config0_inputs(seed):
     """BASELINE.json configs[0]: 1 audio + 1 face stream = the 2-stream call with the second identity's
     ``id_cond`` / ``id_vit_hidden`` and the second audio stream zero-filled."""
@@ -500,7 +561,7 @@ def run_masks(seed):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--case", default="base", choices=["base", "cfg_forcing", "modules", "masks", "depth", "config0",
+    ap.add_argument("--case", default="base", choices=["base", "cfg_forcing", "modules", "masks", "depth", "config0", "prepare_latents",
                                                         "bars"])
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
@@ -509,6 +570,8 @@ if __name__ == "__main__":
     if a.case == "masks":
         install_standins()
         run_masks(a.seed)
+    elif a.case == "prepare_latents":
+        run_prepare_latents()
     elif a.case == "modules":
         run_modules(a.seed)
     elif a.case == "depth":

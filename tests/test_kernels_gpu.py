@@ -199,6 +199,54 @@ def test_gemm_split_k_inside_a_replayed_hip_graph(ops, dev):
     assert torch.equal(replay2, out)
     ops.gemm(small_a, small_w, small_out)
     assert torch.equal(small_out, small_ref)
+    # no finisher gave up (a timed-out finisher still adds slabs that landed long before, so equality alone proves nothing)
+    torch.cuda.synchronize()
+    assert ops.gemm_workspace_status() == 0
+    ops.check_gemm_workspace()
+
+
+def test_gemm_several_split_launches_in_one_replayed_hip_graph(ops, dev):
+    """A hipGraph replays its launches with the launch epochs baked in at capture.  With several split launches in one
+    graph the counter words, shared by all of them, carry the LAST launch's epoch when the next replay starts: the first
+    launch's writers must still be able to claim them (an idle word is claimable whatever its epoch).  Before that rule
+    every replay after the first stalled ~1 s per split launch in the finisher's bounded wait and raised
+    bya_gemm_workspace_status.  Checks: bit-identical replays, status 0, and a wall-time bound far below one time-out."""
+    import time
+    M, N, K = 17776, 3072, 12288
+    a = [rnd((M, K), dev, 51 + i) for i in range(3)]
+    w = rnd((N, K), dev, 55, K ** -0.5)
+    outs = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+    eager = []
+    for x, o in zip(a, outs):
+        ops.gemm(x, w, o)
+        eager.append(o.clone())
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for x, o in zip(a, outs):
+            ops.gemm(x, w, o)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        for x, o in zip(a, outs):
+            ops.gemm(x, w, o)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for rep in range(4):
+        for o in outs:
+            o.zero_()
+        g.replay()
+        if rep == 1:                                    # an eager split launch between two replays stamps a newer epoch too
+            tmp = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm(a[0], w, tmp)
+            assert torch.equal(tmp, eager[0])
+        for o, e in zip(outs, eager):
+            assert torch.equal(o, e)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert ops.gemm_workspace_status() == 0, "a split-K finisher timed out inside a replayed graph"
+    ops.check_gemm_workspace()
+    assert dt < 0.5, f"4 replays of 3 split launches took {dt:.2f} s: a finisher sat in its bounded wait"
 
 
 def test_gemm_mfma_layout_asymmetric(ops, dev):

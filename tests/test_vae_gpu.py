@@ -108,6 +108,51 @@ def test_decode_small_clip_vs_oracle(dev, frames):
     assert torch.isfinite(out.float()).all() and e <= 1.5 * e16 + 2e-3
 
 
+@pytest.mark.parametrize("frames", [1, 3])
+def test_decode_stock_widths_vs_oracle(dev, frames):
+    """The STOCK decoder (128-256-256-512, three resnets per block -- what the pipeline ships) end to end against the oracle on
+    a 6 x 8 latent, 1 and 3 latent frames: every conv of it takes the implicit-GEMM path (C = 128 / 256 / 512 all occur, incl.
+    the up-samplers and conv_out), which the reduced-width tests above reach at one level only.  Same bar as everywhere."""
+    from bind_your_avatar_implementation_amd import vae as vae_mod
+    vae, orc = make(dev, seed=11)
+    g = torch.Generator().manual_seed(12)
+    z = torch.randn(1, 16, frames, 6, 8, generator=g)
+    ref = orc.decode(z)
+    ref16 = orc.to(torch.bfloat16).decode(z.to(torch.bfloat16)).float()
+    seen = []
+    orig = vae_mod.ops.vae_conv3d
+    vae_mod.ops.vae_conv3d = lambda *a, **k: (seen.append(a[0].shape[-1]), orig(*a, **k))[1]
+    try:
+        out = vae.decode(z.to(dev)).sample
+    finally:
+        vae_mod.ops.vae_conv3d = orig
+    assert {128, 256, 512} <= set(seen), f"implicit-GEMM convolution widths seen: {sorted(set(seen))}"
+    assert tuple(out.shape) == tuple(ref.shape) == (1, 3, 4 * (frames - 1) + 1, 48, 64)
+    e, e16 = rel_fro(out.float().cpu(), ref), rel_fro(ref16, ref)
+    print(f"stock-width VAE decode, {frames} latent frames: engine-vs-fp32 {e:.3e}   bf16-oracle-vs-fp32 {e16:.3e}   "
+          f"({len(seen)} implicit-GEMM convolutions)")
+    assert torch.isfinite(out.float()).all() and e <= 1.5 * e16 + 2e-3
+
+
+def test_encode_stock_widths_vs_oracle(dev):
+    """The stock encoder on one 48 x 64 conditioning frame: posterior mean and log-variance against the oracle."""
+    vae, orc = make(dev, seed=13)
+    g = torch.Generator().manual_seed(14)
+    img = torch.randn(2, 3, 48, 64, generator=g)
+    mean, logvar = orc.encode_moments(img.unsqueeze(2))
+    m16, l16 = orc.to(torch.bfloat16).encode_moments(img.unsqueeze(2).to(torch.bfloat16))
+    dist = vae.encode(img.unsqueeze(2).to(dev)).latent_dist
+    e, e16 = rel_fro(dist.mean.float().cpu(), mean), rel_fro(m16.float(), mean)
+    el, el16 = rel_fro(dist.logvar.float().cpu(), logvar.clamp(-30, 20)), rel_fro(l16.float().clamp(-30, 20), logvar.clamp(-30, 20))
+    print(f"stock-width VAE encode: mean engine-vs-fp32 {e:.3e} (bf16 oracle {e16:.3e}); logvar {el:.3e} (bf16 oracle {el16:.3e})")
+    assert e <= 1.5 * e16 + 2e-3 and el <= 1.5 * el16 + 2e-3
+    # the posterior sample: diffusers' arithmetic (mean + std * noise in the parameters' dtype, one draw in that dtype)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    s = dist.sample(gen)
+    noise = torch.randn(dist.mean.shape, generator=torch.Generator(device=dev).manual_seed(3), device=dev, dtype=dist.mean.dtype)
+    assert s.dtype == dist.mean.dtype and torch.equal(s, dist.mean + torch.exp(0.5 * dist.logvar) * noise)
+
+
 def test_decode_latents_pipeline_form_and_chunk_cache(dev):
     """``decode_latents`` as the pipeline calls it (``[B, F, C, h, w]`` scaled latents, models/pipeline_bindyouravatar.py
     :461-466) and a property of the causal cache: decoding 5 latent frames equals decoding them in ONE chunk only where the

@@ -27,7 +27,7 @@ if with_vae:
 pipe = BindyouravatarPipeline(model, scheduler=sched, vae=vae)
 kw = dict(height=480, width=720, num_frames=49, num_inference_steps=steps, guidance_scale=guidance, latents=lat,
           prompt_embeds=bf(inp["encoder_hidden_states"]), negative_prompt_embeds=torch.zeros_like(bf(inp["encoder_hidden_states"])),
-          image_latents=img, id_vit_hidden=[[bf(t) for t in l] for l in inp["id_vit_hidden"]],
+          image_latents=img, image_bg_latents=img, id_vit_hidden=[[bf(t) for t in l] for l in inp["id_vit_hidden"]],
           id_cond=[bf(t) for t in inp["id_cond"]], audio_embs=bf(inp["audio_embeds"]), af_matrix=bf(inp["af_matrix"]),
           generator=torch.Generator(device=dev).manual_seed(0), output_type="pt" if with_vae else "latent")
 pipe(**dict(kw, num_inference_steps=2))
