@@ -71,6 +71,7 @@ SIGNATURES = {
     "bya_unpatchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "bya_act_add": [_vp, _vp, _vp, _i64, _i32, _vp],
     "bya_rowgemm512": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp],
+    "bya_router_group_attn": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _f32, _vp],
     "bya_masks_to_routing_logits": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "bya_vae_patches": [_vp, _vp, _vp] + [_i32] * 14 + [_vp],
     "bya_vae_groupnorm_stats": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],

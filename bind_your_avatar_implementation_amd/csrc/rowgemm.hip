@@ -348,6 +348,305 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
+
+// =====================================================================================================================
+// Fused  LayerNorm -> q|k|v projection -> grouped tiny attention  for the router's temporal and multi-ID sub-blocks
+// (reference models/router.py:476-487: norm2/3 -> diffusers Attention(8 heads x 64) over the 13 frames of a location /
+// over the identities of a token).  Unfused, every such sub-block wrote the [R, 1536] q|k|v tensor (108 MB) and read it
+// back in a separate 13-key / 2-key attention launch; here it never leaves the CU:
+//
+//   * rows are GATHERED so that every 16-row MFMA tile holds whole attention groups (one (id, location) with its 13 frames
+//     + 3 unused slots; 8 tokens x 2 ids; 5 tokens x 3 ids + 1 slot).  The row-stationary loader reads each row straight
+//     from global memory, so the gather costs nothing; unused slots read zeros through the buffer descriptor and their
+//     stores fall outside it.
+//   * the work unit is (row block, head): three 64-column chunks of the packed weight, q_h | k_h | v_h, through the same
+//     LDS ring as rowgemm512_kernel.  q and k use the transposed product (W fragment = A operand), which leaves lane
+//     (g, t) with 16 features of token t -- exactly an A/B operand fragment of the 16 x 16 x 32 MFMA (the feature order
+//     inside the dot product does not matter as long as q and k share it), so  S^T = K . Q^T  of a tile is two MFMAs.
+//   * lane (g, t) then holds S^T[keys 4g .. 4g+3, query t]: keys of other groups are masked, the softmax reduces over 4
+//     registers and, with two cross-lane steps, over g; the rounded P^T IS the B operand of the 16 x 16 x 16 MFMA.
+//   * v uses the straight product (X fragment = A operand): lane (g, i) gets V[tokens 4g .. 4g+3, feature i] = the A
+//     operand V^T of that MFMA.  O^T = V^T . P^T lands as lane (g, t) = 16 consecutive features of token t (the W-row
+//     staging permutation of the ring is the same as rowgemm512's), scaled by 1 / l and stored with two 16-byte stores.
+// Six small MFMAs and ~60 VALU instructions per tile and head replace the 144 MB round trip.  q, k, v and P are rounded
+// to bf16 where the unfused path stored them (P: like every flash kernel here).
+struct RowAttnArgs {
+    const bf16_t* X; const bf16_t* W; const float* colsum; const float* cvec; bf16_t* O;
+    int M, ldx, ldo, L, G;
+    long long n_groups, n_inner, outer_stride, seq_stride;
+    float eps, scale_log2;
+};
+
+#if BYA_ROWGEMM_CH == 64 && BYA_ROWGEMM_HB == 2
+constexpr int RA_N = 1536, RA_HEADS = 8;
+constexpr int RA_CONST_BYTES = RA_N * 8 + NW * HB * 32 * 4;      // colsum | cvec | per-wave (mean[16], rstd[16]) per tile
+
+// one chunk's 128 MFMAs of a wave; SWAP = false: acc[h][j] = W_j . X_h^T (lane (g, t): W rows 4g+e of block j, token t),
+// SWAP = true: acc[h][j] = X_h . W_j^T (lane (g, i): tokens 4g+e, W row i of block j)
+template <bool SWAP>
+__device__ __forceinline__ void rowattn_chunk(f32x4 (&acc)[HB][NJ], const bf16x8 (&xf)[HB][16], const uint32_t (&wa)[4]) {
+#pragma unroll
+    for (int h = 0; h < HB; ++h)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wf[AHEAD + 1][NJ];
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) read_kstep(wf[a], wa, a);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int cur = ks % (AHEAD + 1);
+        if (ks + AHEAD < 16) {
+            read_kstep(wf[(ks + AHEAD) % (AHEAD + 1)], wa, ks + AHEAD);
+            lgkm_wait<AHEAD * NJ>(wf[cur]);
+        } else {
+            lgkm_wait<0>(wf[cur]);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int h = 0; h < HB; ++h)
+                acc[h][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[h][ks], wf[cur][j], acc[h][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][j], xf[h][ks], acc[h][j], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(64 * NW, 2) void rowattn512_kernel(RowAttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const long long tiles = (p.n_groups + p.G - 1) / p.G;
+    const int nrb = (int)((tiles + NW * HB - 1) / (NW * HB));
+    const int total = nrb * RA_HEADS;                                   // (row block, head) units, row-block-major
+    const int rid = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int u0 = (int)((long long)total * rid / gridDim.x), u1 = (int)((long long)total * (rid + 1) / gridDim.x);
+    if (u0 >= u1) return;
+
+    float* s_lds = reinterpret_cast<float*>(smem);
+    float* c_lds = s_lds + RA_N;
+    float* st_lds = c_lds + RA_N + wave * (HB * 32);                    // this wave's statistics
+    char* ring = smem + RA_CONST_BYTES;
+    for (int i = tid; i < RA_N; i += 64 * NW) {
+        s_lds[i] = p.colsum[i];
+        c_lds[i] = p.cvec[i];
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.X, 0, (int)(((long long)(p.M - 1) * p.ldx + RK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, RA_N * RK * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.O, 0, (int)(((long long)(p.M - 1) * p.ldo + RK) * 2), 0x00020000);
+
+    // chunk counter qq = 3 * unit + part (0 = q, 1 = k, 2 = v): W rows part * 512 + head * 64 ..
+    auto stage_chunk = [&](int qq, int stg) {
+        char* dst = ring + stg * STAGE_BYTES + wave * SR * 1024;
+        const int u = qq / 3, part = qq - 3 * u;
+        const int col0 = part * 512 + (u & (RA_HEADS - 1)) * 64;
+        const uint32_t l16 = lane_now() << 4;
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            const int R = wave * SR + r, i = R & 15, j = R >> 4;
+            const uint32_t vo = (l16 ^ (uint32_t)(i << 4)) + (uint32_t)(LPC * (i >> 2) + 4 * j + (i & 3)) * (RK * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dst + r * 1024), 16, vo, col0 * (RK * 2), 0, 0);
+        }
+    };
+    const uint32_t ring_base = (uint32_t)(uintptr_t)LDS_PTR(ring);
+    const uint32_t smem_base = (uint32_t)(uintptr_t)LDS_PTR(smem);
+    const uint32_t st_base = (uint32_t)(uintptr_t)LDS_PTR(st_lds);
+
+    bf16x8 xf[HB][16];
+    const int q_end = 3 * u1;
+    stage_chunk(3 * u0, 0);
+    int u = u0, stg = 0;
+    while (u < u1) {
+        const int rb = u >> 3;
+        const int ue = (rb + 1) * RA_HEADS < u1 ? (rb + 1) * RA_HEADS : u1;
+        float mean[HB], rstd[HB];
+        uint32_t rowi[HB];            // the row of this lane's token slot (M = none: loads read zeros, stores are dropped)
+        uint32_t kmask;               // bit e: key slot 4g+e belongs to the group of this lane's query slot t
+        {
+            const uint32_t ln = lane_now(), to = ln & 15u, go = ln >> 4;
+            const uint32_t used = (uint32_t)(p.G * p.L);
+            const uint32_t gq = to < used ? to / (uint32_t)p.L : 100u + to;
+            kmask = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t kk = 4 * go + e;
+                const uint32_t gk = kk < used ? kk / (uint32_t)p.L : 100u + kk;
+                kmask |= (gk == gq ? 1u : 0u) << e;
+            }
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                const long long tile = (long long)rb * (NW * HB) + wave * HB + h;
+                const long long grp = tile * p.G + (to < used ? gq : 0);
+                const bool ok = to < used && grp < p.n_groups;
+                const long long row = (grp / p.n_inner) * p.outer_stride + (grp % p.n_inner) + (long long)(to - gq * p.L) * p.seq_stride;
+                rowi[h] = ok ? (uint32_t)row : (uint32_t)p.M;
+                const uint32_t vo = rowi[h] * (uint32_t)(p.ldx * 2) + go * 16;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    xf[h][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, vo + ks * 64, 0, 0));
+            }
+            bf16x8 ones;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                f32x4 sm = {0.f, 0.f, 0.f, 0.f}, gr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xf[h][ks], sm, 0, 0, 0);
+                    gr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[h][ks], xf[h][ks], gr, 0, 0, 0);
+                }
+                const int e = to & 3;
+                const float d = e == 0 ? gr[0] : e == 1 ? gr[1] : e == 2 ? gr[2] : gr[3];
+                const float sq = __shfl(d, (int)(to + 16 * (to >> 2)));
+                const float mu = sm[0] * (1.0f / RK);
+                const float var = fmaxf(sq * (1.0f / RK) - mu * mu, 0.0f);
+                mean[h] = mu;
+                rstd[h] = rsqrtf(var + p.eps);
+                if (go == 0) {                        // tokens 4g+e of the v chunk's layout read them from here
+                    st_lds[h * 32 + to] = mean[h];
+                    st_lds[h * 32 + 16 + to] = rstd[h];
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < HB; ++h)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(xf[h][ks]));
+
+        for (; u < ue; ++u) {
+            const int head = u & (RA_HEADS - 1);
+            u32x4 qf[HB][2], kf[HB][2];
+            u32x2 pf[HB];
+            float invl[HB];
+            // ---------------------------------------------------------------- q and k: transposed product + LN epilogue
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const uint32_t ln = lane_now(), to = ln & 15u, go = ln >> 4;
+                // only the previous unit's 2 * HB output stores are younger than this chunk's LDS-DMA (see rowgemm512_kernel)
+                if (part == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * HB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (3 * u + part + 1 < q_end) stage_chunk(3 * u + part + 1, stg ^ 1);
+                uint32_t wa[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    wa[m] = ring_base + stg * STAGE_BYTES + to * 1024 + (((go ^ (to & 3)) | ((m ^ (to >> 2)) << 2)) << 4);
+                f32x4 acc[HB][NJ];
+                rowattn_chunk<false>(acc, xf, wa);
+                const uint32_t sc_base = smem_base + (uint32_t)(part * 512 + head * 64 + LPC * go) * 4;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    f32x4 s0, s1, c0, c1;
+                    const uint32_t a = sc_base + (uint32_t)(8 * kb) * 4, ac = a + (uint32_t)RA_N * 4;
+                    lds_read_f<0>(s0, a);
+                    lds_read_f<16>(s1, a);
+                    lds_read_f<0>(c0, ac);
+                    lds_read_f<16>(c1, ac);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0), "+v"(s1), "+v"(c0), "+v"(c1));
+#pragma unroll
+                    for (int h = 0; h < HB; ++h) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float a0 = acc[h][2 * kb + (e >> 2)][e & 3];
+                            const float sv = (e >> 2) ? s1[e & 3] : s0[e & 3];
+                            const float cv = (e >> 2) ? c1[e & 3] : c0[e & 3];
+                            v[e] = fmaf(rstd[h], fmaf(-mean[h], sv, a0), cv);
+                        }
+                        u32x4 w;
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; ++w2) w[w2] = pack2bf(v[2 * w2], v[2 * w2 + 1]);
+                        if (part == 0) qf[h][kb] = w; else kf[h][kb] = w;
+                    }
+                }
+                stg ^= 1;
+            }
+            // ---------------------------------------------------------------- S^T = K . Q^T, masked softmax over the keys
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[h][kb]),
+                                                                 __builtin_bit_cast(bf16x8, qf[h][kb]), st, 0, 0, 0);
+                float sv[4];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sv[e] = (kmask >> e) & 1u ? st[e] : -INFINITY;
+                    mx = fmaxf(mx, sv[e]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float pe[4], l = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pe[e] = __builtin_amdgcn_exp2f((sv[e] - mx) * p.scale_log2);        // masked keys: exp2(-inf) = 0
+                    l += pe[e];
+                }
+                l += __shfl_xor(l, 16);
+                l += __shfl_xor(l, 32);
+                invl[h] = __builtin_amdgcn_rcpf(l);
+                pf[h][0] = pack2bf(pe[0], pe[1]);
+                pf[h][1] = pack2bf(pe[2], pe[3]);
+            }
+            // ---------------------------------------------------------------- v: straight product, O^T = V^T . P^T, store
+            {
+                const uint32_t ln = lane_now(), to = ln & 15u, go = ln >> 4;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (3 * u + 3 < q_end) stage_chunk(3 * u + 3, stg ^ 1);
+                uint32_t wa[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    wa[m] = ring_base + stg * STAGE_BYTES + to * 1024 + (((go ^ (to & 3)) | ((m ^ (to >> 2)) << 2)) << 4);
+                f32x4 acc[HB][NJ];
+                rowattn_chunk<true>(acc, xf, wa);
+                // lane (g, i): tokens 4g+e, output column 16 (i >> 2) + 4 j + (i & 3) of the head (the ring's staging order)
+                const uint32_t col = (uint32_t)(1024 + head * 64) + LPC * (to >> 2) + (to & 3);
+                float sj[NJ], cj[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    sj[j] = s_lds[col + 4 * j];
+                    cj[j] = c_lds[col + 4 * j];
+                }
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                    f32x4 m4, r4;
+                    lds_read_f<0>(m4, st_base + (uint32_t)(h * 32 + 4 * go) * 4);
+                    lds_read_f<64>(r4, st_base + (uint32_t)(h * 32 + 4 * go) * 4);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m4), "+v"(r4));
+                    float ov[16];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        float vv[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vv[e] = fmaf(r4[e], fmaf(-m4[e], sj[j], acc[h][j][e]), cj[j]);
+                        u32x2 vt;
+                        vt[0] = pack2bf(vv[0], vv[1]);
+                        vt[1] = pack2bf(vv[2], vv[3]);
+                        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, vt), __builtin_bit_cast(s16x4, pf[h]), o, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[4 * j + e] = o[e] * invl[h];
+                    }
+                    // lane (g, t): token t, columns head * 64 + 16 g + 4 j + e
+                    const uint32_t off = rowi[h] * (uint32_t)(p.ldo * 2) + ((uint32_t)(head * 64) + LPC * go) * 2;
+                    __builtin_amdgcn_raw_buffer_store_b128(pack8(ov), rsO, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(pack8(ov + 8), rsO, off + 16, 0, 0);
+                }
+                stg ^= 1;
+            }
+        }
+    }
+}
+#endif
+
 }  // namespace
 
 extern "C" int bya_rowgemm512(const void* X, const void* W, const float* colsum, const float* cvec, const void* res,
@@ -376,4 +675,33 @@ extern "C" int bya_rowgemm512(const void* X, const void* W, const float* colsum,
                          : launch_rowgemm<false, true, BYA_ACT_NONE>(a, stream);
     return gelu ? launch_rowgemm<false, false, BYA_ACT_GELU_ERF>(a, stream)
                 : launch_rowgemm<false, false, BYA_ACT_NONE>(a, stream);
+}
+
+extern "C" int bya_router_group_attn(const void* X, const void* Wqkv, const float* colsum, const float* cvec, void* O,
+                                     int32_t M, int32_t ldx, int32_t ldo, int32_t L, int64_t n_outer, int64_t n_inner,
+                                     int64_t outer_stride, int64_t seq_stride, float eps, float scale, hipStream_t stream) {
+#if BYA_ROWGEMM_CH == 64 && BYA_ROWGEMM_HB == 2
+    if (!X || !Wqkv || !colsum || !cvec || !O || M <= 0 || n_outer <= 0 || n_inner <= 0) return BYA_ERR_SHAPE;
+    if (L < 1 || L > 16) return BYA_ERR_UNSUPPORTED;                  // a group must fit one 16-row MFMA tile
+    if (outer_stride < 0 || seq_stride < 0) return BYA_ERR_SHAPE;
+    if ((n_outer - 1) * outer_stride + (n_inner - 1) + (int64_t)(L - 1) * seq_stride >= M) return BYA_ERR_SHAPE;
+    if (ldx < RK || ldo < RK || ldx % 8 || ldo % 8) return BYA_ERR_ALIGN;
+    if (((uintptr_t)X | (uintptr_t)Wqkv | (uintptr_t)O) & 15) return BYA_ERR_ALIGN;
+    if (((long long)M + 1) * ldx * 2 >= (1LL << 31) || ((long long)M + 1) * ldo * 2 >= (1LL << 31)) return BYA_ERR_SHAPE;
+    RowAttnArgs a;
+    a.X = (const bf16_t*)X; a.W = (const bf16_t*)Wqkv; a.colsum = colsum; a.cvec = cvec; a.O = (bf16_t*)O;
+    a.M = M; a.ldx = ldx; a.ldo = ldo; a.L = L; a.G = 16 / L;
+    a.n_groups = n_outer * n_inner; a.n_inner = n_inner; a.outer_stride = outer_stride; a.seq_stride = seq_stride;
+    a.eps = eps; a.scale_log2 = scale * 1.4426950408889634f;
+    const long long tiles = (a.n_groups + a.G - 1) / a.G;
+    const long long total = ((tiles + NW * HB - 1) / (NW * HB)) * RA_HEADS;
+    const int blocks = (int)(total < 256 ? total : 256);
+    const size_t lds = (size_t)RA_CONST_BYTES + 2 * STAGE_BYTES;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (bya_allow_big_lds(reinterpret_cast<const void*>(rowattn512_kernel), 160 * 1024, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
+    BYA_LAUNCH(rowattn512_kernel, dim3(blocks), dim3(64 * NW), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+#else
+    return BYA_ERR_UNSUPPORTED;
+#endif
 }

@@ -717,6 +717,20 @@ class DenoiseEngine:
         self._ln(x, tmp, ln)
         return ops.gemm(tmp, w, out, bias=b, act=act)
 
+    def _r_group_attn(self, x, tmp, qkv, out, ln, pk, name, L, heads, n_outer, n_inner, outer_stride, seq_stride):
+        """out = Attention over groups of L rows (temporal: the T frames of a location; multi-ID: the identities of a token)
+        of LN(x), up to the out-projection.  One fused launch (ops.router_group_attn: the q|k|v tensor stays on chip) when
+        the group fits a 16-row MFMA tile and the folded weights exist, else LN -> q|k|v GEMM -> attn_tiny."""
+        rg = pk.get("rg_" + name)
+        hd = 64
+        if rg is not None and L <= 16 and heads == 8 and os.environ.get("BYA_ROUTER_FUSED_ATTN", "1") != "0":
+            return ops.router_group_attn(x, rg[0], out, L, n_outer, n_inner, outer_stride, seq_stride, eps=rg[1],
+                                         scale=hd ** -0.5)
+        F = x.shape[1]
+        self._r_lnlin(x, tmp, ln, pk, "rg_" + name, *pk[name], qkv)
+        return ops.attn_tiny(qkv, qkv[:, F:], qkv[:, 2 * F:], out, L, heads, n_outer, n_inner, outer_stride, seq_stride,
+                             3 * F, F, hd ** -0.5)
+
     def _r_linres(self, a, pk, key, lin, x):
         """x += Linear(a) on router rows."""
         rg = pk.get(key)
@@ -762,13 +776,10 @@ class DenoiseEngine:
                           o_strides=(per_frame * F, 0, F), scale=hd ** -0.5)
             self._r_linres(ra, pk, "rg_spatial_attn", st.spatial_attn.to_out[0], rs2)
             # 2. temporal: every (sample, id, location) attends over its T frames
-            self._r_lnlin(rs2, rn, st.norm2, pk, "rg_temporal_attn", *pk["temporal_attn"], qkv)
-            ops.attn_tiny(qkv, qkv[:, F:], qkv[:, 2 * F:], ra, T, heads, B * n_id, per_frame, N, per_frame, 3 * F, F,
-                          hd ** -0.5)
+            self._r_group_attn(rs2, rn, qkv, ra, st.norm2, pk, "temporal_attn", T, heads, B * n_id, per_frame, N, per_frame)
             self._r_linres(ra, pk, "rg_temporal_attn", st.temporal_attn.to_out[0], rs2)
             # 3. multi-ID: every (sample, token) attends over the ids
-            self._r_lnlin(rs2, rn, st.norm3, pk, "rg_multi_id_attn", *pk["multi_id_attn"], qkv)
-            ops.attn_tiny(qkv, qkv[:, F:], qkv[:, 2 * F:], ra, n_id, heads, B, N, n_id * N, N, 3 * F, F, hd ** -0.5)
+            self._r_group_attn(rs2, rn, qkv, ra, st.norm3, pk, "multi_id_attn", n_id, heads, B, N, n_id * N, N)
             self._r_linres(ra, pk, "rg_multi_id_attn", st.multi_id_attn.to_out[0], rs2)
             # 4. MLP (GELU erf)
             self._r_lnlin(rs2, rn, st.norm4, pk, "rg_mlp", st.mlp[0].weight, st.mlp[0].bias, rh, act="gelu_erf")
@@ -822,13 +833,9 @@ class DenoiseEngine:
             # ---- location-major: temporal, multi-ID, MLP
             rp.a_to_b(xa, xb, overlap=overlap if bi == 0 else None)
             xb2 = xb.view(RB, F)
-            self._r_lnlin(xb2, rn_b, st.norm2, pk, "rg_temporal_attn", *pk["temporal_attn"], qkv_b)
-            ops.attn_tiny(qkv_b, qkv_b[:, F:], qkv_b[:, 2 * F:], ra_b, T, heads, n_id, rp.nLB, T * rp.nLB, rp.nLB,
-                          3 * F, F, hd ** -0.5)
+            self._r_group_attn(xb2, rn_b, qkv_b, ra_b, st.norm2, pk, "temporal_attn", T, heads, n_id, rp.nLB, T * rp.nLB, rp.nLB)
             self._r_linres(ra_b, pk, "rg_temporal_attn", st.temporal_attn.to_out[0], xb2)
-            self._r_lnlin(xb2, rn_b, st.norm3, pk, "rg_multi_id_attn", *pk["multi_id_attn"], qkv_b)
-            ops.attn_tiny(qkv_b, qkv_b[:, F:], qkv_b[:, 2 * F:], ra_b, n_id, heads, 1, T * rp.nLB, 0, T * rp.nLB, 3 * F, F,
-                          hd ** -0.5)
+            self._r_group_attn(xb2, rn_b, qkv_b, ra_b, st.norm3, pk, "multi_id_attn", n_id, heads, 1, T * rp.nLB, 0, T * rp.nLB)
             self._r_linres(ra_b, pk, "rg_multi_id_attn", st.multi_id_attn.to_out[0], xb2)
             self._r_lnlin(xb2, rn_b, st.norm4, pk, "rg_mlp", st.mlp[0].weight, st.mlp[0].bias, rh_b, act="gelu_erf")
             self._r_linres(rh_b, pk, "rg_mlp", st.mlp[2], xb2)

@@ -548,6 +548,23 @@ def rowgemm512(x, pack, out, res=None, act=None, eps=1e-5, nsplit=0):
     return out
 
 
+def router_group_attn(x, pack, out, L, n_outer, n_inner, outer_stride, seq_stride, eps=1e-5, scale=0.125):
+    """out = softmax(q k^T * scale) v per group of L rows, (q | k | v) = LN(x) @ Wqkv.T + b, 8 heads x 64: the temporal /
+    multi-ID attention of SpatialTemporalAttentionBlock up to its out-projection in ONE launch (reference
+    models/router.py:476-478, :482-484; include/bya.h bya_router_group_attn).  ``pack`` = ``pack_rowgemm512`` of the
+    concatenated to_q | to_k | to_v with the LayerNorm folded in; groups as for ``attn_tiny``."""
+    lib = _hip.load()
+    M, K = x.shape
+    assert K == 512 and pack["ln"] and pack["w"].shape == (1536, 512) and out.shape == (M, 512)
+    assert x.stride(1) == 1 and out.stride(1) == 1 and x.data_ptr() != out.data_ptr()
+    tok = _begin("bya_router_group_attn", 2.0 * M * 1536 * K + 4.0 * M * L * 512)
+    check(lib.bya_router_group_attn(_p(x), _p(pack["w"]), _p(pack["colsum"]), _p(pack["cvec"]), _p(out), M, x.stride(0),
+                                    out.stride(0), int(L), int(n_outer), int(n_inner), int(outer_stride), int(seq_stride),
+                                    float(eps), float(scale), _stream()), "bya_router_group_attn")
+    _end(tok)
+    return out
+
+
 # ---- video VAE (SURVEY.md section 8f row 4; csrc/vae.hip) ----------------------------------------------------------
 def vae_patches(x, cache, out, KT, stride, pad, up, tmode, Ho, Wo, t0, nt):
     """Patch matrix of a causal KT x 3 x 3 convolution over channels-last x [Ts, Hs, Ws, C] -> out [nt * Ho * Wo, Kpad]."""

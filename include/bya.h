@@ -277,6 +277,23 @@ int bya_rowgemm512(const void* X, const void* W, const float* colsum, const floa
                    int32_t nsplit, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused  LayerNorm(512) -> to_q | to_k | to_v (8 heads x 64) -> softmax(q k^T / 8) v  over SMALL groups of rows: the
+ * temporal attention (the 13 frames of one (identity, location)) and the multi-ID attention (the identities of one
+ * token) of SpatialTemporalAttentionBlock.  Replaces models/router.py:476-478 / :482-484 up to (not including) the
+ * to_out projection: diffusers Attention + the default SDPA processor on [B', L, 512] with L = 13 / n_id, i.e. the
+ * sequence  bya_rowgemm512(ln = 1, N = 1536)  ->  bya_attn_tiny  without the [M, 1536] q|k|v tensor in between.
+ * X [M, 512] bf16 rows (stride ldx), O [M, 512] bf16 attention output in the SAME row order (stride ldo; may not alias X).
+ * Wqkv [1536, 512] bf16: rows 0..511 = gamma-folded to_q, 512..1023 = to_k, 1024..1535 = to_v; colsum / cvec [1536] fp32
+ * exactly as for bya_rowgemm512 with ln = 1.  Groups as for bya_attn_tiny: group (o, i), o < n_outer, i < n_inner,
+ * consists of the L rows  o * outer_stride + i + e * seq_stride,  e < L;  1 <= L <= 16 (a group must fit one 16-row
+ * MFMA tile; longer sequences -- 25 latent frames of a 97-frame clip -- take the unfused pair, BYA_ERR_UNSUPPORTED).
+ * scale = 1 / sqrt(64).  q, k, v are rounded to bf16 where the unfused path stored them, P to bf16 before P.V.
+ * --------------------------------------------------------------------------------------------- */
+int bya_router_group_attn(const void* X, const void* Wqkv, const float* colsum, const float* cvec, void* O,
+                          int32_t M, int32_t ldx, int32_t ldo, int32_t L, int64_t n_outer, int64_t n_inner,
+                          int64_t outer_stride, int64_t seq_stride, float eps, float scale, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Classifier-free-guidance combine + scheduler step in one pass over the latents.
  * Replaces models/pipeline_bindyouravatar.py:924-948: noise = u + g*(c - u) in fp32 on the bf16 prediction
  * (n_pred = 2: [uncond, cond], second sample at pred + pred_stride; n_pred = 1: no guidance), then the

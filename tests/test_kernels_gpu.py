@@ -403,6 +403,93 @@ def test_rowgemm512_repeatable_at_router_shape(ops, dev, N, ln, res):
     assert all(torch.equal(first, o) for o in outs)
 
 
+def _group_attn_inputs(dev, M, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, 512, generator=g) * (0.5 + 1.5 * torch.rand(M, 1, generator=g)) + torch.randn(M, 1, generator=g)
+    x = bf(x).to(dev)
+    w, b = rnd((1536, 512), dev, seed + 1, 3.0 * 512 ** -0.5), rnd((1536,), dev, seed + 2, 0.2)      # scores of a few units
+    gam, bet = bf(1 + 0.3 * torch.randn(512, generator=g)).to(dev), bf(0.2 * torch.randn(512, generator=g)).to(dev)
+    return x, w, b, gam, bet
+
+
+def _group_rows(L, n_outer, n_inner, outer_stride, seq_stride, dev):
+    o = torch.arange(n_outer, device=dev)[:, None, None] * outer_stride
+    i = torch.arange(n_inner, device=dev)[None, :, None]
+    e = torch.arange(L, device=dev)[None, None, :] * seq_stride
+    return (o + i + e).reshape(-1, L)                                    # [groups, L] row indices
+
+
+@pytest.mark.parametrize("name,L,n_outer,n_inner,outer_stride,seq_stride,M", [
+    ("temporal 13 frames x 2 ids", 13, 2, 1350, 17550, 1350, 35100),            # one group + 3 unused slots per tile
+    ("multi-ID 2 ids", 2, 1, 17550, 35100, 17550, 35100),                        # 8 groups per tile
+    ("multi-ID 3 ids", 3, 1, 1111, 3333, 1111, 3333),                            # 5 groups + 1 unused slot, ragged tail
+    ("temporal, one rank's location range", 13, 2, 169, 13 * 169, 169, 2 * 13 * 169),
+    ("temporal 16 frames, CFG batch", 16, 4, 77, 16 * 77, 77, 4 * 16 * 77 + 5),  # full tiles, rows beyond the groups untouched
+    ("single rows", 1, 1, 300, 0, 0, 300),                                        # softmax over one key = v itself
+])
+def test_router_group_attn_fused_vs_fp32_and_unfused(ops, dev, name, L, n_outer, n_inner, outer_stride, seq_stride, M):
+    """bya_router_group_attn (LayerNorm -> q|k|v -> attention over groups of L gathered rows, q|k|v never written) against
+    (a) the fp32 chain LayerNorm -> Linear -> softmax(q k^T / 8) v, with the usual bar "no further from it than the
+    reference's own bf16 op chain", and (b) the unfused pair bya_rowgemm512 + bya_attn_tiny on the same packed weights:
+    the same bf16 q, k, v, only P is rounded to bf16 before P.V -- a few 1e-3.  Rows outside every group are not written."""
+    x, w, b, gam, bet = _group_attn_inputs(dev, M, 90 + L)
+    pack = ops.pack_rowgemm512(w, b, gam, bet)
+    out = torch.full((M, 512), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.router_group_attn(x, pack, out, L, n_outer, n_inner, outer_stride, seq_stride)
+    rows = _group_rows(L, n_outer, n_inner, outer_stride, seq_stride, dev)
+    def chain(rounded):
+        r_ = (lambda v: bf(v).float()) if rounded else (lambda v: v)
+        h = r_(F.layer_norm(x.float(), (512,), gam.float(), bet.float(), 1e-5))
+        qkv = r_(h @ w.float().T + b.float())
+        q, k, v = (qkv[:, i * 512:(i + 1) * 512][rows].view(-1, L, 8, 64).transpose(1, 2) for i in range(3))
+        o = r_(sdpa_ref(q, k, v, 0.125))                                  # [groups, 8, L, 64]
+        return o.transpose(1, 2).reshape(-1, L, 512)
+    truth, ref16 = chain(False), chain(True)
+    got = out[rows].float()
+    e, e16 = rel_fro(got, truth), rel_fro(ref16, truth)
+    qkv = torch.empty(M, 1536, dtype=torch.bfloat16, device=dev)
+    ops.rowgemm512(x, pack, qkv)
+    un = torch.full((M, 512), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.attn_tiny(qkv, qkv[:, 512:], qkv[:, 1024:], un, L, 8, n_outer, n_inner, outer_stride, seq_stride, 1536, 512, 0.125)
+    d = rel_fro(got, un[rows].float())
+    print(f"{name}: fused vs fp32 {e:.3e} (reference bf16 chain {e16:.3e}); fused vs unfused pair {d:.3e}")
+    assert torch.isfinite(out.float()).all()
+    assert e <= 1.25 * e16 + 1e-3 and d <= 4e-3
+    touched = torch.zeros(M, dtype=torch.bool, device=dev)
+    touched[rows.reshape(-1)] = True
+    assert bool((out[~touched] == 7.0).all()), "rows outside the groups were written"
+    assert not bool((out[touched] == 7.0).all(dim=1).any()), "a group row was not written"
+
+
+def test_router_group_attn_repeatable_and_masks_exact(ops, dev):
+    """(1) 20 launches at the router's full size on a busy GPU are bit-identical (the chunk ring's counted waits now differ
+    per chunk kind: q after 4 stores, k and v after none).  (2) Groups do not leak into each other: changing the rows of ONE
+    group changes that group's outputs only, bit for bit -- the in-tile mask is exact, not approximately zero."""
+    L, n_outer, n_inner, M = 13, 2, 1350, 35100
+    x, w, b, gam, bet = _group_attn_inputs(dev, M, 77)
+    pack = ops.pack_rowgemm512(w, b, gam, bet)
+    run = lambda xx, LL=L, no=n_outer, ni=n_inner, os_=17550, ss=1350: ops.router_group_attn(
+        xx, pack, torch.zeros(M, 512, dtype=torch.bfloat16, device=dev), LL, no, ni, os_, ss)
+    first = run(x)
+    torch.cuda.synchronize()
+    a, bb = rnd((8192, 8192), dev, 86), rnd((8192, 8192), dev, 87)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            a @ bb
+    outs = [run(x) for _ in range(20)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(first, o) for o in outs)
+    # multi-ID groups share tiles (8 per tile): perturb token 1234 of both identities
+    base = run(x, 2, 1, 17550, 35100, 17550)
+    x2 = x.clone()
+    x2[[1234, 17550 + 1234]] = rnd((2, 512), dev, 5)
+    pert = run(x2, 2, 1, 17550, 35100, 17550)
+    same = (base == pert).all(dim=1)
+    assert bool(same[:1234].all()) and bool(same[1235:17550 + 1234].all()) and bool(same[17550 + 1235:].all())
+    assert not bool(same[1234]) and not bool(same[17550 + 1234])
+
+
 @pytest.mark.parametrize("variant", ["v4", "w8"])
 def test_gemm_big_tile_kernels_whole_suite(dev, variant):
     """Every GEMM parity test again with the 256x256 pipelined kernels FORCED for all shapes (BYA_GEMM_TILE=4: ragged M / N,
