@@ -60,6 +60,9 @@ SIGNATURES = {
     "bya_qknorm_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _f32, _vp],
     "bya_attn_fwd": [_vp, _vp, _vp, _vp, _c.POINTER(AttnDesc), _vp],
     "bya_attn_variant": [_c.POINTER(AttnDesc)],
+    "bya_set_attn_workspace": [_vp, _i64],
+    "bya_attn_workspace_bytes": [_c.POINTER(_i64)],
+    "bya_attn_workspace_status": [_c.POINTER(_i32), _vp],
     "bya_attn_kv_mix": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(AttnMixDesc), _vp],
     "bya_attn_tiny": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
     "bya_router_scores": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp],

@@ -13,6 +13,8 @@ struct AttnArgs {
     float scale_log2;  // scale * log2(e)
     int prescaled;     // scores already in exp2 units (scale folded into k by the producer)
     float score_bound; // > 0: |score| <= bound guaranteed by the caller -> static-offset softmax (no running maximum)
+    float* sk_part;    // stream-K exchange slots / flags of the joint-attention kernel (attn_w4.hip; set by its launcher)
+    unsigned* sk_flags;
 };
 
 constexpr int KV_TILE = 64;

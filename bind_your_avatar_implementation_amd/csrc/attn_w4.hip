@@ -52,6 +52,23 @@ constexpr int QB = 4;                                   // 32-row query blocks p
 constexpr int ROWS_PER_WG = 4 * QB * 32;                // 512
 constexpr int RB = 128, TILE_BYTES = KV_TILE * RB, STAGE_BYTES = 2 * TILE_BYTES, NST = 3;
 
+// Stream-K form (SK = true, bya_launch_attn_w4 when a workspace is registered): 1680 (head, q-tile) items on 256 CUs are
+// 6.56 rounds that cost 7.  Here the grid is 256 persistent workgroups, 32 per XCD, and an XCD owns whole heads as before.
+//   * full rounds: workgroup i of the XCD takes items i, i + 32, i + 64, ... of the XCD's (head, q-tile) list -- at any
+//     moment the 32 workgroups sit on 32 consecutive q-tiles of (mostly) one head and stream the same K/V through the
+//     XCD's L2, exactly like the dispatcher's order of the one-workgroup-per-item launch (contiguous ranges per
+//     workgroup lost that: every CU streamed its own head position, -5 % at 47026 tokens).
+//   * the remaining < 32 items are cut along the keys: their (item, key tile) steps form one list that is divided
+//     evenly over the 32 workgroups.  With the static-bound softmax partial results are simply additive (no running
+//     maximum to reconcile): a piece that does not start at key tile 0 writes its un-normalised O^T accumulators and
+//     row sums to its workgroup's workspace slot and raises the slot's flag; the owner of the item's FIRST piece adds
+//     the other pieces to its registers, normalises and stores.  Writers never wait, so there is no circular wait.
+struct SkItem { int bh, qt, tb, nt, nt_all, role, local; };      // role: 0 whole item, 1 later piece (writer), 2 first piece (merger)
+
+constexpr int SK_SLOT_FLOATS = 4 * QB * 2 * 16 * 64 + 4 * QB * 64;        // O^T register image + per-lane row sums
+constexpr int SK_FLAG_BYTES = 4096;                                       // 1024 words: [slot] flags, [1023] time-outs
+
+template <bool SK>
 __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int D = 64;
@@ -59,33 +76,48 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hf = lane >> 5;
 
-    // block -> (bh, q-tile): blocks with equal (blockIdx % 8) share an XCD; whole (batch, head)s per XCD when the count
-    // divides by 8, else a contiguous eighth of the (head, q-tile) order (same rule as attn.hip)
     const int nbh = p.nb1 * p.nb2 * p.heads;
-    int bh, qt;
-    if (nbh % 8 == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        bh = (j / p.nqt) * 8 + xcd;
-        qt = j % p.nqt;
+    const int nt_all = (p.Skv + KV_TILE - 1) / KV_TILE;
+    // ---- the work of this workgroup
+    const int sk_xcd = blockIdx.x & 7, sk_idx = blockIdx.x >> 3, sk_ncu = gridDim.x >> 3;
+    int sk_round = 0, sk_rfull = 0, sk_s = 0, sk_end = 0;      // SK: full rounds done / to do, tail steps [sk_s, sk_end)
+    long long sk_tail = 0;
+    SkItem it;
+    int sk_base = 0;                                               // nbh % 8 != 0: first item of this XCD in (head, q-tile) order
+    if (SK) {
+        // items of this XCD: whole (batch, head)s when their count divides by 8, else a contiguous eighth of the
+        // (head, q-tile) order -- the same two rules as the one-workgroup-per-item launch below
+        int ipx = (nbh >> 3) * p.nqt;
+        if (nbh % 8 != 0) {
+            const int total = nbh * p.nqt, cq = total >> 3, cr = total & 7;
+            sk_base = sk_xcd < cr ? sk_xcd * (cq + 1) : cr * (cq + 1) + (sk_xcd - cr) * cq;
+            ipx = cq + (sk_xcd < cr ? 1 : 0);
+        }
+        sk_rfull = ipx / sk_ncu;
+        sk_tail = (long long)(ipx - sk_rfull * sk_ncu) * nt_all;   // (item, key tile) steps of the leftover items
+        sk_s = (int)(sk_tail * sk_idx / sk_ncu);
+        sk_end = (int)(sk_tail * (sk_idx + 1) / sk_ncu);
     } else {
-        const int total = nbh * p.nqt, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int cq = total >> 3, cr = total & 7;
-        const int base = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
-        if (j >= cq + (xcd < cr ? 1 : 0)) return;
-        bh = (base + j) / p.nqt;
-        qt = (base + j) % p.nqt;
+        // block -> (bh, q-tile): blocks with equal (blockIdx % 8) share an XCD; whole (batch, head)s per XCD when the count
+        // divides by 8, else a contiguous eighth of the (head, q-tile) order (same rule as attn.hip)
+        if (nbh % 8 == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            it.bh = (j / p.nqt) * 8 + xcd;
+            it.qt = j % p.nqt;
+        } else {
+            const int total = nbh * p.nqt, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            const int cq = total >> 3, cr = total & 7;
+            const int base = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+            if (j >= cq + (xcd < cr ? 1 : 0)) return;
+            it.bh = (base + j) / p.nqt;
+            it.qt = (base + j) % p.nqt;
+        }
+        if (it.bh >= nbh) return;
+        it.tb = 0; it.nt = nt_all; it.nt_all = nt_all; it.role = 0; it.local = 0;
     }
-    if (bh >= nbh) return;
-    const int head = bh % p.heads, b12 = bh / p.heads;
-    const int b1 = b12 / p.nb2, b2 = b12 % p.nb2;
-    const bf16_t* Qp = p.q + b1 * p.q_s1 + b2 * p.q_s2 + (long long)head * D;
-    const bf16_t* Kp = p.k + b1 * p.k_s1 + b2 * p.k_s2 + (long long)head * D;
-    const bf16_t* Vp = p.v + b1 * p.v_s1 + b2 * p.v_s2 + (long long)head * D;
-    bf16_t* Op = p.o + b1 * p.o_s1 + b2 * p.o_s2 + (long long)head * D;
 
     // ---- K/V staging: wave w moves rows [16 w, 16 w + 16) of the K tile and of the V tile, two 1-KiB pieces each
-    const i32x4 rsK = raw_rsrc(Kp, (uint32_t)(((long long)(p.Skv - 1) * p.k_row + D) * 2));
-    const i32x4 rsV = raw_rsrc(Vp, (uint32_t)(((long long)(p.Skv - 1) * p.v_row + D) * 2));
+    i32x4 rsK, rsV;
     uint32_t dvo[4];                                       // per-lane source offsets of pieces K0 K1 V0 V1
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -96,7 +128,6 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
     const uint32_t k_tile_stride = KV_TILE * (uint32_t)p.k_row * 2, v_tile_stride = KV_TILE * (uint32_t)p.v_row * 2;
     const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
     const uint32_t lds0s = __builtin_amdgcn_readfirstlane(lds0) + wave * 16 * RB;       // this wave's first K piece, stage 0
-    const int ntiles = (p.Skv + KV_TILE - 1) / KV_TILE;
     auto stage_tile = [&](int t, int st) {                 // tiles past the end are outside the descriptors: zeros land
         const uint32_t dst = lds0s + st * STAGE_BYTES;
         dma_piece(dst, dvo[0], rsK, t * k_tile_stride);
@@ -104,49 +135,17 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
         dma_piece(dst + TILE_BYTES, dvo[2], rsV, t * v_tile_stride);
         dma_piece(dst + TILE_BYTES + 1024, dvo[3], rsV, t * v_tile_stride);
     };
-    stage_tile(0, 0);
-    stage_tile(1, 1);
-    stage_tile(2, 2);
 
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane (r, hf) holds Q[q0 + 32 b + r][16 s + 8 hf .. + 7]
-    const int q0 = qt * ROWS_PER_WG + wave * (QB * 32);
+    // ---- state.  Q fragments (B operand of S^T = K.Q^T): lane (r, hf) holds Q[q0 + 32 b + r][16 s + 8 hf .. + 7].  S and P
+    // are double-buffered by block parity; the loop's first period finishes "block 3 of tile -1": S[1][1] = -inf
+    // (exp2 -> 0), P[1] = 0 and V = 0 make that a no-op.  (Re-)initialised per item below.
     bf16x8 qf[QB][4];
     bool q_valid[QB];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        int qrow = q0 + b * 32 + r;
-        q_valid[b] = qrow < p.Sq;
-        qrow = q_valid[b] ? qrow : p.Sq - 1;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            qf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Qp + (long long)qrow * p.q_row + s * 16 + hf * 8));
-    }
-
-    // ---- state.  S and P are double-buffered by block parity; the loop's first period finishes "block 3 of tile -1":
-    // S[1][1] = -inf (exp2 -> 0), P[1] = 0 and V = 0 make that a no-op.
     f32x16 oacc[QB][2], sacc[2][2];
     u32x4 pf[2][4];
     u32x2 vh[2][4][2];
     bf16x8 kf[2][4];
     float psum[QB][2];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        psum[b][0] = psum[b][1] = 0.f;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[b][d][i] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { sacc[0][0][i] = 0.f; sacc[0][1][i] = 0.f; sacc[1][0][i] = 0.f; sacc[1][1][i] = -INFINITY; }
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            pf[x][ks] = u32x4{0u, 0u, 0u, 0u};
-            vh[x][ks][0] = u32x2{0u, 0u};
-            vh[x][ks][1] = u32x2{0u, 0u};
-        }
 
     // per-lane LDS offsets inside a stage: K fragment (u, s) at kofs[s] + u * 32 rows; V fragment (d, ks, h) at
     // vofs[d] + (16 ks + 8 h) rows (transposed read: 4 rows x 64 B per half-wave, attn.hip)
@@ -196,71 +195,265 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
         // GENERATED-END
     };
 
-    // The Q loads are hipcc's own: make it wait for them HERE (an empty asm that takes every fragment as an AGPR operand),
-    // or it parks one s_waitcnt vmcnt(N) in front of each fragment's first MFMA inside the loop -- down to vmcnt(0), which
-    // would drain the K/V prefetch every tile.  (That drains tiles 0..2 as well: the prologue's wait below is then free.)
-#pragma unroll
-    for (int b = 0; b < QB; ++b)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) asm volatile("" : "+a"(qf[b][s]));
-    // tile 0 has landed once all but the 8 younger pieces (tiles 1, 2) have; then its K fragments
-    VMC(8);
-    BAR();
-    {
-        uint32_t kaddr[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) kaddr[s] = kofs[s];
-        RK(0, 0); RK(0, 1); RK(0, 2); RK(0, 3); RK(1, 0); RK(1, 1); RK(1, 2); RK(1, 3);
-        LGKM(0);
-    }
-    int st = 0;                                            // ring stage of tile t (= of tile t + 3)
-    for (int t = 0; t < ntiles; ++t) {
-        const int st1 = st == NST - 1 ? 0 : st + 1;
-        uint32_t kaddr[4], vaddr[2];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) kaddr[s] = kofs[s] + st1 * STAGE_BYTES;
-#pragma unroll
-        for (int d = 0; d < 2; ++d) vaddr[d] = vofs[d] + st * STAGE_BYTES;
-        body(IntTagC<'L'>{}, kaddr, vaddr, lds0s + st * STAGE_BYTES, (uint32_t)(t + 3) * k_tile_stride,
-             (uint32_t)(t + 3) * v_tile_stride);
-        st = st1;
-    }
-    {
-        const uint32_t none4[4] = {0u, 0u, 0u, 0u}, none2[2] = {0u, 0u};
-        body(IntTagC<'T'>{}, none4, none2, 0u, 0u, 0u);
-    }
-    // the MFMAs are inline asm: pad their last results before compiler code reads them; drain the (empty) tail prefetches
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    bool first_item = true;
+    for (;;) {
+        if (SK) {
+            int item;
+            if (sk_round < sk_rfull) {
+                item = sk_round * sk_ncu + sk_idx;
+                ++sk_round;
+                it.tb = 0; it.nt = nt_all; it.role = 0; it.local = 0;
+            } else {
+                if (sk_s >= sk_end) break;
+                it.local = sk_s / nt_all;
+                item = sk_rfull * sk_ncu + it.local;
+                it.tb = sk_s - it.local * nt_all;
+                const int left = sk_end - sk_s;
+                it.nt = nt_all - it.tb < left ? nt_all - it.tb : left;
+                it.role = it.tb > 0 ? 1 : (it.nt < nt_all ? 2 : 0);
+                sk_s += it.nt;
+            }
+            it.nt_all = nt_all;
+            if (nbh % 8 == 0) {
+                it.bh = (item / p.nqt) * 8 + sk_xcd;
+                it.qt = item % p.nqt;
+            } else {
+                it.bh = (sk_base + item) / p.nqt;
+                it.qt = (sk_base + item) % p.nqt;
+            }
+            // every wave is done with the previous item's K/V stages before the next item's tiles land in them
+            if (!first_item) asm volatile("s_barrier" ::: "memory");
+            first_item = false;
+        }
+        const int head = it.bh % p.heads, b12 = it.bh / p.heads;
+        const int b1 = b12 / p.nb2, b2 = b12 % p.nb2;
+        const bf16_t* Qp = p.q + b1 * p.q_s1 + b2 * p.q_s2 + (long long)head * D;
+        const bf16_t* Kp = p.k + b1 * p.k_s1 + b2 * p.k_s2 + (long long)head * D + (long long)it.tb * KV_TILE * p.k_row;
+        const bf16_t* Vp = p.v + b1 * p.v_s1 + b2 * p.v_s2 + (long long)head * D + (long long)it.tb * KV_TILE * p.v_row;
+        bf16_t* Op = p.o + b1 * p.o_s1 + b2 * p.o_s2 + (long long)head * D;
+        const int skv_left = p.Skv - it.tb * KV_TILE;             // keys from this piece's first tile to the end of K / V
+        rsK = raw_rsrc(Kp, (uint32_t)(((long long)(skv_left - 1) * p.k_row + D) * 2));
+        rsV = raw_rsrc(Vp, (uint32_t)(((long long)(skv_left - 1) * p.v_row + D) * 2));
+        const int ntiles = it.nt;
+        stage_tile(0, 0);
+        stage_tile(1, 1);
+        stage_tile(2, 2);
 
-    // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (r, hf) holds d = 32 dd + (i & 3) + 8 (i >> 2) + 4 hf
-    const float pad_keys = (float)(ntiles * KV_TILE - p.Skv);        // keys of the last tile that do not exist: P = 1 each
+        const int q0 = it.qt * ROWS_PER_WG + wave * (QB * 32);
 #pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        const float l_half = psum[b][0] + psum[b][1];
-        const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_half), __float_as_uint(l_half), false, false);
-        const float inv = 1.0f / (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1]) - pad_keys);
-        if (q_valid[b]) {
-            bf16_t* orow = Op + (long long)(q0 + b * 32 + r) * p.o_row;
+        for (int b = 0; b < QB; ++b) {
+            int qrow = q0 + b * 32 + r;
+            q_valid[b] = qrow < p.Sq;
+            qrow = q_valid[b] ? qrow : p.Sq - 1;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                qf[b][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Qp + (long long)qrow * p.q_row + s * 16 + hf * 8));
+        }
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            psum[b][0] = psum[b][1] = 0.f;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    u32x2 w;
-                    w[0] = pack2bf(oacc[b][d][gq * 4 + 0] * inv, oacc[b][d][gq * 4 + 1] * inv);
-                    w[1] = pack2bf(oacc[b][d][gq * 4 + 2] * inv, oacc[b][d][gq * 4 + 3] * inv);
-                    *reinterpret_cast<u32x2*>(orow + d * 32 + gq * 8 + hf * 4) = w;
-                }
+                for (int i = 0; i < 16; ++i) oacc[b][d][i] = 0.f;
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sacc[0][0][i] = 0.f; sacc[0][1][i] = 0.f; sacc[1][0][i] = 0.f; sacc[1][1][i] = -INFINITY; }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                pf[x][ks] = u32x4{0u, 0u, 0u, 0u};
+                vh[x][ks][0] = u32x2{0u, 0u};
+                vh[x][ks][1] = u32x2{0u, 0u};
+            }
+
+        // The Q loads are hipcc's own: make it wait for them HERE (an empty asm that takes every fragment as an AGPR operand),
+        // or it parks one s_waitcnt vmcnt(N) in front of each fragment's first MFMA inside the loop -- down to vmcnt(0), which
+        // would drain the K/V prefetch every tile.  (That drains tiles 0..2 as well: the prologue's wait below is then free.)
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) asm volatile("" : "+a"(qf[b][s]));
+        // tile 0 has landed once all but the 8 younger pieces (tiles 1, 2) have; then its K fragments
+        VMC(8);
+        BAR();
+        {
+            uint32_t kaddr[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kaddr[s] = kofs[s];
+            RK(0, 0); RK(0, 1); RK(0, 2); RK(0, 3); RK(1, 0); RK(1, 1); RK(1, 2); RK(1, 3);
+            LGKM(0);
+        }
+        int st = 0;                                            // ring stage of tile t (= of tile t + 3)
+        for (int t = 0; t < ntiles; ++t) {
+            const int st1 = st == NST - 1 ? 0 : st + 1;
+            uint32_t kaddr[4], vaddr[2];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kaddr[s] = kofs[s] + st1 * STAGE_BYTES;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) vaddr[d] = vofs[d] + st * STAGE_BYTES;
+            body(IntTagC<'L'>{}, kaddr, vaddr, lds0s + st * STAGE_BYTES, (uint32_t)(t + 3) * k_tile_stride,
+                 (uint32_t)(t + 3) * v_tile_stride);
+            st = st1;
+        }
+        {
+            const uint32_t none4[4] = {0u, 0u, 0u, 0u}, none2[2] = {0u, 0u};
+            body(IntTagC<'T'>{}, none4, none2, 0u, 0u, 0u);
+        }
+        // the MFMAs are inline asm: pad their last results before compiler code reads them; drain the tail prefetches
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");
+
+        // keys of the LAST tile that do not exist: P = 1 each (only the piece that holds the last tile sees them)
+        const float pad_keys = it.tb + it.nt == it.nt_all ? (float)(it.nt_all * KV_TILE - p.Skv) : 0.f;
+        if (SK && it.role == 1) {
+            // ---- a later piece of a cut item: hand the un-normalised accumulators and row sums to the owner of its first piece
+            const int my_slot = sk_xcd * sk_ncu + sk_idx;
+            float* const slot = p.sk_part + (size_t)my_slot * SK_SLOT_FLOATS;
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        f32x4 w = {oacc[b][d][gq * 4 + 0], oacc[b][d][gq * 4 + 1], oacc[b][d][gq * 4 + 2], oacc[b][d][gq * 4 + 3]};
+                        *reinterpret_cast<f32x4*>(slot + ((size_t)(((wave * QB + b) * 2 + d) * 4 + gq) * 64 + lane) * 4) = w;
+                    }
+                slot[4 * QB * 2 * 16 * 64 + (wave * QB + b) * 64 + lane] = psum[b][0] + psum[b][1] - 0.5f * pad_keys;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (tid == 0) __hip_atomic_store(p.sk_flags + my_slot, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (SK && it.role == 2) {
+            // ---- first piece of a cut item: the following workgroups of this XCD hold the rest of it (each one's FIRST tail piece)
+            const int item_end = (it.local + 1) * nt_all;
+            for (int c = sk_idx + 1; c < sk_ncu; ++c) {
+                if ((int)(sk_tail * c / sk_ncu) >= item_end) break;
+                const int cs = sk_xcd * sk_ncu + c;
+                if (tid == 0) {
+                    int spins = 0;
+                    while (__hip_atomic_load(p.sk_flags + cs, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1 << 22)) {     // ~1 s: never hang the GPU; the event is counted (bya_attn_workspace_status)
+                            __hip_atomic_fetch_add(p.sk_flags + 1023, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const float* const slot = p.sk_part + (size_t)cs * SK_SLOT_FLOATS;
+#pragma unroll
+                for (int b = 0; b < QB; ++b) {
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(slot + ((size_t)(((wave * QB + b) * 2 + d) * 4 + gq) * 64 + lane) * 4);
+                            oacc[b][d][gq * 4 + 0] += w[0]; oacc[b][d][gq * 4 + 1] += w[1];
+                            oacc[b][d][gq * 4 + 2] += w[2]; oacc[b][d][gq * 4 + 3] += w[3];
+                        }
+                    psum[b][0] += slot[4 * QB * 2 * 16 * 64 + (wave * QB + b) * 64 + lane];
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // one block at a time: 128 loads in flight would spill
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");          // every wave has read the slot: the flag goes back to 0
+                if (tid == 0) __hip_atomic_store(p.sk_flags + cs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+
+        // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane (r, hf) holds d = 32 dd + (i & 3) + 8 (i >> 2) + 4 hf
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            const float l_half = psum[b][0] + psum[b][1];
+            const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_half), __float_as_uint(l_half), false, false);
+            const float inv = 1.0f / (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1]) - pad_keys);
+            if (q_valid[b]) {
+                bf16_t* orow = Op + (long long)(q0 + b * 32 + r) * p.o_row;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        u32x2 w;
+                        w[0] = pack2bf(oacc[b][d][gq * 4 + 0] * inv, oacc[b][d][gq * 4 + 1] * inv);
+                        w[1] = pack2bf(oacc[b][d][gq * 4 + 2] * inv, oacc[b][d][gq * 4 + 3] * inv);
+                        *reinterpret_cast<u32x2*>(orow + d * 32 + gq * 8 + hf * 4) = w;
+                    }
+            }
+        }
+        if (!SK) break;
     }
 }
 
 }  // namespace
 
+namespace {
+// stream-K exchange workspace, caller-owned, one per DEVICE (same rules as the GEMM's split-K workspace, gemm.hip)
+constexpr int SK_MAX_DEVICES = 64, SK_GRID = 256, SK_SLOTS = SK_GRID;      // slot = xcd * 32 + index of the left neighbour
+constexpr long long SK_WS_BYTES = SK_FLAG_BYTES + (long long)SK_SLOTS * SK_SLOT_FLOATS * 4;
+std::atomic<void*> g_attn_ws[SK_MAX_DEVICES];
+inline int sk_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < SK_MAX_DEVICES ? dev : -1;
+}
+}  // namespace
+
+extern "C" int bya_set_attn_workspace(void* ws, int64_t bytes) {
+    if (ws && (bytes < (int64_t)SK_WS_BYTES || ((uintptr_t)ws & 255))) return BYA_ERR_SHAPE;
+    const int dev = sk_device();
+    if (dev < 0) return BYA_ERR_UNSUPPORTED;
+    g_attn_ws[dev].store(ws);
+    return BYA_OK;
+}
+
+extern "C" int bya_attn_workspace_bytes(int64_t* bytes) {
+    if (!bytes) return BYA_ERR_SHAPE;
+    *bytes = (int64_t)SK_WS_BYTES;
+    return BYA_OK;
+}
+
+extern "C" int bya_attn_workspace_status(int32_t* timeouts, hipStream_t stream) {
+    if (!timeouts) return BYA_ERR_SHAPE;
+    *timeouts = 0;
+    const int dev = sk_device();
+    char* const ws = dev < 0 ? nullptr : static_cast<char*>(g_attn_ws[dev].load());
+    if (!ws) return BYA_OK;
+    unsigned word = 0;
+    if (hipMemcpyAsync(&word, ws + 1023 * 4, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return BYA_ERR_LAUNCH;
+    if (hipStreamSynchronize(stream) != hipSuccess) return BYA_ERR_LAUNCH;
+    *timeouts = (int32_t)word;
+    return BYA_OK;
+}
+
 int bya_launch_attn_w4(const void* args, hipStream_t s) {
     AttnArgs a = *static_cast<const AttnArgs*>(args);
     a.nqt = (a.Sq + ROWS_PER_WG - 1) / ROWS_PER_WG;
     const int nbh = a.nb1 * a.nb2 * a.heads;
-    dim3 grid((nbh * a.nqt + 7) / 8 * 8);
-    BYA_LAUNCH(attn_joint_w4_kernel, grid, dim3(256), (size_t)NST * STAGE_BYTES, s, a);
+    const int dev = sk_device();
+    char* const ws = dev < 0 ? nullptr : static_cast<char*>(g_attn_ws[dev].load());
+    const char* e = getenv("BYA_ATTN_STREAMK");              // A/B switch, read per call; default on when a workspace exists
+    const long long nt_all = (a.Skv + KV_TILE - 1) / KV_TILE;
+    const long long items = (long long)nbh * a.nqt;
+    // stream-K pays when an XCD's items make at least one whole round of its 32 CUs plus a partial one.  (Measured,
+    // profiles/r4_g_attn_streamk_probe.json: +1.3 % at 48 heads x 17776, +9 % at a 2-rank shard's 24 heads, +2.2 % at
+    // 47026 tokens.  A grid that does not fill ONE round -- 6 heads of an 8-rank shard, 210 items -- LOSES 2 % although a
+    // range is 0.82 items long: in the evenly cut tail the CUs of an XCD sit at different key positions, the 4.5 MB of a
+    // head's K/V no longer stream through the 4 MB L2 in step.)
+    const long long ipx = items / 8, tail_steps = (ipx % (SK_GRID / 8)) * nt_all;     // (per XCD, +- one item when 8 does not divide)
+    const bool sk = ws && !(e && e[0] == '0') && ipx >= SK_GRID / 8 && (items % SK_GRID != 0) && tail_steps >= 16 * (SK_GRID / 8) &&
+                    items * nt_all < (1LL << 31);
+    if (sk) {
+        a.sk_flags = reinterpret_cast<unsigned*>(ws);
+        a.sk_part = reinterpret_cast<float*>(ws + SK_FLAG_BYTES);
+        BYA_LAUNCH(attn_joint_w4_kernel<true>, dim3(SK_GRID), dim3(256), (size_t)NST * STAGE_BYTES, s, a);
+    } else {
+        a.sk_flags = nullptr;
+        a.sk_part = nullptr;
+        dim3 grid((nbh * a.nqt + 7) / 8 * 8);
+        BYA_LAUNCH(attn_joint_w4_kernel<false>, grid, dim3(256), (size_t)NST * STAGE_BYTES, s, a);
+    }
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

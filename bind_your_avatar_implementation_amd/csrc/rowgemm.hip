@@ -356,7 +356,7 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
 // back in a separate 13-key / 2-key attention launch; here it never leaves the CU:
 //
 //   * rows are GATHERED so that every 16-row MFMA tile holds whole attention groups (one (id, location) with its 13 frames
-//     + 3 unused slots; 8 tokens x 2 ids; 5 tokens x 3 ids + 1 slot).  The row-stationary loader reads each row straight
+//     + 3 unused slots; 8 tokens x 2 ids; 4 tokens x 3 ids in 4-slot cells).  The row-stationary loader reads each row straight
 //     from global memory, so the gather costs nothing; unused slots read zeros through the buffer descriptor and their
 //     stores fall outside it.
 //   * the work unit is (row block, head): three 64-column chunks of the packed weight, q_h | k_h | v_h, through the same
@@ -372,7 +372,7 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
 // to bf16 where the unfused path stored them (P: like every flash kernel here).
 struct RowAttnArgs {
     const bf16_t* X; const bf16_t* W; const float* colsum; const float* cvec; bf16_t* O;
-    int M, ldx, ldo, L, G;
+    int M, ldx, ldo, L, P, G;     // group size, slots per group (power of two >= L), groups per 16-row tile
     long long n_groups, n_inner, outer_stride, seq_stride;
     float eps, scale_log2;
 };
@@ -467,21 +467,24 @@ __global__ __launch_bounds__(64 * NW, 2) void rowattn512_kernel(RowAttnArgs p) {
         uint32_t kmask;               // bit e: key slot 4g+e belongs to the group of this lane's query slot t
         {
             const uint32_t ln = lane_now(), to = ln & 15u, go = ln >> 4;
-            const uint32_t used = (uint32_t)(p.G * p.L);
-            const uint32_t gq = to < used ? to / (uint32_t)p.L : 100u + to;
+            // slot s of a tile = member s % P of the tile's group s / P (P = the power of two >= L, G = 16 / P groups): a
+            // group never straddles a 4-slot lane group unless it fills whole ones, so WHERE in a tile a group sits does
+            // not change the order in which the matrix core and the row-sum reduction add its terms (the other slots
+            // contribute exact zeros) -- results do not depend on how the caller's rows are partitioned (a rank's shard
+            // of the router rows vs the whole clip).
+            const uint32_t P = (uint32_t)p.P, gq = to / P, mq = to - gq * P;
             kmask = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint32_t kk = 4 * go + e;
-                const uint32_t gk = kk < used ? kk / (uint32_t)p.L : 100u + kk;
-                kmask |= (gk == gq ? 1u : 0u) << e;
+                const uint32_t kk = 4 * go + e, gk = kk / P, mk = kk - gk * P;
+                kmask |= (gk == gq && mk < (uint32_t)p.L ? 1u : 0u) << e;
             }
 #pragma unroll
             for (int h = 0; h < HB; ++h) {
                 const long long tile = (long long)rb * (NW * HB) + wave * HB + h;
-                const long long grp = tile * p.G + (to < used ? gq : 0);
-                const bool ok = to < used && grp < p.n_groups;
-                const long long row = (grp / p.n_inner) * p.outer_stride + (grp % p.n_inner) + (long long)(to - gq * p.L) * p.seq_stride;
+                const long long grp = tile * p.G + gq;
+                const bool ok = mq < (uint32_t)p.L && grp < p.n_groups;
+                const long long row = (grp / p.n_inner) * p.outer_stride + (grp % p.n_inner) + (long long)mq * p.seq_stride;
                 rowi[h] = ok ? (uint32_t)row : (uint32_t)p.M;
                 const uint32_t vo = rowi[h] * (uint32_t)(p.ldx * 2) + go * 16;
 #pragma unroll
@@ -690,7 +693,9 @@ extern "C" int bya_router_group_attn(const void* X, const void* Wqkv, const floa
     if (((long long)M + 1) * ldx * 2 >= (1LL << 31) || ((long long)M + 1) * ldo * 2 >= (1LL << 31)) return BYA_ERR_SHAPE;
     RowAttnArgs a;
     a.X = (const bf16_t*)X; a.W = (const bf16_t*)Wqkv; a.colsum = colsum; a.cvec = cvec; a.O = (bf16_t*)O;
-    a.M = M; a.ldx = ldx; a.ldo = ldo; a.L = L; a.G = 16 / L;
+    a.M = M; a.ldx = ldx; a.ldo = ldo; a.L = L;
+    a.P = L <= 1 ? 1 : L <= 2 ? 2 : L <= 4 ? 4 : L <= 8 ? 8 : 16;
+    a.G = 16 / a.P;
     a.n_groups = n_outer * n_inner; a.n_inner = n_inner; a.outer_stride = outer_stride; a.seq_stride = seq_stride;
     a.eps = eps; a.scale_log2 = scale * 1.4426950408889634f;
     const long long tiles = (a.n_groups + a.G - 1) / a.G;

@@ -145,6 +145,44 @@ def check_gemm_workspace(device=None):
     if n:
         raise _hip.ByaError(f"{n} split-K tile(s) of bya_gemm_bf16 were finished without all their partial sums (a hand-off "
                             f"between workgroups timed out): results of this run are not to be trusted")
+    if _ATTN_WS:
+        n = attn_workspace_status(device)
+        if n:
+            raise _hip.ByaError(f"{n} stream-K hand-off(s) of the joint attention timed out: results of this run are not to be trusted")
+
+
+_ATTN_WS = {}          # device index -> stream-K exchange workspace of the joint-attention kernel
+
+
+def ensure_attn_workspace(device):
+    """Register the stream-K workspace of the joint-attention kernel (bya_set_attn_workspace) once per DEVICE: 34 MB of
+    zero-filled device memory that lives as long as the process.  With it, a launch whose (head, q-tile) items do not fill
+    whole rounds of 256 CUs runs as 256 persistent workgroups over evenly cut (item, key-tile) ranges; without it, one
+    workgroup per item (the last round partly idle).  Same results up to fp32 summation order at the cut items."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _ATTN_WS.get(idx)
+    if ws is not None:
+        return ws
+    lib = _hip.load()
+    n = ctypes.c_int64(0)
+    check(lib.bya_attn_workspace_bytes(ctypes.byref(n)), "bya_attn_workspace_bytes")
+    with torch.cuda.device(idx):
+        ws = torch.zeros(n.value, dtype=torch.uint8, device=torch.device("cuda", idx))
+        torch.cuda.synchronize(idx)
+        check(lib.bya_set_attn_workspace(ws.data_ptr(), n.value), "bya_set_attn_workspace")
+    _ATTN_WS[idx] = ws
+    return ws
+
+
+def attn_workspace_status(device=None):
+    """Number of stream-K hand-offs of the joint attention that timed out on this device (0 on a healthy run); synchronises."""
+    lib = _hip.load()
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    n = ctypes.c_int32(0)
+    with torch.cuda.device(idx):
+        check(lib.bya_attn_workspace_status(ctypes.byref(n), _stream()), "bya_attn_workspace_status")
+    return n.value
 
 
 def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, gate_batch_stride=0, act=None,
@@ -336,6 +374,8 @@ def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_
     d.score_bound = float(score_bound)
     for t in (q, k, v, out):
         assert t.dtype == torch.bfloat16 and t.is_cuda
+    if prescaled and score_bound > 0 and q.device.index not in _ATTN_WS:
+        ensure_attn_workspace(q.device)
     var = ATTN_VARIANT_NAMES.get(lib.bya_attn_variant(ctypes.byref(d)), "rejected")
     ATTN_VARIANTS[tag, var] = ATTN_VARIANTS.get((tag, var), 0) + 1
     label = "bya_attn_fwd:" + tag

@@ -422,7 +422,7 @@ def _group_rows(L, n_outer, n_inner, outer_stride, seq_stride, dev):
 @pytest.mark.parametrize("name,L,n_outer,n_inner,outer_stride,seq_stride,M", [
     ("temporal 13 frames x 2 ids", 13, 2, 1350, 17550, 1350, 35100),            # one group + 3 unused slots per tile
     ("multi-ID 2 ids", 2, 1, 17550, 35100, 17550, 35100),                        # 8 groups per tile
-    ("multi-ID 3 ids", 3, 1, 1111, 3333, 1111, 3333),                            # 5 groups + 1 unused slot, ragged tail
+    ("multi-ID 3 ids", 3, 1, 1111, 3333, 1111, 3333),                            # 4 groups in 4-slot cells, ragged tail
     ("temporal, one rank's location range", 13, 2, 169, 13 * 169, 169, 2 * 13 * 169),
     ("temporal 16 frames, CFG batch", 16, 4, 77, 16 * 77, 77, 4 * 16 * 77 + 5),  # full tiles, rows beyond the groups untouched
     ("single rows", 1, 1, 300, 0, 0, 300),                                        # softmax over one key = v itself
@@ -488,6 +488,17 @@ def test_router_group_attn_repeatable_and_masks_exact(ops, dev):
     same = (base == pert).all(dim=1)
     assert bool(same[:1234].all()) and bool(same[1235:17550 + 1234].all()) and bool(same[17550 + 1235:].all())
     assert not bool(same[1234]) and not bool(same[17550 + 1234])
+    # (3) where a group sits inside a 16-row tile does not change its result: three identities, the whole token range against
+    # the same tokens presented as two shards that start at different offsets modulo the groups-per-tile count
+    N3 = 1111
+    x3 = x[:3 * N3].contiguous()
+    whole = ops.router_group_attn(x3, pack, torch.zeros(3 * N3, 512, dtype=torch.bfloat16, device=dev), 3, 1, N3, 3 * N3, N3)
+    for lo, hi in ((0, 557), (557, N3)):
+        n = hi - lo
+        shard = torch.cat([x3[i * N3 + lo:i * N3 + hi] for i in range(3)]).contiguous()
+        part = ops.router_group_attn(shard, pack, torch.zeros(3 * n, 512, dtype=torch.bfloat16, device=dev), 3, 1, n, 3 * n, n)
+        want = torch.cat([whole[i * N3 + lo:i * N3 + hi] for i in range(3)])
+        assert torch.equal(part, want), (lo, hi)
 
 
 @pytest.mark.parametrize("variant", ["v4", "w8"])
@@ -896,6 +907,63 @@ def test_attn_static_bound_softmax(ops, dev, S, kernel, monkeypatch):
     out2 = torch.empty_like(out)
     ops.self_attention(q.view(1, S, H * D), k.view(1, S, H * D), v, out2, heads=H, prescaled=True, score_bound=500.0)
     check(out2.view(1, S, H, D).transpose(1, 2), ref, tol=ATTN_TOL, what="unusable bound -> running-max kernel")
+
+
+@pytest.mark.parametrize("S,H", [(17776, 48), (5000, 16), (33976, 8), (17776, 12)])
+def test_attn_stream_k_matches_one_workgroup_per_item(ops, dev, S, H, monkeypatch):
+    """The joint attention as 256 persistent workgroups over evenly cut (item, key-tile) ranges (stream-K; workspace
+    registered by ops.attention) against the one-workgroup-per-item launch of the same kernel (BYA_ATTN_STREAMK=0).
+    Partials of the static-bound softmax are additive, so an item cut between two workgroups differs from the uncut form by
+    fp32 summation order only: (1) every row outside the <= 248 cut items is bit-identical, (2) cut rows agree to bf16
+    rounding, (3) both agree with the fp32 softmax on sampled heads, (4) 8 launches on a busy GPU are bit-identical (the
+    suffix -> prefix hand-off: flag, fences, flag reset) and no hand-off timed out.  Shapes: BASELINE configs[1] (1680 items,
+    6.56 rounds), a small one (160 items < 256 CUs: stream-K declines, both launches are the same kernel), the 97-frame
+    sequence with 8 heads (536 items, ragged last q-tile and ragged last key tile) and a 4-rank shard's 12 heads (8 does not
+    divide the head count: an XCD owns a contiguous eighth of the (head, q-tile) order, 52 or 53 items)."""
+    D = 64
+    g = torch.Generator().manual_seed(S + H)
+    def unit_rows(scale_rows):
+        x = torch.randn(1, S, H, D, generator=g)
+        return x / x.norm(dim=-1, keepdim=True) * 8.0 * scale_rows
+    k_scale = D ** -0.5 * 1.4426950408889634
+    q = bf(unit_rows(torch.rand(1, S, H, 1, generator=g) * 0.9 + 0.1)).to(dev).view(1, S, H * D)
+    k = bf(unit_rows(torch.ones(1, S, H, 1)) * k_scale).to(dev).view(1, S, H * D)
+    v = rnd((1, S, H * D), dev, 3)
+    bound = 1.02 * 64 * k_scale
+    def run():
+        out = torch.empty(1, S, H * D, dtype=torch.bfloat16, device=dev)
+        ops.self_attention(q, k, v, out, heads=H, prescaled=True, score_bound=bound, tag="joint")
+        return out
+    sk = run()
+    monkeypatch.setenv("BYA_ATTN_STREAMK", "0")
+    plain = run()
+    monkeypatch.delenv("BYA_ATTN_STREAMK")
+    diff_rows = (sk != plain).view(S, H, D).any(dim=-1)                       # [S, H]
+    n_diff_tiles = int(diff_rows.view(-1, H).float().sum().item())
+    # a cut item is one (head, 512-row q-tile): at most 248 of them
+    cut_items = set()
+    idx = diff_rows.nonzero()
+    for row, head in idx[:: max(1, len(idx) // 20000)].tolist():
+        cut_items.add((head, row // 512))
+    print(f"S={S} H={H}: {n_diff_tiles} (row, head) pairs differ, in {len(cut_items)} (head, q-tile) items (sampled)")
+    assert len(cut_items) <= 248
+    e = rel_fro(sk.float(), plain.float())
+    assert e < 2e-3, e
+    for head in (0, H - 1):
+        sl = slice(head * D, (head + 1) * D)
+        rows = torch.arange(0, S, 7, device=dev)[:700]
+        s_ = (q[0, rows, sl].float() @ k[0, :, sl].float().T) * math.log(2.0)
+        ref = torch.softmax(s_, dim=-1) @ v[0, :, sl].float()
+        check(sk[0, rows, sl], ref, tol=ATTN_TOL, what=f"stream-K attention head {head}")
+    a, bb = rnd((8192, 8192), dev, 86), rnd((8192, 8192), dev, 87)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(4):
+            a @ bb
+    outs = [run() for _ in range(8)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(sk, o) for o in outs)
+    assert ops.attn_workspace_status() == 0
 
 
 @pytest.mark.parametrize("mode,D,H,n_id,grp,Sq", [("audio", 64, 48, 2, 13, 150), ("audio", 64, 6, 3, 4, 333),
