@@ -84,6 +84,8 @@ SIGNATURES = {
     "bya_vae_upsample_pad": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "bya_allgather_kv": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "bya_alltoall_router": [_vp, _vp, _vp, _vp, _i32, _vp, _vp],
+    "bya_p2p_push": [_vp, _i32, _i64, _vp, _i32, _i32, _vp, _vp],
+    "bya_p2p_wait": [_vp, _i32, _vp],
     "bya_cfg_scheduler_step": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _c.POINTER(SchedCoef), _vp],
 }
 

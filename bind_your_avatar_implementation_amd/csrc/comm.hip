@@ -93,3 +93,97 @@ extern "C" int bya_alltoall_router(const void* send, void* recv, const int64_t* 
     const ncclResult_t e = r.group_end();
     return (good && e == ncclSuccess) ? BYA_OK : BYA_ERR_LAUNCH;
 }
+
+// =====================================================================================================================
+// P2P exchange engine: the exchanges of the sharded step as PUSH kernels over peer-mapped device memory.
+//
+// xGMI is point to point and a GPU can store straight into a peer's HBM: an exchange does not need a collective library,
+// it needs (1) the peers' receive buffers mapped into this process (hipIpc handles, traded once at set-up by the host
+// module), (2) a kernel that copies this rank's outgoing pieces to their final addresses on the peers, and (3) a flag per
+// (channel, source rank) on every peer.  What that buys over RCCL's grouped send/recv on this stack:
+//   * a whole exchange -- any scatter/gather list, e.g. the 3 x W column blocks of the packed q|k|v projection to their
+//     places in W peers' q / k / v buffers -- is ONE ordinary kernel launch (~5 us) instead of one collective per tensor
+//     (~20 us each, 360 of them per rank-step in round 3);
+//   * ordinary kernels can be captured: the sharded step replays as a hipGraph (an RCCL collective under capture never
+//     returns on this stack, profiles/r3_rccl_graph_probe.txt).  Sequence numbers therefore live in DEVICE memory (the
+//     push kernel bumps its channel's send counter, the wait kernel its expect counter): a replay advances them itself.
+// Ordering: every workgroup of the push kernel makes its stores visible system-wide (__threadfence_system) before it
+// counts itself done; the last one publishes the new sequence number to every peer's flag (system-scope release store).
+// The receiver runs bya_p2p_wait -- one wave spinning on its LOCAL flags -- as the next kernel on its stream; the
+// consumers are later kernels on that stream, whose dispatch acquires at system scope (stale L2 lines of the receive
+// buffer are dropped).  A peer may only overwrite a receive buffer after this rank has consumed it: the step's own data
+// dependencies guarantee that for every exchange the engine issues (multi-GPU section, lists them).
+// Bounded waits (~1 s) count a time-out in the channel's control words instead of hanging the GPU.
+namespace {
+
+constexpr int P2P_CHUNK = 64 * 1024;                 // bytes per workgroup iteration
+constexpr int P2P_CTRL_WORDS = 64;                   // per channel: [0..31] flags by source rank, [32] sent, [33] expected,
+constexpr int P2P_SENT = 32, P2P_EXPECT = 33, P2P_DONE = 34, P2P_TIMEOUTS = 35;      // [34] workgroups done, [35] time-outs
+
+__global__ __launch_bounds__(256) void p2p_push_kernel(const bya_p2p_copy* __restrict__ copies, int n_copies, long long total_chunks,
+                                                        unsigned* const* __restrict__ peer_ctrl, int world, int rank,
+                                                        unsigned* __restrict__ ctrl) {
+    const int tid = threadIdx.x;
+    for (long long c = blockIdx.x; c < total_chunks; c += gridDim.x) {
+        int i = 0;
+        while (i + 1 < n_copies && copies[i + 1].chunk0 <= c) ++i;               // <= 100 entries: a linear scan
+        const long long off = (c - copies[i].chunk0) * (long long)P2P_CHUNK;
+        const long long left = copies[i].bytes - off;
+        const int n = (int)(left < P2P_CHUNK ? left : P2P_CHUNK);
+        const char* src = static_cast<const char*>(copies[i].src) + off;
+        char* dst = static_cast<char*>(copies[i].dst) + off;
+        for (int b = tid * 16; b < n; b += 256 * 16)
+            *reinterpret_cast<u32x4*>(dst + b) = *reinterpret_cast<const u32x4*>(src + b);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned done = __hip_atomic_fetch_add(ctrl + P2P_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(ctrl + P2P_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned seq = ctrl[P2P_SENT] + 1u;
+            ctrl[P2P_SENT] = seq;
+            __threadfence_system();
+            for (int p = 0; p < world; ++p)
+                __hip_atomic_store(peer_ctrl[p] + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void p2p_wait_kernel(unsigned* __restrict__ ctrl, int world) {
+    const int lane = threadIdx.x;
+    const unsigned expect = ctrl[P2P_EXPECT] + 1u;
+    if (lane < world) {
+        int spins = 0;
+        // (sequence numbers wrap after 4 G exchanges: compare by signed distance)
+        while ((int)(__hip_atomic_load(ctrl + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - expect) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1 << 21)) {
+                __hip_atomic_fetch_add(ctrl + P2P_TIMEOUTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    if (lane == 0) ctrl[P2P_EXPECT] = expect;
+}
+
+}  // namespace
+
+extern "C" int bya_p2p_push(const bya_p2p_copy* copies_dev, int32_t n_copies, int64_t total_chunks, void* const* peer_ctrl_dev,
+                            int32_t world, int32_t rank, void* ctrl, hipStream_t stream) {
+    if (!copies_dev || !peer_ctrl_dev || !ctrl || n_copies <= 0 || total_chunks <= 0) return BYA_ERR_SHAPE;
+    if (world <= 0 || world > 32 || rank < 0 || rank >= world) return BYA_ERR_SHAPE;
+    if (((uintptr_t)copies_dev | (uintptr_t)peer_ctrl_dev) & 7 || ((uintptr_t)ctrl & 3)) return BYA_ERR_ALIGN;
+    // enough workgroups to keep every xGMI link and the local HBM busy, few enough to leave the CUs to the compute stream
+    const long long want = total_chunks < 64 ? total_chunks : 64;
+    BYA_LAUNCH(p2p_push_kernel, dim3((unsigned)want), dim3(256), 0, stream, copies_dev, n_copies, (long long)total_chunks,
+               reinterpret_cast<unsigned* const*>(peer_ctrl_dev), world, rank, static_cast<unsigned*>(ctrl));
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+extern "C" int bya_p2p_wait(void* ctrl, int32_t world, hipStream_t stream) {
+    if (!ctrl || world <= 0 || world > 32) return BYA_ERR_SHAPE;
+    BYA_LAUNCH(p2p_wait_kernel, dim3(1), dim3(64), 0, stream, static_cast<unsigned*>(ctrl), world);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}

@@ -214,14 +214,14 @@ class DenoiseEngine:
         key = ("seq", rank, world, S, Tt, id(group))
         sh = self._parts.get(key)
         if sh is None:
-            sh = self._parts[key] = SeqShard(rank, world, S, Tt, group)
+            sh = self._parts[key] = SeqShard(rank, world, S, Tt, group, getattr(self.m, "_seq_p2p", None) if group is not None else None)
         return sh
 
     def _router_partition(self, sh, pairs, per_frame):
         key = ("router", sh.rank, sh.world, pairs, per_frame, id(sh.group))
         rp = self._parts.get(key)
         if rp is None:
-            rp = self._parts[key] = RouterPartition(sh.rank, sh.world, pairs, per_frame, sh.group)
+            rp = self._parts[key] = RouterPartition(sh.rank, sh.world, pairs, per_frame, sh.group, sh.p2p)
         return rp
 
     def _buf(self, name, *shape):
@@ -547,9 +547,22 @@ class DenoiseEngine:
                         # v needs no norm: its exchange runs on the RCCL stream underneath q's norm + RoPE, q's exchange
                         # underneath k's; only k's is exposed (every exchange is enqueued on the communicator's stream,
                         # the compute stream waits by event right before the attention launch)
-                        pending = [sh.rows_to_heads(qkvb[2 * W:], vh, async_op=True)]
                         qk_kw = dict(heads=H // W, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
                                      k_scale=self.k_scale)
+                        if sh.p2p is not None:
+                            # P2P transport: q/k-norm + RoPE on the local rows of both, then ONE push kernel carries all
+                            # 3 x W column blocks to their places in the peers' q / k / v buffers
+                            ops.qknorm_rope(qkvb[:W], qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
+                                            at.norm_k.bias, cos, sin, **qk_kw)
+                            hx, qh_, kh_, vh_ = sh.rows_to_heads_qkv(qkvb)
+                            hx.wait()
+                            ops.self_attention(qh_[None], kh_[None], vh_[None], oh[None], heads=H // W, tag="joint", prescaled=True,
+                                               score_bound=self.score_bound[i])
+                            sh.heads_to_rows(oh, xn[0])
+                            self._dit_linear("out", i, xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x,
+                                             gate0=mo[:, 5 * D:], gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
+                            continue
+                        pending = [sh.rows_to_heads(qkvb[2 * W:], vh, async_op=True)]
                         ops.qknorm_rope(qkvb[:W], None, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias,
                                         cos, sin, **qk_kw)
                         pending.append(sh.rows_to_heads(qkvb[:W], qh, async_op=True))
@@ -816,7 +829,7 @@ class DenoiseEngine:
         xa.copy_(rs_full.view(pairs, per_frame, F)[rp.pa0:rp.pa1])
         RA, RB = rp.nPA * per_frame, pairs * rp.nLB
         rn_a, qkv_a, ra_a = buf("rp_rn_a", RA, F), buf("rp_qkv_a", RA, 3 * F), buf("rp_ra_a", RA, F)
-        xb = buf("rp_xb", pairs, rp.nLB, F)
+        xb = rp.recv_buf("rp_xb", (pairs, rp.nLB, F), xa)          # (P2P transport: the peers store into it directly)
         rn_b, qkv_b, ra_b, rh_b = buf("rp_rn_b", RB, F), buf("rp_qkv_b", RB, 3 * F), buf("rp_ra_b", RB, F), buf("rp_rh_b", RB, F)
         hd = 64
         heads = F // hd

@@ -20,6 +20,12 @@ e.g. S = 47026 of BASELINE configs[3]).  Everything on the path is row-local EXC
 
 Weights are replicated (17 GB of 288 GB).  There is no reduce: no GEMM is K-split across ranks.
 
+Transport (``BYA_SP_TRANSPORT``, default ``p2p`` on GPUs): every exchange below is ONE push kernel that stores straight
+into the peers' receive buffers (``p2p.py`` / ``bya_p2p_push``, hipIpc-mapped, xGMI on a node) plus a one-wave wait kernel
+on the receiver -- capturable in a hipGraph, ~5 us of launch instead of ~20 us per collective, and the packed q|k|v
+projection travels as ONE exchange instead of three.  ``torch`` keeps the round-3 path: ``torch.distributed`` collectives
+(RCCL on the ``nccl`` backend, host-staged on ``gloo``).
+
 ``FORCE_COLLECTIVES`` (``BYA_SP_FORCE_COLLECTIVES=1``): take the collective code path even with ONE rank -- a 1-rank
 RCCL communicator on one GPU then executes every exchange (symbol resolution, dtypes, split lists, async handles on the
 communicator's stream) although nothing moves between devices; used by ``tests/test_rccl_gpu.py``.
@@ -47,6 +53,7 @@ class SeqShard:
     S: int
     Tt: int
     group: object = None
+    p2p: object = None               # p2p.P2PGroup: exchanges as push kernels over peer-mapped buffers (None: torch.distributed)
 
     def __post_init__(self):
         # contiguous row ranges whose sizes differ by at most one (17776 = 8 * 2222 divides exactly; the 720x1280
@@ -80,6 +87,18 @@ class SeqShard:
             t = (torch.zeros if zero else torch.empty)(*shape, dtype=like.dtype, device=like.device)
             self._bufs[key] = t
         return t
+
+    def recv_buf(self, name, shape, like):
+        """A buffer an exchange RECEIVES into: with the P2P transport it must be a symmetric buffer the peers have mapped."""
+        if self.p2p is not None:
+            return self.p2p.symmetric(f"{name}:{tuple(shape)}", tuple(shape), like.dtype)
+        return self.buf(name, shape, like)
+
+    def _push(self, key, pieces, side=False):
+        """One P2P exchange: pieces = [(contiguous local tensor, peer, receive-buffer name, element offset there)]."""
+        ch = self.p2p.channel((key,) + tuple(p[0].data_ptr() for p in pieces), pieces)
+        _count("p2p_exchange")
+        return ch.push(side=side)
 
     def staged(self, t):
         """gloo has no device collectives (single-GPU functional tests, CPU tests): stage through host memory."""
@@ -119,6 +138,17 @@ class SeqShard:
         """[S_loc, F] per rank -> [S, F], rank-major == global row order."""
         if not self.active:
             return local
+        if self.p2p is not None:
+            F = local[0].numel()
+            name = f"gr:{(self.S, F)}"
+            full = self.p2p.symmetric(name, (self.S, F), local.dtype)
+            src = local.contiguous().view(self.S_loc, F)
+            self._push("gr", [(src, j, name, self.r0 * F) for j in range(self.world)]).wait()
+            full = full.view(self.S, *local.shape[1:])
+            if out is None:
+                return full.clone()
+            out.copy_(full)
+            return out
         if self.even:
             if out is None:
                 out = torch.empty(self.S, *local.shape[1:], dtype=local.dtype, device=local.device)
@@ -141,6 +171,16 @@ class SeqShard:
         F = local_video.shape[-1]
         flat = local_video.reshape(-1, self.N_loc, F)
         C = flat.shape[0]
+        if self.p2p is not None:
+            # every rank stores its video rows of every leading index straight into place on every peer
+            name = f"gv:{(C, self.N, F)}"
+            full = self.p2p.symmetric(name, (C, self.N, F), flat.dtype)
+            src = flat.contiguous()
+            self._push("gv", [(src[c], j, name, (c * self.N + self.v0) * F) for j in range(self.world) for c in range(C)]).wait()
+            if out is None:
+                return full.view(*lead, self.N, F).clone()
+            out.view(C, self.N, F).copy_(full)
+            return out
         pad = self.buf("gv_pad", (C, self.S_loc, F), flat, zero=True) if scratch is None else scratch
         pad[:, self.Tt_loc:] = flat
         if self.Tt_loc and scratch is not None:
@@ -178,12 +218,33 @@ class SeqShard:
             h = self._a2a(out.view(-1), blocks.reshape(-1), [n * Dl for n in self.sizes], [S_loc * Dl] * W, async_op=async_op)
         return h if async_op else out
 
+    def rows_to_heads_qkv(self, blocks, side=False):
+        """P2P transport: the packed projection's column blocks [3 * world, S_loc, Dl] (block t * world + j = tensor t of
+        q | k | v, heads of rank j) -> ONE exchange into the symmetric [3, S, Dl] buffer of every destination.  Returns
+        (channel handle, q_heads, k_heads, v_heads); call ``handle.wait()`` before the attention."""
+        W3, S_loc, Dl = blocks.shape
+        W = self.world
+        name = f"qkvh:{(3, self.S, Dl)}"
+        full = self.p2p.symmetric(name, (3, self.S, Dl), blocks.dtype)
+        pieces = [(blocks[t * W + j], j, name, (t * self.S + self.r0) * Dl) for j in range(W) for t in range(3)]
+        return self._push("qkvh", pieces, side=side), full[0], full[1], full[2]
+
     def heads_to_rows(self, o_heads, out=None):
         """o_heads [S, Dl] (all rows, this rank's heads) -> [S_loc, world*Dl] (this rank's rows, all heads).  The
         exchange is enqueued on the communicator's own stream like every other one here (``async_op``) and the compute
         stream waits for it by event: nothing of the step is independent of the attention output, so there is nothing to
         put underneath it -- what the side stream buys here is that the exchange never queues behind unrelated compute."""
         S, Dl = o_heads.shape
+        if self.p2p is not None:
+            name = f"h2r:{Dl}"
+            recv = self.p2p.symmetric(name, (self.world, self.S_loc, Dl), o_heads.dtype)       # (rank j: [W, sizes[j], Dl])
+            pieces = [(o_heads[self.starts[j]:self.starts[j] + self.sizes[j]], j, name, self.rank * self.sizes[j] * Dl)
+                      for j in range(self.world)]
+            self._push("h2r", pieces).wait()
+            if out is None:
+                out = torch.empty(self.S_loc, self.world * Dl, dtype=o_heads.dtype, device=o_heads.device)
+            out.view(self.S_loc, self.world, Dl).copy_(recv.permute(1, 0, 2))
+            return out
         recv = self.buf("h2r_recv", (self.world, self.S_loc, Dl), o_heads)
         if self.even:
             h = self._a2a(recv.view(-1), o_heads.reshape(-1), async_op=True)
@@ -232,8 +293,9 @@ class RouterPartition:
     all-gather.  A -> B packs on the send side (W slice copies) and receives in place; B -> A sends in place and
     unpacks on the receive side."""
 
-    def __init__(self, rank, world, pairs, per_frame, group=None):
+    def __init__(self, rank, world, pairs, per_frame, group=None, p2p=None):
         self.rank, self.world, self.pairs, self.per_frame, self.group = rank, world, pairs, per_frame, group
+        self.p2p = p2p
         self.PA = _splits(pairs, world)
         self.LB = _splits(per_frame, world)
         self.pa0, self.pa1 = self.PA[rank]
@@ -248,6 +310,19 @@ class RouterPartition:
             t = (torch.zeros if zero else torch.empty)(*shape, dtype=like.dtype, device=like.device)
             self._bufs[key] = t
         return t
+
+    def recv_buf(self, name, shape, like):
+        if self.p2p is not None:
+            return self.p2p.symmetric(f"{name}:{(self.pairs, self.per_frame)}:{tuple(shape)}", tuple(shape), like.dtype)
+        return self.buf(name, shape, like)
+
+    def _push(self, key, pieces, side=False):
+        ch = self.p2p.channel((key, self.pairs, self.per_frame) + tuple(p[0].data_ptr() for p in pieces), pieces)
+        _count("p2p_exchange")
+        return ch.push(side=side)
+
+    def _name(self, base, shape):
+        return f"{base}:{(self.pairs, self.per_frame)}:{tuple(shape)}"
 
     def _a2a(self, out, inp, out_splits, in_splits):
         """Uneven all-to-all on the communicator's own stream; returns the handle whose ``wait()`` makes the compute stream
@@ -270,6 +345,19 @@ class RouterPartition:
         for (a, b), n in zip(self.LB, in_splits):                  # pack per destination: W slice copies, no temporaries
             send[off:off + n].view(self.nPA, b - a, F).copy_(xa[:, a:b])
             off += n
+        if self.p2p is not None:
+            # my pairs of destination j's locations go to rows [pa0, pa1) of j's xb [pairs, nLB_j, F]
+            xb = self.recv_buf("rp_xb", (self.pairs, self.nLB, F), xa)
+            name = self._name("rp_xb", (self.pairs, self.nLB, F))
+            pieces, off = [], 0
+            for j, ((a, b), n) in enumerate(zip(self.LB, in_splits)):
+                pieces.append((send[off:off + n], j, name, self.pa0 * (b - a) * F))     # (peer j's copy has ITS shape)
+                off += n
+            h = self._push("a2b", pieces, side=overlap is not None)
+            if overlap is not None:
+                overlap()
+            h.wait()
+            return xb
         if xb is None:
             xb = torch.empty(self.pairs, self.nLB, F, dtype=xa.dtype, device=xa.device)
         out_splits = [(b - a) * self.nLB * F for a, b in self.PA]
@@ -287,10 +375,18 @@ class RouterPartition:
             xa = torch.empty(self.nPA, self.per_frame, F, dtype=xb.dtype, device=xb.device)
         in_splits = [(b - a) * self.nLB * F for a, b in self.PA]
         out_splits = [self.nPA * (b - a) * F for a, b in self.LB]
-        recv = self.buf("b2a_recv", (sum(out_splits),), xb)
-        h = self._a2a(recv, xb.reshape(-1), out_splits, in_splits)
-        if h is not None:
-            h.wait()
+        if self.p2p is not None:
+            # destination j receives, source after source, [nPA_j, nLB_source, F]: mine starts after the lower ranks' locations
+            recv = self.recv_buf("b2a_recv", (sum(out_splits),), xb)
+            name = self._name("b2a_recv", (sum(out_splits),))
+            before = self.LB[self.rank][0]                          # locations owned by lower ranks
+            pieces = [(xb[a:b], j, name, (b - a) * before * F) for j, (a, b) in enumerate(self.PA)]
+            self._push("b2a", pieces).wait()
+        else:
+            recv = self.buf("b2a_recv", (sum(out_splits),), xb)
+            h = self._a2a(recv, xb.reshape(-1), out_splits, in_splits)
+            if h is not None:
+                h.wait()
         off = 0
         for a, b in self.LB:
             n = self.nPA * (b - a) * F
@@ -304,6 +400,16 @@ class RouterPartition:
         nmax = max(b - a for a, b in self.LB)
         pad = self.buf("gb_pad", (lead, nmax, C), yb, zero=True)
         pad[:, :self.nLB] = yb
+        if self.p2p is not None:
+            full = self.recv_buf("gb_full", (self.world * lead, nmax, C), yb)
+            name = self._name("gb_full", (self.world * lead, nmax, C))
+            self._push("gb", [(pad, j, name, self.rank * lead * nmax * C) for j in range(self.world)]).wait()
+            full = full.view(self.world, lead, nmax, C)
+            if out is None:
+                out = torch.empty(lead, self.per_frame, C, dtype=yb.dtype, device=yb.device)
+            for j, (a, b) in enumerate(self.LB):
+                out[:, a:b] = full[j, :, :b - a]
+            return out
         full = self.buf("gb_full", (self.world * lead, nmax, C), yb)
         if pad.is_cuda and dist.get_backend(self.group) == "gloo":
             host = torch.empty(full.shape, dtype=full.dtype)
@@ -320,11 +426,21 @@ class RouterPartition:
         return out
 
 
-def shard_sequence(model, group=None):
-    """Switch ``model`` (BindyouravatarTransformer3DModel) to sequence-parallel execution over ``group``."""
+def shard_sequence(model, group=None, transport=None):
+    """Switch ``model`` (BindyouravatarTransformer3DModel) to sequence-parallel execution over ``group``.
+    ``transport``: "p2p" (default on GPUs; BYA_SP_TRANSPORT) = push kernels over peer-mapped buffers, "torch" =
+    torch.distributed collectives.  COLLECTIVE: every rank of the group calls it at the same point."""
     model._seq_group = group if group is not None else dist.group.WORLD
     model._seq_world = dist.get_world_size(model._seq_group)
     model._seq_rank = dist.get_rank(model._seq_group)
+    transport = transport or os.environ.get("BYA_SP_TRANSPORT") or ("p2p" if torch.cuda.is_available() else "torch")
+    if transport not in ("p2p", "torch"):
+        raise ValueError(f"unknown transport {transport!r}")
+    model._seq_p2p = None
+    if transport == "p2p":
+        from .p2p import P2PGroup
+        dev = next(model.parameters()).device
+        model._seq_p2p = P2PGroup(model._seq_group, dev)
     model.invalidate_engine()
     return model
 

@@ -451,13 +451,16 @@ class BindyouravatarTransformer3DModel(nn.Module):
         return (out, None, None, None, None)
 
     def _graph_capturable(self):
-        """Only the unsharded step is replayed from a hipGraph.  Capturing the sharded step needs RCCL collectives inside a
-        stream capture, and on this stack (PyTorch 2.10-ROCm 7.0, RCCL of ROCm 7.2) even a lone ``all_to_all_single`` under
-        ``torch.cuda.graph`` never returns (tools/rccl_graph_probe.py, profiles/r3_rccl_graph_probe.txt): the sharded
-        step stays eager, its exchanges stream-ordered on the communicator's stream.  BYA_GRAPH_SHARDED=1 lifts the guard for
-        a stack where the probe passes."""
+        """The unsharded step, and the sharded step on the P2P transport (its exchanges are ordinary kernels with device-
+        resident sequence numbers: bya_p2p_push / bya_p2p_wait), replay from a hipGraph.  With the ``torch`` transport the
+        sharded step stays eager: capturing it needs RCCL collectives inside a stream capture, and on this stack (PyTorch
+        2.10-ROCm 7.0, RCCL of ROCm 7.2) even a lone ``all_to_all_single`` under ``torch.cuda.graph`` never returns
+        (tools/rccl_graph_probe.py, profiles/r3_rccl_graph_probe.txt); BYA_GRAPH_SHARDED=1 lifts that guard for a stack where
+        the probe passes."""
         group = getattr(self, "_seq_group", None)
         if getattr(self, "_seq_world", 1) == 1 and group is None:
+            return True
+        if getattr(self, "_seq_p2p", None) is not None:
             return True
         if os.environ.get("BYA_GRAPH_SHARDED") != "1":
             return False

@@ -400,6 +400,33 @@ int bya_allgather_kv(const void* k_local, const void* v_local, void* k_full, voi
 int bya_alltoall_router(const void* send, void* recv, const int64_t* send_counts, const int64_t* recv_counts,
                         int32_t world, void* comm, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * P2P exchange engine (csrc/comm.hip): the exchanges of the sharded step as ordinary kernels that store
+ * straight into the peers' HBM over xGMI -- one launch per exchange whatever its scatter/gather list, capturable in a
+ * hipGraph (RCCL collectives are neither).  No reference counterpart (the reference has no inference parallelism).
+ * Set-up is the host's (bind_your_avatar_implementation_amd/p2p.py): every rank allocates its receive buffers and one
+ * control block of 64 uint32 words per channel (zero-filled), trades hipIpc handles once, and builds per channel, in DEVICE
+ * memory, (a) the copy table: `src` local, `dst` an address inside a peer's (or its own) receive buffer mapped into this
+ * process, `bytes` % 16 == 0, `chunk0` = number of 64 KiB chunks of the entries before it; (b) `peer_ctrl[p]` = the
+ * channel's control block ON PEER p (mapped), p < world, own rank included.
+ * bya_p2p_push: copy every table entry, then publish the channel's next sequence number to word `rank` of every peer's
+ * control block.  bya_p2p_wait (receiver, same channel, once per push of the peers): returns to the stream when all
+ * `world` source ranks have published the receiver's next expected number; kernels enqueued behind it see the data.
+ * Sequence numbers live in the control block (words 32 / 33): a hipGraph replay advances them by itself.  Word 35 counts
+ * waits that gave up after ~1 s (0 on a healthy run).  The caller guarantees that a receive buffer is not pushed into
+ * again before its owner has consumed it (the step's data dependencies do).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct bya_p2p_copy {
+    const void* src;
+    void* dst;
+    int64_t bytes;
+    int64_t chunk0;
+} bya_p2p_copy;
+
+int bya_p2p_push(const bya_p2p_copy* copies_dev, int32_t n_copies, int64_t total_chunks, void* const* peer_ctrl_dev,
+                 int32_t world, int32_t rank, void* ctrl, hipStream_t stream);
+int bya_p2p_wait(void* ctrl, int32_t world, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""The P2P exchange engine (bya_p2p_push / bya_p2p_wait + p2p.py) with several processes sharing the ONE test GPU: peer
+buffers are mapped through hipIpc exactly as they are across the GPUs of a node (xGMI is then the path the stores take;
+here it is the local HBM).  Checks the protocol, not link speed: scatter/gather lists, uneven pieces, an empty piece,
+sequence numbers over many exchanges on a reused buffer, the side-stream form, and replay inside a hipGraph."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, ret, mode):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bind_your_avatar_implementation_amd.p2p import P2PGroup
+        g = P2PGroup(dist.group.WORLD, dev)
+        # an uneven all-to-all with TWO pieces per destination (like q|k|v blocks): rank r sends to rank j
+        #   piece A: (r + 1) * 1000 + 8 * j elements, piece B: 4096 elements, values encode (iteration, r, j, piece)
+        nA = lambda r, j: ((r + 1) * 1000 + 8 * j) // 8 * 8
+        nB = 4096
+        recvA = g.symmetric("recvA", (sum(nA(r, rank) for r in range(world)),), torch.bfloat16, zero=True)
+        recvB = g.symmetric("recvB", (world, nB), torch.bfloat16, zero=True)
+        sendA = [torch.zeros(nA(rank, j), dtype=torch.bfloat16, device=dev) for j in range(world)]
+        sendB = torch.zeros(world, nB, dtype=torch.bfloat16, device=dev)
+        empty = torch.zeros(0, dtype=torch.bfloat16, device=dev)
+        pieces = []
+        for j in range(world):
+            offA = sum(nA(r, j) for r in range(rank))
+            pieces += [(sendA[j], j, "recvA", offA), (sendB[j], j, "recvB", rank * nB), (empty, j, "recvB", 0)]
+        ch = g.channel("a2a", pieces)
+
+        def fill(it):
+            for j in range(world):
+                sendA[j].fill_(float((it % 50) + rank * 0.5 + j * 0.125))
+                sendB[j].fill_(float(-(it % 50) - rank * 0.5 - j * 0.125))
+
+        def expect(it):
+            a = torch.cat([torch.full((nA(r, rank),), float((it % 50) + r * 0.5 + rank * 0.125)) for r in range(world)])
+            b = torch.stack([torch.full((nB,), float(-(it % 50) - r * 0.5 - rank * 0.125)) for r in range(world)])
+            return a.to(torch.bfloat16), b.to(torch.bfloat16)
+
+        ok = True
+        if mode in ("plain", "side"):
+            for it in range(40):
+                fill(it)
+                if mode == "side":
+                    ch.push(side=True)
+                    junk = torch.randn(512, 512, device=dev) @ torch.randn(512, 512, device=dev)     # independent work underneath
+                    ch.wait()
+                else:
+                    ch.exchange()
+                a, b = expect(it)
+                got_a, got_b = recvA.clone(), recvB.clone()          # consumer kernels, stream-ordered behind the wait
+                # the NEXT push may only overwrite recvA/B on the peers after they consumed this one: a second channel
+                # (consumed -> ready) carries that dependency here, like the attention output exchange does in the step
+                g.channel("ack", [(empty, j, "recvB", 0) for j in range(world)]).exchange()
+                ok &= bool(torch.equal(got_a.cpu(), a)) and bool(torch.equal(got_b.cpu(), b))
+        else:                                                         # the exchange inside a replayed hipGraph
+            fill(0)
+            ack = g.channel("ack", [(empty, j, "recvB", 0) for j in range(world)])
+            got_a, got_b = torch.empty_like(recvA), torch.empty_like(recvB)
+            ch.exchange()
+            ack.exchange()
+            torch.cuda.synchronize()
+            dist.barrier()
+            graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                with torch.cuda.graph(graph, stream=s):
+                    ch.push(side=(mode == "graph_side"))
+                    ch.wait()
+                    got_a.copy_(recvA)
+                    got_b.copy_(recvB)
+                    ack.exchange()
+            torch.cuda.current_stream().wait_stream(s)
+            for it in range(1, 25):
+                fill(it)
+                graph.replay()
+                torch.cuda.synchronize()
+                a, b = expect(it)
+                ok &= bool(torch.equal(got_a.cpu(), a)) and bool(torch.equal(got_b.cpu(), b))
+        ret[rank] = (ok, g.timeouts(), g.pushes)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "plain"), (4, "side"), (8, "plain"), (2, "graph"), (4, "graph_side")])
+def test_p2p_exchange_between_processes_on_one_gpu(dev, world, mode):
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, 32100 + os.getpid() % 500 + world * 7 + len(mode), ret, mode), nprocs=world, join=True)
+    print(dict(ret))
+    for r in range(world):
+        ok, timeouts, pushes = ret[r]
+        assert ok and timeouts == 0 and pushes > 0, (r, ret[r])

@@ -20,6 +20,7 @@ def _engine_worker(rank, port, ret, mode):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["BYA_SP_TRANSPORT"] = "torch"             # this file covers the torch.distributed / RCCL transport
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
