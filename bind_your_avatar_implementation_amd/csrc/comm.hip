@@ -132,8 +132,16 @@ __global__ __launch_bounds__(256) void p2p_push_kernel(const bya_p2p_copy* __res
         const int n = (int)(left < P2P_CHUNK ? left : P2P_CHUNK);
         const char* src = static_cast<const char*>(copies[i].src) + off;
         char* dst = static_cast<char*>(copies[i].dst) + off;
-        for (int b = tid * 16; b < n; b += 256 * 16)
-            *reinterpret_cast<u32x4*>(dst + b) = *reinterpret_cast<const u32x4*>(src + b);
+        if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+            const int n16 = n & ~15;
+            for (int b = tid * 16; b < n16; b += 256 * 16)
+                *reinterpret_cast<u32x4*>(dst + b) = *reinterpret_cast<const u32x4*>(src + b);
+            for (int b = n16 + tid * 2; b < n; b += 256 * 2)            // (a piece ends on a bf16 element, not on 16 bytes)
+                *reinterpret_cast<uint16_t*>(dst + b) = *reinterpret_cast<const uint16_t*>(src + b);
+        } else {                                                        // small odd-sized pieces (the router's logits)
+            for (int b = tid * 2; b < n; b += 256 * 2)
+                *reinterpret_cast<uint16_t*>(dst + b) = *reinterpret_cast<const uint16_t*>(src + b);
+        }
     }
     __threadfence_system();
     __syncthreads();

@@ -147,8 +147,8 @@ class P2PGroup:
             if dst_t.dtype != src.dtype or offset < 0 or offset + src.numel() > dst_t.numel():
                 raise ValueError(f"P2P piece does not fit buffer {name!r} on rank {peer}")
             dst = dst_t.data_ptr() + offset * src.element_size()
-            if (src.data_ptr() | dst | nbytes) & 15:
-                raise ValueError("P2P pieces must be 16-byte aligned in address and size")
+            if (src.data_ptr() | dst | nbytes) & 1:
+                raise ValueError("P2P pieces must be 2-byte aligned in address and size")
             rows.append((src.data_ptr(), dst, nbytes, chunk0))
             chunk0 += (nbytes + CHUNK - 1) // CHUNK
         if not rows:                                     # nothing to send: still takes part in the flag protocol

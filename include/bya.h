@@ -407,7 +407,7 @@ int bya_alltoall_router(const void* send, void* recv, const int64_t* send_counts
  * Set-up is the host's (bind_your_avatar_implementation_amd/p2p.py): every rank allocates its receive buffers and one
  * control block of 64 uint32 words per channel (zero-filled), trades hipIpc handles once, and builds per channel, in DEVICE
  * memory, (a) the copy table: `src` local, `dst` an address inside a peer's (or its own) receive buffer mapped into this
- * process, `bytes` % 16 == 0, `chunk0` = number of 64 KiB chunks of the entries before it; (b) `peer_ctrl[p]` = the
+ * process, `bytes` % 2 == 0 (16-byte aligned pieces take the fast path), `chunk0` = number of 64 KiB chunks of the entries before it; (b) `peer_ctrl[p]` = the
  * channel's control block ON PEER p (mapped), p < world, own rank included.
  * bya_p2p_push: copy every table entry, then publish the channel's next sequence number to word `rank` of every peer's
  * control block.  bya_p2p_wait (receiver, same channel, once per push of the peers): returns to the stream when all
