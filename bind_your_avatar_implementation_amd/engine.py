@@ -824,9 +824,12 @@ class DenoiseEngine:
         rs_loc = buf("r_s_loc", 1, n_id, N_loc, F)
         ops.router_scores(qr[0], kr[0].contiguous(), r.norm.weight, r.norm.bias, self.r_pos[sh.v0:sh.v1], rs_loc[0],
                           n_id, N_loc, eps=r.norm.eps)
-        rs_full = sh.gather_video_rows(rs_loc, out=buf("r_s_full", 1, n_id, N, F))     # token ranges -> everyone (36 MB, once)
-        xa = buf("rp_xa", rp.nPA, per_frame, F)
-        xa.copy_(rs_full.view(pairs, per_frame, F)[rp.pa0:rp.pa1])
+        if rp.p2p is not None:
+            xa = rp.tokens_to_a(rs_loc[0], sh.v0, T)                                   # token ranges -> the owners of their pairs
+        else:
+            rs_full = sh.gather_video_rows(rs_loc, out=buf("r_s_full", 1, n_id, N, F))     # token ranges -> everyone (36 MB, once)
+            xa = buf("rp_xa", rp.nPA, per_frame, F)
+            xa.copy_(rs_full.view(pairs, per_frame, F)[rp.pa0:rp.pa1])
         RA, RB = rp.nPA * per_frame, pairs * rp.nLB
         rn_a, qkv_a, ra_a = buf("rp_rn_a", RA, F), buf("rp_qkv_a", RA, 3 * F), buf("rp_ra_a", RA, F)
         xb = rp.recv_buf("rp_xb", (pairs, rp.nLB, F), xa)          # (P2P transport: the peers store into it directly)

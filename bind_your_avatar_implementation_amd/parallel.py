@@ -335,6 +335,29 @@ class RouterPartition:
         _count("all_to_all_async")
         return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
 
+    def tokens_to_a(self, rs_loc, v0, T):
+        """P2P transport: this rank's token rows of the router features, rs_loc [n_id, N_loc, F] (global video tokens
+        v0 .. v0 + N_loc), go straight to the owners of their (id, frame) pairs: xa [nPA, per_frame, F] on every rank is filled
+        by ONE exchange in which each element crosses one link once (the round-3 form all-gathered all 36 MB onto every
+        rank and let it pick its pairs).  -> xa"""
+        n_id, N_loc, F = rs_loc.shape
+        pf = self.per_frame
+        xa = self.recv_buf("rp_xa", (self.nPA, pf, F), rs_loc)
+        name = self._name("rp_xa", (self.nPA, pf, F))
+        src = rs_loc.contiguous()
+        pieces = []
+        for i in range(n_id):
+            v = v0
+            while v < v0 + N_loc:
+                f = v // pf
+                end = min(v0 + N_loc, (f + 1) * pf)
+                pair = i * T + f
+                owner = next(j for j, (a, b) in enumerate(self.PA) if a <= pair < b)
+                pieces.append((src[i, v - v0:end - v0], owner, name, ((pair - self.PA[owner][0]) * pf + (v - f * pf)) * F))
+                v = end
+        self._push("t2a", pieces).wait()
+        return xa
+
     def a_to_b(self, xa, xb=None, overlap=None):
         """xa [nPA, per_frame, F] -> xb [pairs, nLB, F].  ``overlap``: a callable that enqueues independent work on the
         compute stream; it runs while the exchange is in flight on the communicator's stream."""

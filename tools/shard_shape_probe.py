@@ -88,10 +88,8 @@ def main():
     rows.append(dict(kernel="adaln layernorm", shape=f"{S_loc}x{D}", us=t * 1e6, gbps=2 * x.numel() * 2 / t / 1e9, per_step=2 * L + L + L // 2))
     qq, kk = rnd(1, S_loc, D), rnd(1, S_loc, D)
     cos, sin, w64 = torch.randn(S_loc, 64, device=dev), torch.randn(S_loc, 64, device=dev), rnd(64)
-    # (the sharded step norms q and k in two launches so that q's exchange runs under k's norm)
-    t = timeit(lambda: (ops.qknorm_rope(qq, None, w64, w64, w64, w64, cos, sin, heads=H, text_rows=0),
-                        ops.qknorm_rope(None, kk, w64, w64, w64, w64, cos, sin, heads=H, text_rows=0)))
-    rows.append(dict(kernel="qknorm_rope (q, then k)", shape=f"{S_loc}x{D} x2", us=t * 1e6, gbps=4 * qq.numel() * 2 / t / 1e9, per_step=L))
+    t = timeit(lambda: ops.qknorm_rope(qq, kk, w64, w64, w64, w64, cos, sin, heads=H, text_rows=0))
+    rows.append(dict(kernel="qknorm_rope (q and k)", shape=f"{S_loc}x{D} x2", us=t * 1e6, gbps=4 * qq.numel() * 2 / t / 1e9, per_step=L))
     # the two cross-attentions with the masked combine in their epilogue (bya_attn_kv_mix): audio = one launch per (partial)
     # frame of this rank's rows, perceiver = one launch
     segs = -(-N_loc // PER_FRAME) + 1
@@ -126,10 +124,17 @@ def main():
         o3, o1 = torch.empty(R, 1536, dtype=torch.bfloat16, device=dev), torch.empty(R, 512, dtype=torch.bfloat16, device=dev)
         pk3 = ops.pack_rowgemm512(rnd(1536, 512) * 0.04, rnd(1536), rnd(512), rnd(512))
         pk1 = ops.pack_rowgemm512(rnd(512, 512) * 0.04, rnd(512))
-        n3, n1 = (1, 1) if name == "frame-major" else (2, 3)          # launches per ST block in that partition
-        t = timeit(lambda: ops.rowgemm512(xr, pk3, o3))
-        rows.append(dict(kernel=f"rowgemm LN+qkv ({name})", shape=f"{R}x1536x512", us=t * 1e6, tflops=2.0 * R * 1536 * 512 / t / 1e12,
-                         per_step=n3 * 4 * (L // 2)))
+        n3, n1 = (1, 1) if name == "frame-major" else (0, 3)          # launches per ST block in that partition
+        if n3:
+            t = timeit(lambda: ops.rowgemm512(xr, pk3, o3))
+            rows.append(dict(kernel=f"rowgemm LN+qkv ({name})", shape=f"{R}x1536x512", us=t * 1e6, tflops=2.0 * R * 1536 * 512 / t / 1e12,
+                             per_step=n3 * 4 * (L // 2)))
+        else:
+            # round 4: LayerNorm -> q|k|v -> temporal / multi-ID attention in ONE launch each (bya_router_group_attn)
+            t = timeit(lambda: ops.router_group_attn(xr, pk3, o1, T, NID, nLB, T * nLB, nLB))
+            rows.append(dict(kernel="fused LN+qkv+temporal attention", shape=f"{R} rows", us=t * 1e6, per_step=4 * (L // 2)))
+            t = timeit(lambda: ops.router_group_attn(xr, pk3, o1, NID, 1, T * nLB, 0, T * nLB))
+            rows.append(dict(kernel="fused LN+qkv+multi-id attention", shape=f"{R} rows", us=t * 1e6, per_step=4 * (L // 2)))
         t = timeit(lambda: ops.rowgemm512(xr, pk1, o1, res=o1))
         rows.append(dict(kernel=f"rowgemm out+res ({name})", shape=f"{R}x512x512", us=t * 1e6, tflops=2.0 * R * 512 * 512 / t / 1e12,
                          per_step=(n1 + (1 if name != "frame-major" else 0)) * 4 * (L // 2)))
@@ -141,33 +146,39 @@ def main():
                                      v_strides=(PER_FRAME * 3 * F, 0, 3 * F), o_strides=(PER_FRAME * F, 0, F), scale=0.125))
     rows.append(dict(kernel="router spatial attention", shape=f"{nPA} pairs x 8 heads x {PER_FRAME}^2", us=t * 1e6,
                      tflops=4.0 * nPA * 8 * PER_FRAME ** 2 * 64 / t / 1e12, per_step=4 * (L // 2)))
-    qkvb = rnd(RB, 1536)
-    rb = torch.empty(RB, 512, dtype=torch.bfloat16, device=dev)
-    t = timeit(lambda: ops.attn_tiny(qkvb, qkvb[:, F:], qkvb[:, 2 * F:], rb, T, 8, NID, nLB, T * nLB, nLB, 3 * F, F, 0.125))
-    rows.append(dict(kernel="router temporal attention", shape=f"{RB} rows", us=t * 1e6, per_step=4 * (L // 2)))
-    t = timeit(lambda: ops.attn_tiny(qkvb, qkvb[:, F:], qkvb[:, 2 * F:], rb, NID, 8, 1, T * nLB, 0, T * nLB, 3 * F, F, 0.125))
-    rows.append(dict(kernel="router multi-id attention", shape=f"{RB} rows", us=t * 1e6, per_step=4 * (L // 2)))
-
     xl = rnd(NID, T * nLB, 512)
     lg = torch.empty(T * nLB, NID, dtype=torch.bfloat16, device=dev)
     hw, hb = rnd(1, 512), rnd(1)
     t = timeit(lambda: ops.router_head(xl, hw, hb, lg, NID, T * nLB))
     rows.append(dict(kernel="router head", shape=f"{T * nLB} tokens", us=t * 1e6, per_step=L // 2))
     compute_ms = sum(r["us"] * r["per_step"] for r in rows) / 1e3
-    # exchanges (bytes RECEIVED per rank and step; every element crosses one link once, W - 1 links busy in parallel)
+    # ---- exchanges on the P2P transport (round 4): ONE push kernel + one wait kernel per exchange.  Their fixed cost is
+    # measured here (a 1-rank group: the push stores into this GPU's own buffer, so the time is launch + flag protocol,
+    # not link time); the bytes are priced at the xGMI link rate, W - 1 links busy in parallel, every element crosses one
+    # link once.  Per step: joint attention 2 per layer (packed q|k|v in, o out); router per routing layer 1 (tokens ->
+    # pair owners) + 4 (frame-major -> location-major) + 3 (back) + 1 (logits) = 9; 1 output gather.
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29833")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    from bind_your_avatar_implementation_amd.p2p import P2PGroup
+    grp = P2PGroup(dist.group.WORLD, dev)
+    rb_ = grp.symmetric("probe", (3 * W, 64), torch.bfloat16)
+    srcs = [rnd(64) for _ in range(3 * W)]
+    ch = grp.channel("probe", [(srcs[i], 0, "probe", i * 64) for i in range(3 * W)])
+    t_x = timeit(lambda: ch.exchange(), iters=50)
+    exchanges = 2 * L + 9 * (L // 2) + 1
     a2a_attn = 4 * L * S_loc * D * 2 * (W - 1) / W                       # q, k, v in and o out, head-parallel
-    a2a_router = 7 * (L // 2) * pairs * PER_FRAME * 512 * 2 / W * (W - 1) / W + (L // 2) * NID * N * 512 * 2 * (W - 1) / W
+    a2a_router = (7 * pairs * PER_FRAME * 512 * 2 / W + NID * N_loc * 512 * 2) * (L // 2) * (W - 1) / W
     comm_ms = (a2a_attn + a2a_router) / ((W - 1) * LINK_GBPS * 1e9) * 1e3
-    launches = 4 * L + 9 * (L // 2)
-    comm_latency_ms = launches * 0.02                                    # ~20 us per collective launch + sync
-    # what the side-stream issue order hides: v's exchange under q's norm, q's under k's norm (2 of the 4 exchanges of a
-    # layer), the router's first repartition under the perceiver attention (1 of 9 per routing layer)
-    hidden = (2 * L + (L // 2)) / launches
-    res = {"world": W, "rows": rows, "projected_ms_per_step": {
+    comm_latency_ms = exchanges * t_x * 1e3
+    res = {"world": W, "rows": rows, "exchange": {"per_step": exchanges, "push_plus_wait_us_measured_on_one_gpu": round(t_x * 1e6, 2),
+                                                  "rccl_collectives_per_step": 0},
+           "projected_ms_per_step": {
         "compute_per_rank": round(compute_ms, 2), "exchange_bytes_over_links": round(comm_ms, 2),
-        "exchange_launch_latency(20us each)": round(comm_latency_ms, 2),
-        "total_if_nothing_overlaps": round(compute_ms + comm_ms + comm_latency_ms, 2),
-        "total_with_the_issued_overlaps": round(compute_ms + (comm_ms + comm_latency_ms) * (1 - hidden), 2)},
+        "exchange_fixed_cost(push+wait kernels)": round(comm_latency_ms, 2),
+        "total_if_nothing_overlaps": round(compute_ms + comm_ms + comm_latency_ms, 2)},
         "note": "per-rank kernels timed on ONE MI355X at the shapes of a W-rank sequence-parallel step; every kernel of the step is "
                 "listed except the replicated step-invariant conditioning (face extractor, audio projector, their K/V: ~7 ms on "
                 "every rank unless cached by precompute_conditioning) and the six small-M linears (0.6 ms)"}
