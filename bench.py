@@ -310,7 +310,7 @@ def main():
                 attn_roof = {"kernel": f"joint {tokens}-token self-attention, softmax variant(s): " + ", ".join(jv),
                              "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                              "frac": ach / PEAK_BF16_TFLOPS,
-                             "traffic": pmc_traffic(world, *(("attn_joint_w4_kernel",) if any("w4" in v for v in jv) else ()),
+                             "traffic": pmc_traffic(world, *(("attn_joint_w4_kernel<true>", "attn_joint_w4_kernel<false>", "attn_joint_w4_kernel") if any("w4" in v for v in jv) else ()),
                                                     "attn_fwd_kernel_d64_bounded2", "attn_fwd_kernel_d64_bounded", "attn_fwd_kernel_d64_prescaled"),
                              "avg_launch_ms": avg * 1e3, "launches": len(attn),
                              "ms_per_step": sum(attn) / args.steps * 1e3}

@@ -198,7 +198,17 @@ class DenoiseEngine:
                     # row-stationary K = 512 GEMMs: LayerNorm folded into the q|k|v / MLP weights (ops.pack_rowgemm512)
                     for name, ln in (("spatial_attn", st.norm1), ("temporal_attn", st.norm2), ("multi_id_attn", st.norm3)):
                         a = getattr(st, name)
-                        packed["rg_" + name] = (ops.pack_rowgemm512(*packed[name], ln.weight, ln.bias), ln.eps,
+                        w, b = packed[name]
+                        if name == "spatial_attn":
+                            # softmax scale * log2(e) folded into to_k (weights and bias, in fp32 before the one bf16 rounding
+                            # of the packed weight): the 1350 x 1350 attention's scores are born in exp2 units, like the joint
+                            # attention's (-9 % on that launch, profiles/r4_m_spatial_attn_probe.json)
+                            c = (64 ** -0.5) * 1.4426950408889634
+                            F_ = r.feat_dim
+                            w, b = w.float().clone(), b.float().clone()
+                            w[F_:2 * F_] *= c
+                            b[F_:2 * F_] *= c
+                        packed["rg_" + name] = (ops.pack_rowgemm512(w, b, ln.weight, ln.bias), ln.eps,
                                                 ops.pack_rowgemm512(a.to_out[0].weight, a.to_out[0].bias))
                     packed["rg_mlp"] = (ops.pack_rowgemm512(st.mlp[0].weight, st.mlp[0].bias, st.norm4.weight, st.norm4.bias),
                                         st.norm4.eps, ops.pack_rowgemm512(st.mlp[2].weight, st.mlp[2].bias))
@@ -786,7 +796,7 @@ class DenoiseEngine:
             ops.attention(qkv, qkv[:, F:], qkv[:, 2 * F:], ra, head_dim=hd, heads=heads, nb1=B * n_id * T, nb2=1,
                           Sq=per_frame, Skv=per_frame, q_strides=(per_frame * 3 * F, 0, 3 * F),
                           k_strides=(per_frame * 3 * F, 0, 3 * F), v_strides=(per_frame * 3 * F, 0, 3 * F),
-                          o_strides=(per_frame * F, 0, F), scale=hd ** -0.5)
+                          o_strides=(per_frame * F, 0, F), scale=hd ** -0.5, prescaled="rg_spatial_attn" in pk)
             self._r_linres(ra, pk, "rg_spatial_attn", st.spatial_attn.to_out[0], rs2)
             # 2. temporal: every (sample, id, location) attends over its T frames
             self._r_group_attn(rs2, rn, qkv, ra, st.norm2, pk, "temporal_attn", T, heads, B * n_id, per_frame, N, per_frame)
@@ -844,7 +854,7 @@ class DenoiseEngine:
             ops.attention(qkv_a, qkv_a[:, F:], qkv_a[:, 2 * F:], ra_a, head_dim=hd, heads=heads, nb1=rp.nPA, nb2=1,
                           Sq=per_frame, Skv=per_frame, q_strides=(per_frame * 3 * F, 0, 3 * F),
                           k_strides=(per_frame * 3 * F, 0, 3 * F), v_strides=(per_frame * 3 * F, 0, 3 * F),
-                          o_strides=(per_frame * F, 0, F), scale=hd ** -0.5)
+                          o_strides=(per_frame * F, 0, F), scale=hd ** -0.5, prescaled="rg_spatial_attn" in pk)
             self._r_linres(ra_a, pk, "rg_spatial_attn", st.spatial_attn.to_out[0], xa2)
             # ---- location-major: temporal, multi-ID, MLP
             rp.a_to_b(xa, xb, overlap=overlap if bi == 0 else None)

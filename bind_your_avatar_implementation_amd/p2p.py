@@ -116,7 +116,8 @@ class P2PGroup:
                         continue
                     st = torch.UntypedStorage._new_shared_cuda(*inf)
                     self._keep.append(st)
-                    peers[j] = torch.empty(0, dtype=dtype, device=self.dev).set_(st, off, shp)
+                    # (the mapped storage carries the OWNER's device index; only its address is used, by kernels of this GPU)
+                    peers[j] = torch.empty(0, dtype=dtype, device=st.device).set_(st, off, shp)
                 dist.barrier(group=self.group)          # nobody pushes before everybody has mapped
         self._named[name] = (local, peers)
         return local
@@ -158,6 +159,20 @@ class P2PGroup:
         ch._sources = [p[0] for p in pieces]              # keep the source tensors alive
         self._channels[key] = ch
         return ch
+
+    def self_test(self):
+        """One tiny all-to-all through the engine, checked: every rank must see every peer's value (raises otherwise).
+        Run once at set-up, so that a platform where peer stores do not arrive is noticed before the first step."""
+        n = 64
+        recv = self.symmetric("__selftest__", (self.world, n), torch.float32, zero=True)
+        send = [torch.full((n,), 1000.0 + self.rank * 32 + j, dtype=torch.float32, device=self.dev) for j in range(self.world)]
+        self.channel("__selftest__", [(send[j], j, "__selftest__", self.rank * n) for j in range(self.world)]).exchange()
+        want = torch.tensor([1000.0 + r * 32 + self.rank for r in range(self.world)], device=self.dev)[:, None].expand(-1, n)
+        torch.cuda.synchronize(self.dev)
+        if self.timeouts() or not torch.equal(recv, want):
+            raise RuntimeError("P2P exchange self-test failed: peer stores did not arrive")
+        if self.world > 1:
+            dist.barrier(group=self.group)
 
     def timeouts(self):
         """Waits that gave up (0 on a healthy run); synchronises."""

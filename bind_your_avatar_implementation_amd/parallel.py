@@ -463,7 +463,21 @@ def shard_sequence(model, group=None, transport=None):
     if transport == "p2p":
         from .p2p import P2PGroup
         dev = next(model.parameters()).device
-        model._seq_p2p = P2PGroup(model._seq_group, dev)
+        p2p, err = None, None
+        try:
+            p2p = P2PGroup(model._seq_group, dev)
+            p2p.self_test()
+        except Exception as e:              # no hipIpc on this platform, peer access refused, ...
+            err = e
+        # every rank must agree: one rank on collectives and another on push kernels would deadlock
+        ok = [None] * model._seq_world
+        dist.all_gather_object(ok, err is None, group=model._seq_group)
+        if all(ok):
+            model._seq_p2p = p2p
+        else:
+            import warnings
+            warnings.warn(f"P2P exchange engine unavailable ({err!r} on this rank; ranks ok: {ok}): falling back to "
+                          "torch.distributed collectives")
     model.invalidate_engine()
     return model
 
