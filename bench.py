@@ -229,7 +229,7 @@ def main():
     inp["id_cond"] = [t.to(dev, torch.bfloat16) for t in inp["id_cond"]]
     inp["id_vit_hidden"] = [[t.to(dev, torch.bfloat16) for t in l] for l in inp["id_vit_hidden"]]
 
-    if args.graph and world == 1:
+    if args.graph and (world == 1 or getattr(model, "_seq_p2p", None) is not None):
         model.use_hip_graph = True
         args.no_kernel_timers = True          # events cannot be recorded per kernel inside a replayed graph
 
@@ -287,11 +287,13 @@ def main():
                                     f"({lt}x{lh // 2}x{lw // 2} latent tokens + 226 text), {nid} characters, batch {args.batch}"
                                     + (", fp8 weights" if args.fp8_weights else "")),
                        "layers": args.layers, "tokens": 226 + lt * (lh // 2) * (lw // 2), "batch": args.batch,
-                       "launch": "hipGraph replay" if (args.graph and world == 1) else "eager",
+                       "launch": "hipGraph replay" if getattr(model, "use_hip_graph", False) else "eager",
                        "parallelism": "single GPU" if world == 1 else
                        (f"CFG batch split x2, each half sequence-parallel x{world // 2}" if args.batch == 2 else
-                        f"sequence-parallel x{world} (head-parallel all-to-all around the joint attention, sharded "
-                        f"Embedding Router)")},
+                        f"sequence-parallel x{world} (head-parallel exchange around the joint attention, sharded "
+                        f"Embedding Router)") + ("; exchanges = P2P push kernels over hipIpc-mapped peer buffers"
+                                                 if getattr(model, "_seq_p2p", None) is not None else
+                                                 "; exchanges = torch.distributed collectives (RCCL)")},
         }
         if ktimes:
             tot = {k: sum(v) for k, v in ktimes.items()}
@@ -322,7 +324,7 @@ def main():
                                        "128x128 tiles; `traffic` is gemm256p_kernel's, per launch of that kernel)",
                              "bound": "mfma", "achieved": gflop / 1e12 / sum(gemm), "peak": PEAK_BF16_TFLOPS,
                              "unit": "TFLOP/s", "frac": gflop / 1e12 / sum(gemm) / PEAK_BF16_TFLOPS,
-                             "traffic": pmc_traffic(world, "gemm256p_kernel<false>", "gemm256p_kernel", "gemm256_kernel"), "launches": len(gemm),
+                             "traffic": pmc_traffic(world, "gemm256p_kernel<false, false>", "gemm256p_kernel<false>", "gemm256p_kernel", "gemm256_kernel"), "launches": len(gemm),
                              "avg_launch_ms": sum(gemm) / len(gemm) * 1e3, "tflop_per_launch_avg": gflop / 1e12 / len(gemm),
                              "ms_per_step": sum(gemm) / args.steps * 1e3}
             # headline = the kernel that dominates the step's time (the GEMM kernel when both were timed)

@@ -141,11 +141,7 @@ __global__ __launch_bounds__(64 * NW, HB == 4 ? 1 : 2) void rowgemm512_kernel(Ro
     // work range of this workgroup.  Neighbouring ranges share a row block (a range is about half a row block at N = 1536):
     // give consecutive ranges to the SAME XCD (blockIdx % 8 under round-robin dispatch) so that the second reader of a row
     // block's X finds it in that XCD's L2
-#ifndef BYA_ROWGEMM_PLAIN_ORDER
     const int rid = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
-#else
-    const int rid = (int)blockIdx.x;
-#endif
     const int q0 = (int)(total * rid / gridDim.x), q1 = (int)(total * (rid + 1) / gridDim.x);
     if (q0 >= q1) return;
 

@@ -134,6 +134,25 @@ def test_decode_stock_widths_vs_oracle(dev, frames):
     assert torch.isfinite(out.float()).all() and e <= 1.5 * e16 + 2e-3
 
 
+def test_patch_matrix_arm_agrees_with_implicit_gemm_decode(dev, monkeypatch):
+    """BYA_VAE_IMPLICIT_CONV=0 (every convolution as patch gather + bya_gemm_bf16, the round-3 first form, still the path of
+    channel counts the implicit kernel does not take) decodes the same clip as the default implicit-GEMM path: same products,
+    different K order inside the accumulation."""
+    from bind_your_avatar_implementation_amd import BindyouravatarVAE
+    g = torch.Generator().manual_seed(21)
+    z = torch.randn(1, 16, 3, 6, 8, generator=g).to(dev)
+    kw = dict(block_out_channels=(128, 256, 256, 512), layers_per_block=1)
+    a = BindyouravatarVAE(**kw, device=dev).init_synthetic(22)
+    monkeypatch.setenv("BYA_VAE_IMPLICIT_CONV", "0")
+    b = BindyouravatarVAE(**kw, device=dev).init_synthetic(22)
+    monkeypatch.delenv("BYA_VAE_IMPLICIT_CONV")
+    assert a.implicit_conv and not b.implicit_conv
+    ya, yb = a.decode(z).sample, b.decode(z).sample
+    e = rel_fro(ya.float(), yb.float())
+    print(f"implicit-GEMM decode vs patch-matrix decode: {e:.3e}")
+    assert torch.isfinite(yb.float()).all() and e < 6e-3
+
+
 def test_encode_stock_widths_vs_oracle(dev):
     """The stock encoder on one 48 x 64 conditioning frame: posterior mean and log-variance against the oracle."""
     vae, orc = make(dev, seed=13)
