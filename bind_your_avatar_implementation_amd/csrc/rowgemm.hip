@@ -406,12 +406,16 @@ __device__ __forceinline__ void rowattn_chunk(f32x4 (&acc)[HB][NJ], const bf16x8
     }
 }
 
+// WIDE = false: groups of L <= 16 rows in cells of P = 1, 2, 4, 8 or 16 slots of one tile.  WIDE = true: 16 < L <= 32 (the 25
+// latent frames of a 97-frame clip): a group is the two tiles of ONE wave, member m in slot m % 16 of tile m / 16; S^T is the
+// 2 x 2 grid of (key tile, query tile) products, the softmax runs over both key tiles, O^T sums two P.V products.
+template <bool WIDE>
 __global__ __launch_bounds__(64 * NW, 2) void rowattn512_kernel(RowAttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const long long tiles = (p.n_groups + p.G - 1) / p.G;
+    const long long tiles = WIDE ? 2 * p.n_groups : (p.n_groups + p.G - 1) / p.G;
     const int nrb = (int)((tiles + NW * HB - 1) / (NW * HB));
     const int total = nrb * RA_HEADS;                                   // (row block, head) units, row-block-major
     const int rid = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rowattn512_kernel(RowAttnArgs p) {
         const int ue = (rb + 1) * RA_HEADS < u1 ? (rb + 1) * RA_HEADS : u1;
         float mean[HB], rstd[HB];
         uint32_t rowi[HB];            // the row of this lane's token slot (M = none: loads read zeros, stores are dropped)
-        uint32_t kmask;               // bit e: key slot 4g+e belongs to the group of this lane's query slot t
+        uint32_t kmask;               // bit e (+ 4 hk when WIDE): key slot 4g+e (of key tile hk) belongs to the group of this lane's query
         {
             const uint32_t ln = lane_now(), to = ln & 15u, go = ln >> 4;
             // slot s of a tile = member s % P of the tile's group s / P (P = the power of two >= L, G = 16 / P groups): a
@@ -468,19 +472,25 @@ __global__ __launch_bounds__(64 * NW, 2) void rowattn512_kernel(RowAttnArgs p) {
             // not change the order in which the matrix core and the row-sum reduction add its terms (the other slots
             // contribute exact zeros) -- results do not depend on how the caller's rows are partitioned (a rank's shard
             // of the router rows vs the whole clip).
-            const uint32_t P = (uint32_t)p.P, gq = to / P, mq = to - gq * P;
+            const uint32_t P = WIDE ? 16u : (uint32_t)p.P, gq = WIDE ? 0u : to / P, mq = to - gq * P;
             kmask = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const uint32_t kk = 4 * go + e, gk = kk / P, mk = kk - gk * P;
-                kmask |= (gk == gq && mk < (uint32_t)p.L ? 1u : 0u) << e;
+                if (WIDE) {
+                    kmask |= (kk < (uint32_t)p.L ? 1u : 0u) << e;                 // key tile 0: members 0 .. 15
+                    kmask |= (16u + kk < (uint32_t)p.L ? 1u : 0u) << (4 + e);     // key tile 1: members 16 .. 31
+                } else {
+                    kmask |= (gk == gq && mk < (uint32_t)p.L ? 1u : 0u) << e;
+                }
             }
 #pragma unroll
             for (int h = 0; h < HB; ++h) {
                 const long long tile = (long long)rb * (NW * HB) + wave * HB + h;
-                const long long grp = tile * p.G + gq;
-                const bool ok = mq < (uint32_t)p.L && grp < p.n_groups;
-                const long long row = (grp / p.n_inner) * p.outer_stride + (grp % p.n_inner) + (long long)mq * p.seq_stride;
+                const long long grp = WIDE ? tile / 2 : tile * p.G + gq;
+                const uint32_t member = WIDE ? 16u * (uint32_t)h + to : mq;
+                const bool ok = member < (uint32_t)p.L && grp < p.n_groups;
+                const long long row = (grp / p.n_inner) * p.outer_stride + (grp % p.n_inner) + (long long)member * p.seq_stride;
                 rowi[h] = ok ? (uint32_t)row : (uint32_t)p.M;
                 const uint32_t vo = rowi[h] * (uint32_t)(p.ldx * 2) + go * 16;
 #pragma unroll
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rowattn512_kernel(RowAttnArgs p) {
         for (; u < ue; ++u) {
             const int head = u & (RA_HEADS - 1);
             u32x4 qf[HB][2], kf[HB][2];
-            u32x2 pf[HB];
+            u32x2 pf[HB][WIDE ? HB : 1];
             float invl[HB];
             // ---------------------------------------------------------------- q and k: transposed product + LN epilogue
 #pragma unroll
@@ -566,33 +576,42 @@ __global__ __launch_bounds__(64 * NW, 2) void rowattn512_kernel(RowAttnArgs p) {
                 stg ^= 1;
             }
             // ---------------------------------------------------------------- S^T = K . Q^T, masked softmax over the keys
+            constexpr int NKT = WIDE ? HB : 1;                  // key tiles a query attends to
 #pragma unroll
-            for (int h = 0; h < HB; ++h) {
-                f32x4 st = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[h][kb]),
-                                                                 __builtin_bit_cast(bf16x8, qf[h][kb]), st, 0, 0, 0);
-                float sv[4];
+            for (int h = 0; h < HB; ++h) {                      // query tile
+                float sv[NKT][4];
                 float mx = -INFINITY;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sv[e] = (kmask >> e) & 1u ? st[e] : -INFINITY;
-                    mx = fmaxf(mx, sv[e]);
+                for (int hk = 0; hk < NKT; ++hk) {
+                    const int kt = WIDE ? hk : h;               // key tile: the other tile of the wave too when WIDE
+                    f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+                        st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[kt][kb]),
+                                                                     __builtin_bit_cast(bf16x8, qf[h][kb]), st, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sv[hk][e] = (kmask >> (4 * hk + e)) & 1u ? st[e] : -INFINITY;
+                        mx = fmaxf(mx, sv[hk][e]);
+                    }
                 }
                 mx = fmaxf(mx, __shfl_xor(mx, 16));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
-                float pe[4], l = 0.f;
+                float l = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pe[e] = __builtin_amdgcn_exp2f((sv[e] - mx) * p.scale_log2);        // masked keys: exp2(-inf) = 0
-                    l += pe[e];
+                for (int hk = 0; hk < NKT; ++hk) {
+                    float pe[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pe[e] = __builtin_amdgcn_exp2f((sv[hk][e] - mx) * p.scale_log2);    // masked keys: exp2(-inf) = 0
+                        l += pe[e];
+                    }
+                    pf[h][hk][0] = pack2bf(pe[0], pe[1]);
+                    pf[h][hk][1] = pack2bf(pe[2], pe[3]);
                 }
                 l += __shfl_xor(l, 16);
                 l += __shfl_xor(l, 32);
                 invl[h] = __builtin_amdgcn_rcpf(l);
-                pf[h][0] = pack2bf(pe[0], pe[1]);
-                pf[h][1] = pack2bf(pe[2], pe[3]);
             }
             // ---------------------------------------------------------------- v: straight product, O^T = V^T . P^T, store
             {
@@ -614,23 +633,38 @@ __global__ __launch_bounds__(64 * NW, 2) void rowattn512_kernel(RowAttnArgs p) {
                     sj[j] = s_lds[col + 4 * j];
                     cj[j] = c_lds[col + 4 * j];
                 }
-#pragma unroll
-                for (int h = 0; h < HB; ++h) {
+                // V^T fragments (A operands: lane (g, i) = V[tokens 4g+e of the tile, column of W row i]).  WIDE: of both tiles
+                // first, every query tile needs both; else tile by tile (fewer live registers)
+                auto make_vt = [&](int h, u32x2 (&vt)[NJ]) {
                     f32x4 m4, r4;
                     lds_read_f<0>(m4, st_base + (uint32_t)(h * 32 + 4 * go) * 4);
                     lds_read_f<64>(r4, st_base + (uint32_t)(h * 32 + 4 * go) * 4);
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m4), "+v"(r4));
-                    float ov[16];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         float vv[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) vv[e] = fmaf(r4[e], fmaf(-m4[e], sj[j], acc[h][j][e]), cj[j]);
-                        u32x2 vt;
-                        vt[0] = pack2bf(vv[0], vv[1]);
-                        vt[1] = pack2bf(vv[2], vv[3]);
+                        vt[j][0] = pack2bf(vv[0], vv[1]);
+                        vt[j][1] = pack2bf(vv[2], vv[3]);
+                    }
+                };
+                u32x2 vt[WIDE ? HB : 1][NJ];
+                if constexpr (WIDE) {
+#pragma unroll
+                    for (int h = 0; h < HB; ++h) make_vt(h, vt[h]);
+                }
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {                  // query tile
+                    if constexpr (!WIDE) make_vt(h, vt[0]);
+                    float ov[16];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
                         f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, vt), __builtin_bit_cast(s16x4, pf[h]), o, 0, 0, 0);
+#pragma unroll
+                        for (int hk = 0; hk < NKT; ++hk)
+                            o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, vt[WIDE ? hk : 0][j]),
+                                                                          __builtin_bit_cast(s16x4, pf[h][hk]), o, 0, 0, 0);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) ov[4 * j + e] = o[e] * invl[h];
                     }
@@ -681,7 +715,7 @@ extern "C" int bya_router_group_attn(const void* X, const void* Wqkv, const floa
                                      int64_t outer_stride, int64_t seq_stride, float eps, float scale, hipStream_t stream) {
 #if BYA_ROWGEMM_CH == 64 && BYA_ROWGEMM_HB == 2
     if (!X || !Wqkv || !colsum || !cvec || !O || M <= 0 || n_outer <= 0 || n_inner <= 0) return BYA_ERR_SHAPE;
-    if (L < 1 || L > 16) return BYA_ERR_UNSUPPORTED;                  // a group must fit one 16-row MFMA tile
+    if (L < 1 || L > 32) return BYA_ERR_UNSUPPORTED;                  // a group must fit the two 16-row MFMA tiles of a wave
     if (outer_stride < 0 || seq_stride < 0) return BYA_ERR_SHAPE;
     if ((n_outer - 1) * outer_stride + (n_inner - 1) + (int64_t)(L - 1) * seq_stride >= M) return BYA_ERR_SHAPE;
     if (ldx < RK || ldo < RK || ldx % 8 || ldo % 8) return BYA_ERR_ALIGN;
@@ -690,17 +724,24 @@ extern "C" int bya_router_group_attn(const void* X, const void* Wqkv, const floa
     RowAttnArgs a;
     a.X = (const bf16_t*)X; a.W = (const bf16_t*)Wqkv; a.colsum = colsum; a.cvec = cvec; a.O = (bf16_t*)O;
     a.M = M; a.ldx = ldx; a.ldo = ldo; a.L = L;
+    const bool wide = L > 16;
     a.P = L <= 1 ? 1 : L <= 2 ? 2 : L <= 4 ? 4 : L <= 8 ? 8 : 16;
     a.G = 16 / a.P;
     a.n_groups = n_outer * n_inner; a.n_inner = n_inner; a.outer_stride = outer_stride; a.seq_stride = seq_stride;
     a.eps = eps; a.scale_log2 = scale * 1.4426950408889634f;
-    const long long tiles = (a.n_groups + a.G - 1) / a.G;
+    const long long tiles = wide ? 2 * a.n_groups : (a.n_groups + a.G - 1) / a.G;
     const long long total = ((tiles + NW * HB - 1) / (NW * HB)) * RA_HEADS;
     const int blocks = (int)(total < 256 ? total : 256);
     const size_t lds = (size_t)RA_CONST_BYTES + 2 * STAGE_BYTES;
     static std::atomic<unsigned long long> attr_done{0};
-    if (bya_allow_big_lds(reinterpret_cast<const void*>(rowattn512_kernel), 160 * 1024, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
-    BYA_LAUNCH(rowattn512_kernel, dim3(blocks), dim3(64 * NW), lds, stream, a);
+    static std::atomic<unsigned long long> attr_done_w{0};
+    if (wide) {
+        if (bya_allow_big_lds(reinterpret_cast<const void*>(rowattn512_kernel<true>), 160 * 1024, attr_done_w) != BYA_OK) return BYA_ERR_LAUNCH;
+        BYA_LAUNCH(rowattn512_kernel<true>, dim3(blocks), dim3(64 * NW), lds, stream, a);
+    } else {
+        if (bya_allow_big_lds(reinterpret_cast<const void*>(rowattn512_kernel<false>), 160 * 1024, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
+        BYA_LAUNCH(rowattn512_kernel<false>, dim3(blocks), dim3(64 * NW), lds, stream, a);
+    }
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 #else
     return BYA_ERR_UNSUPPORTED;

@@ -746,10 +746,10 @@ class DenoiseEngine:
     def _r_group_attn(self, x, tmp, qkv, out, ln, pk, name, L, heads, n_outer, n_inner, outer_stride, seq_stride):
         """out = Attention over groups of L rows (temporal: the T frames of a location; multi-ID: the identities of a token)
         of LN(x), up to the out-projection.  One fused launch (ops.router_group_attn: the q|k|v tensor stays on chip) when
-        the group fits a 16-row MFMA tile and the folded weights exist, else LN -> q|k|v GEMM -> attn_tiny."""
+        the group fits the two 16-row MFMA tiles of a wave (32 rows) and the folded weights exist, else LN -> q|k|v GEMM -> attn_tiny."""
         rg = pk.get("rg_" + name)
         hd = 64
-        if rg is not None and L <= 16 and heads == 8 and os.environ.get("BYA_ROUTER_FUSED_ATTN", "1") != "0":
+        if rg is not None and L <= 32 and heads == 8 and os.environ.get("BYA_ROUTER_FUSED_ATTN", "1") != "0":
             return ops.router_group_attn(x, rg[0], out, L, n_outer, n_inner, outer_stride, seq_stride, eps=rg[1],
                                          scale=hd ** -0.5)
         F = x.shape[1]

@@ -299,8 +299,9 @@ int bya_rowgemm512(const void* X, const void* W, const float* colsum, const floa
  * X [M, 512] bf16 rows (stride ldx), O [M, 512] bf16 attention output in the SAME row order (stride ldo; may not alias X).
  * Wqkv [1536, 512] bf16: rows 0..511 = gamma-folded to_q, 512..1023 = to_k, 1024..1535 = to_v; colsum / cvec [1536] fp32
  * exactly as for bya_rowgemm512 with ln = 1.  Groups as for bya_attn_tiny: group (o, i), o < n_outer, i < n_inner,
- * consists of the L rows  o * outer_stride + i + e * seq_stride,  e < L;  1 <= L <= 16 (a group must fit one 16-row
- * MFMA tile; longer sequences -- 25 latent frames of a 97-frame clip -- take the unfused pair, BYA_ERR_UNSUPPORTED).
+ * consists of the L rows  o * outer_stride + i + e * seq_stride,  e < L;  1 <= L <= 32: groups of up to 16 rows share a
+ * 16-row MFMA tile in power-of-two cells, groups of 17 .. 32 rows (25 latent frames of a 97-frame clip) take the two
+ * tiles of one wave; longer sequences return BYA_ERR_UNSUPPORTED (the unfused pair handles them).
  * scale = 1 / sqrt(64).  q, k, v are rounded to bf16 where the unfused path stored them, P to bf16 before P.V.
  * --------------------------------------------------------------------------------------------- */
 int bya_router_group_attn(const void* X, const void* Wqkv, const float* colsum, const float* cvec, void* O,

@@ -426,6 +426,9 @@ def _group_rows(L, n_outer, n_inner, outer_stride, seq_stride, dev):
     ("temporal, one rank's location range", 13, 2, 169, 13 * 169, 169, 2 * 13 * 169),
     ("temporal 16 frames, CFG batch", 16, 4, 77, 16 * 77, 77, 4 * 16 * 77 + 5),  # full tiles, rows beyond the groups untouched
     ("single rows", 1, 1, 300, 0, 0, 300),                                        # softmax over one key = v itself
+    ("temporal 25 frames x 3 ids (97-frame clip)", 25, 3, 1350, 25 * 1350, 1350, 3 * 25 * 1350),   # a group = both tiles of a wave
+    ("17 rows, ragged", 17, 2, 101, 17 * 101, 101, 2 * 17 * 101 + 3),
+    ("32 rows", 32, 1, 77, 0, 77, 32 * 77),
 ])
 def test_router_group_attn_fused_vs_fp32_and_unfused(ops, dev, name, L, n_outer, n_inner, outer_stride, seq_stride, M):
     """bya_router_group_attn (LayerNorm -> q|k|v -> attention over groups of L gathered rows, q|k|v never written) against
@@ -455,6 +458,8 @@ def test_router_group_attn_fused_vs_fp32_and_unfused(ops, dev, name, L, n_outer,
     print(f"{name}: fused vs fp32 {e:.3e} (reference bf16 chain {e16:.3e}); fused vs unfused pair {d:.3e}")
     assert torch.isfinite(out.float()).all()
     assert e <= 1.25 * e16 + 1e-3 and d <= 4e-3
+    with pytest.raises(Exception):
+        ops.router_group_attn(x, pack, out, 33, 1, 1, 0, 1)            # longer than two tiles: refused, not wrong
     touched = torch.zeros(M, dtype=torch.bool, device=dev)
     touched[rows.reshape(-1)] = True
     assert bool((out[~touched] == 7.0).all()), "rows outside the groups were written"
