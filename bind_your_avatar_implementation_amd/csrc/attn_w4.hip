@@ -57,13 +57,20 @@ constexpr int RB = 128, TILE_BYTES = KV_TILE * RB, STAGE_BYTES = 2 * TILE_BYTES,
 //   * full rounds: workgroup i of the XCD takes items i, i + 32, i + 64, ... of the XCD's (head, q-tile) list -- at any
 //     moment the 32 workgroups sit on 32 consecutive q-tiles of (mostly) one head and stream the same K/V through the
 //     XCD's L2, exactly like the dispatcher's order of the one-workgroup-per-item launch (contiguous ranges per
-//     workgroup lost that: every CU streamed its own head position, -5 % at 47026 tokens).
-//   * the remaining < 32 items are cut along the keys: their (item, key tile) steps form one list that is divided
-//     evenly over the 32 workgroups.  With the static-bound softmax partial results are simply additive (no running
-//     maximum to reconcile): a piece that does not start at key tile 0 writes its un-normalised O^T accumulators and
-//     row sums to its workgroup's workspace slot and raises the slot's flag; the owner of the item's FIRST piece adds
-//     the other pieces to its registers, normalises and stores.  Writers never wait, so there is no circular wait.
-struct SkItem { int bh, qt, tb, nt, nt_all, role, local; };      // role: 0 whole item, 1 later piece (writer), 2 first piece (merger)
+//     workgroup puts every CU at its own head position).
+//   * the remaining rem < 32 items are cut along the keys AT THE SAME KEY TILE a = nt * rem / 32: workgroups 0 .. rem-1 of the
+//     XCD ("mains") take key tiles [0, a) of one item each -- in step, like a full round -- and the other 32 - rem
+//     ("helpers") share the suffixes [a, nt) of those items evenly, item after item (the suffix K/V of a head is < 1 MB and
+//     stays in the L2 while a helper walks the q-tiles of that head).  Cutting the (item, key tile) list into 32
+//     contiguous ranges instead puts every workgroup at a different key position; both forms measure the same (+1 % at
+//     48 heads, +9 % at 24), so the cleaner one stays.  With the static-bound softmax partial results are additive (no running maximum toum to
+//     reconcile): a helper writes the un-normalised O^T accumulators and row sums of each of its pieces to that piece's
+//     workspace slot (pieces are numbered in step order: helper index + item index, < 64 per XCD) and raises the slot's
+//     flag; the main adds the slots of its item to its registers, normalises and stores.  Helpers never wait, so there
+//     is no circular wait.  A grid that does not fill ONE round (a rank's 6 heads of an 8-GPU step: 210 items on 256 CUs:
+//     every item a leftover item) runs correctly this way too but 7 % SLOWER than one workgroup per item, so the launcher
+//     declines it (see bya_launch_attn_w4).
+struct SkItem { int bh, qt, tb, nt, nt_all, role, local, slot; };   // role: 0 whole item, 1 suffix piece (writer), 2 prefix (merger)
 
 constexpr int SK_SLOT_FLOATS = 4 * QB * 2 * 16 * 64 + 4 * QB * 64;        // O^T register image + per-lane row sums
 constexpr int SK_FLAG_BYTES = 4096;                                       // 1024 words: [slot] flags, [1023] time-outs
@@ -80,8 +87,8 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
     const int nt_all = (p.Skv + KV_TILE - 1) / KV_TILE;
     // ---- the work of this workgroup
     const int sk_xcd = blockIdx.x & 7, sk_idx = blockIdx.x >> 3, sk_ncu = gridDim.x >> 3;
-    int sk_round = 0, sk_rfull = 0, sk_s = 0, sk_end = 0;      // SK: full rounds done / to do, tail steps [sk_s, sk_end)
-    long long sk_tail = 0;
+    int sk_round = 0, sk_rfull = 0, sk_rem = 0, sk_a = 0, sk_suf = 0, sk_s = 0, sk_end = 0;   // SK: rounds, leftover split, helper steps
+    bool sk_main_done = false;
     SkItem it;
     int sk_base = 0;                                               // nbh % 8 != 0: first item of this XCD in (head, q-tile) order
     if (SK) {
@@ -94,9 +101,15 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
             ipx = cq + (sk_xcd < cr ? 1 : 0);
         }
         sk_rfull = ipx / sk_ncu;
-        sk_tail = (long long)(ipx - sk_rfull * sk_ncu) * nt_all;   // (item, key tile) steps of the leftover items
-        sk_s = (int)(sk_tail * sk_idx / sk_ncu);
-        sk_end = (int)(sk_tail * (sk_idx + 1) / sk_ncu);
+        sk_rem = ipx - sk_rfull * sk_ncu;                          // leftover items: mains 0 .. rem-1, helpers rem .. ncu-1
+        sk_a = sk_rem ? (int)(((long long)nt_all * sk_rem + sk_ncu - 1) / sk_ncu) : nt_all;      // mains' key tiles [0, a)
+        sk_suf = nt_all - sk_a;                                    // suffix tiles per leftover item
+        if (sk_idx >= sk_rem && sk_rem && sk_suf) {                // helper: its share of the rem * suf suffix steps
+            const long long S = (long long)sk_rem * sk_suf;
+            const int nh = sk_ncu - sk_rem, h = sk_idx - sk_rem;
+            sk_s = (int)(S * h / nh);
+            sk_end = (int)(S * (h + 1) / nh);
+        }
     } else {
         // block -> (bh, q-tile): blocks with equal (blockIdx % 8) share an XCD; whole (batch, head)s per XCD when the count
         // divides by 8, else a contiguous eighth of the (head, q-tile) order (same rule as attn.hip)
@@ -203,14 +216,21 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
                 item = sk_round * sk_ncu + sk_idx;
                 ++sk_round;
                 it.tb = 0; it.nt = nt_all; it.role = 0; it.local = 0;
-            } else {
-                if (sk_s >= sk_end) break;
-                it.local = sk_s / nt_all;
+            } else if (sk_idx < sk_rem) {                       // main: key tiles [0, a) of leftover item sk_idx
+                if (sk_main_done) break;
+                sk_main_done = true;
+                it.local = sk_idx;
                 item = sk_rfull * sk_ncu + it.local;
-                it.tb = sk_s - it.local * nt_all;
-                const int left = sk_end - sk_s;
-                it.nt = nt_all - it.tb < left ? nt_all - it.tb : left;
-                it.role = it.tb > 0 ? 1 : (it.nt < nt_all ? 2 : 0);
+                it.tb = 0; it.nt = sk_a; it.role = sk_suf ? 2 : 0; it.slot = 0;
+            } else {                                            // helper: the next piece of its suffix steps
+                if (sk_s >= sk_end) break;
+                it.local = sk_s / sk_suf;
+                item = sk_rfull * sk_ncu + it.local;
+                const int off = sk_s - it.local * sk_suf, left = sk_end - sk_s;
+                it.tb = sk_a + off;
+                it.nt = sk_suf - off < left ? sk_suf - off : left;
+                it.role = 1;
+                it.slot = sk_xcd * (2 * sk_ncu) + (sk_idx - sk_rem) + it.local;      // pieces in step order: helper h + item index
                 sk_s += it.nt;
             }
             it.nt_all = nt_all;
@@ -307,8 +327,8 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
         // keys of the LAST tile that do not exist: P = 1 each (only the piece that holds the last tile sees them)
         const float pad_keys = it.tb + it.nt == it.nt_all ? (float)(it.nt_all * KV_TILE - p.Skv) : 0.f;
         if (SK && it.role == 1) {
-            // ---- a later piece of a cut item: hand the un-normalised accumulators and row sums to the owner of its first piece
-            const int my_slot = sk_xcd * sk_ncu + sk_idx;
+            // ---- a suffix piece of a leftover item: hand the un-normalised accumulators and row sums to the item's main
+            const int my_slot = it.slot;
             float* const slot = p.sk_part + (size_t)my_slot * SK_SLOT_FLOATS;
 #pragma unroll
             for (int b = 0; b < QB; ++b) {
@@ -328,11 +348,15 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
             continue;
         }
         if (SK && it.role == 2) {
-            // ---- first piece of a cut item: the following workgroups of this XCD hold the rest of it (each one's FIRST tail piece)
-            const int item_end = (it.local + 1) * nt_all;
-            for (int c = sk_idx + 1; c < sk_ncu; ++c) {
-                if ((int)(sk_tail * c / sk_ncu) >= item_end) break;
-                const int cs = sk_xcd * sk_ncu + c;
+            // ---- prefix [0, a) of a leftover item: the helpers of this XCD hold its suffix
+            // the suffix [local * suf, (local + 1) * suf) of the helpers' step list is held by every helper whose range
+            // [S h / nh, S (h + 1) / nh) overlaps it; a piece's slot is (helper + item index): its ordinal in step order
+            const long long S = (long long)sk_rem * sk_suf;
+            const int nh = sk_ncu - sk_rem, lo = it.local * sk_suf, hi = lo + sk_suf;
+            for (int hb = 0; hb < nh; ++hb) {
+                const int b0 = (int)(S * hb / nh), b1 = (int)(S * (hb + 1) / nh);
+                if (b1 <= lo || b0 >= hi || b0 == b1) continue;
+                const int cs = sk_xcd * (2 * sk_ncu) + hb + it.local;
                 if (tid == 0) {
                     int spins = 0;
                     while (__hip_atomic_load(p.sk_flags + cs, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
@@ -392,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
 
 namespace {
 // stream-K exchange workspace, caller-owned, one per DEVICE (same rules as the GEMM's split-K workspace, gemm.hip)
-constexpr int SK_MAX_DEVICES = 64, SK_GRID = 256, SK_SLOTS = SK_GRID;      // slot = xcd * 32 + index of the left neighbour
+constexpr int SK_MAX_DEVICES = 64, SK_GRID = 256, SK_SLOTS = 2 * SK_GRID;  // slot = xcd * 64 + helper + leftover item
 constexpr long long SK_WS_BYTES = SK_FLAG_BYTES + (long long)SK_SLOTS * SK_SLOT_FLOATS * 4;
 std::atomic<void*> g_attn_ws[SK_MAX_DEVICES];
 inline int sk_device() {
@@ -437,14 +461,17 @@ int bya_launch_attn_w4(const void* args, hipStream_t s) {
     const char* e = getenv("BYA_ATTN_STREAMK");              // A/B switch, read per call; default on when a workspace exists
     const long long nt_all = (a.Skv + KV_TILE - 1) / KV_TILE;
     const long long items = (long long)nbh * a.nqt;
-    // stream-K pays when an XCD's items make at least one whole round of its 32 CUs plus a partial one.  (Measured,
-    // profiles/r4_g_attn_streamk_probe.json: +1.3 % at 48 heads x 17776, +9 % at a 2-rank shard's 24 heads, +2.2 % at
-    // 47026 tokens.  A grid that does not fill ONE round -- 6 heads of an 8-rank shard, 210 items -- LOSES 2 % although a
-    // range is 0.82 items long: in the evenly cut tail the CUs of an XCD sit at different key positions, the 4.5 MB of a
-    // head's K/V no longer stream through the 4 MB L2 in step.)
-    const long long ipx = items / 8, tail_steps = (ipx % (SK_GRID / 8)) * nt_all;     // (per XCD, +- one item when 8 does not divide)
-    const bool sk = ws && !(e && e[0] == '0') && ipx >= SK_GRID / 8 && (items % SK_GRID != 0) && tail_steps >= 16 * (SK_GRID / 8) &&
-                    items * nt_all < (1LL << 31);
+    // stream-K pays when an XCD's items make at least one whole round of its 32 CUs plus a partial one.  Measured
+    // (profiles/r4_r_attn_streamk_probe.json): +1 % at 48 heads x 17776 (6.56 rounds), +8.5 % at a 2-rank shard's 24 heads
+    // (3.28 rounds), +2.7 % at 47026 tokens -- a fraction of what the round counts promise, and a grid that does not fill ONE
+    // round (6 heads of an 8-rank shard: 210 items on 256 CUs) LOSES 7 % although every workgroup then has 0.81 items
+    // of work.  Two forms of the cut (contiguous step ranges; mains + helpers at one key tile) measure the same, so it is
+    // not L2 locality: the kernel is power-limited, the CUs a partial round leaves idle give their
+    // power budget to the busy ones as clock, and filling them buys little; below one round the hand-offs cost more.
+    const long long ipx = items / 8;                            // per XCD, +- one item when 8 does not divide
+    const long long rem = ipx % (SK_GRID / 8);
+    const bool sk = ws && !(e && e[0] == '0') && ipx >= SK_GRID / 8 && (items % SK_GRID != 0) && rem * nt_all >= 8 * (SK_GRID / 8) &&
+                    nt_all >= 16 && items * nt_all < (1LL << 31);
     if (sk) {
         a.sk_flags = reinterpret_cast<unsigned*>(ws);
         a.sk_part = reinterpret_cast<float*>(ws + SK_FLAG_BYTES);

