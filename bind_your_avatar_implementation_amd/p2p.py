@@ -85,6 +85,7 @@ class P2PGroup:
         self._named = {}
         self._keep = []
         self._channels = {}
+        self._p2p_enabled = set()
         self.pushes = 0
         self.side_stream = torch.cuda.Stream(self.dev)
         self.ctrl = self.symmetric("__ctrl__", (MAX_CHANNELS, CTRL_WORDS), torch.int32, zero=True)
@@ -118,6 +119,12 @@ class P2PGroup:
                     self._keep.append(st)
                     # (the mapped storage carries the OWNER's device index; only its address is used, by kernels of this GPU)
                     peers[j] = torch.empty(0, dtype=dtype, device=st.device).set_(st, off, shp)
+                    if st.device != self.dev and (self.dev.index, st.device.index) not in self._p2p_enabled:
+                        # one process sees several GPUs (torchrun without per-rank visibility): a kernel of THIS GPU may only
+                        # dereference the peer's memory once peer access is enabled; torch does that on the first P2P copy
+                        probe = torch.empty(1, dtype=dtype, device=self.dev)
+                        probe.copy_(peers[j].reshape(-1)[:1])
+                        self._p2p_enabled.add((self.dev.index, st.device.index))
                 dist.barrier(group=self.group)          # nobody pushes before everybody has mapped
         self._named[name] = (local, peers)
         return local
