@@ -35,7 +35,7 @@ def timed(fn, iters=20):
 
 
 res = {}
-for W in (8, 4, 2):
+for W in ((8, 4, 2) if "--w1" not in sys.argv else (1,)):
     S_loc, N_loc = 17776 // W, 17550 // W
     shapes = [("qkv", S_loc, 9216, 3072, {}), ("attn_out", S_loc, 3072, 3072, {"res": True}),
               ("ff1", S_loc, 12288, 3072, {"act": "gelu_tanh"}), ("ff2", S_loc, 3072, 12288, {"res": True}),
@@ -65,5 +65,6 @@ for W in (8, 4, 2):
         best = max((v for v in row.values() if isinstance(v, float)), default=0)
         res[f"W{W} {name} {M}x{N}x{K}"] = row
         print(f"W{W} {name:14s} {M}x{N}x{K}: " + "  ".join(f"{k_}={v_}" for k_, v_ in row.items()), flush=True)
-if len(sys.argv) > 1:
-    json.dump(res, open(sys.argv[1], "w"), indent=1)
+outs = [a for a in sys.argv[1:] if not a.startswith("--")]
+if outs:
+    json.dump(res, open(outs[0], "w"), indent=1)
