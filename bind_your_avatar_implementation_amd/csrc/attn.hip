@@ -501,19 +501,26 @@ __device__ __forceinline__ void attn_mix_body(const MixArgs& p, char* smem) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) zacc[d][i] = 0.f;
     for (int id = 0; id < p.n_id; ++id) {
-        const bf16_t* K = p.k + id * p.k_id + grp * p.k_grp + (long long)head * D;
-        const bf16_t* V = p.v + id * p.v_id + grp * p.v_grp + (long long)head * D;
-        char* st = smem + (id & 1) * 2 * TILE_BYTES;           // two stages: identity id + 1 lands while id computes
+        char* st = smem + (id & 1) * 2 * TILE_BYTES;           // two stages
+        auto stage_id = [&](int j) {
+            char* dst = smem + (j & 1) * 2 * TILE_BYTES;
+            stage_kv<D, false>(p.k + j * p.k_id + grp * p.k_grp + (long long)head * D, p.k_row, 0, p.Skv - 1, dst, wave, lane);
+            stage_kv<D, true>(p.v + j * p.v_id + grp * p.v_grp + (long long)head * D, p.v_row, 0, p.Skv - 1, dst + TILE_BYTES, wave, lane);
+        };
+        // the K/V of the first TWO identities are requested together (one memory round trip and one rendezvous for the
+        // common two-identity case: the kernel is latency-bound, 13 rounds of small workgroups); identity id + 1 >= 3
+        // lands in the stage identity id - 1 has left while id computes
         if (id == 0) {
-            stage_kv<D, false>(K, p.k_row, 0, p.Skv - 1, st, wave, lane);
-            stage_kv<D, true>(V, p.v_row, 0, p.Skv - 1, st + TILE_BYTES, wave, lane);
+            stage_id(0);
+            if (p.n_id > 1) stage_id(1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (id + 1 < p.n_id) {
-            char* nx = smem + ((id + 1) & 1) * 2 * TILE_BYTES;
-            stage_kv<D, false>(p.k + (id + 1) * p.k_id + grp * p.k_grp + (long long)head * D, p.k_row, 0, p.Skv - 1, nx, wave, lane);
-            stage_kv<D, true>(p.v + (id + 1) * p.v_id + grp * p.v_grp + (long long)head * D, p.v_row, 0, p.Skv - 1, nx + TILE_BYTES, wave, lane);
+        if (id != 1) {                                          // identity 1 landed together with identity 0
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (id >= 1 && id + 1 < p.n_id) {
+            if (id == 1) __syncthreads();                       // every wave is done with identity 0's stage
+            stage_id(id + 1);
         }
         f32x16 oacc[DT];
 #pragma unroll
