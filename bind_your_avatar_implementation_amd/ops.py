@@ -42,6 +42,41 @@ class pinned_stream:
         return False
 
 
+class on_stream:
+    """Enqueue the launches inside the block on ``stream`` (a torch.cuda.Stream) instead of the step's pinned stream, behind
+    everything already enqueued on the pinned stream; ``join()`` afterwards makes the pinned stream wait for them.  Used for
+    work that nothing of the current stream's near future depends on (the step-invariant conditioning, which the first
+    routing layer needs ~8 ms later): its small launches fill the CUs the big kernels leave idle."""
+
+    def __init__(self, stream):
+        self.stream, self.done = stream, None
+
+    def __enter__(self):
+        global _PINNED_STREAM
+        self.main = torch.cuda.current_stream()
+        self.prev_pin = _PINNED_STREAM
+        fork = torch.cuda.Event()
+        fork.record(self.main)
+        self.stream.wait_event(fork)
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        _PINNED_STREAM = self.stream.cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        global _PINNED_STREAM
+        self.done = torch.cuda.Event()
+        self.done.record(self.stream)
+        _PINNED_STREAM = self.prev_pin
+        self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.done is not None:
+            torch.cuda.current_stream().wait_event(self.done)
+            self.done = None
+
+
 # ---- optional per-entry-point timers (HIP events recorded on the launch stream; used by bench.py) -------------
 _TIMERS = None
 _FLOPS = {}
