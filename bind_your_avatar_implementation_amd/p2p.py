@@ -10,9 +10,10 @@ and the whole sharded step replays as a graph.
 ``.symmetric(name, shape, dtype)``  a buffer every rank allocates under the same name: returns the local tensor; peers'
                                     copies are mapped into this process through hipIpc (torch's CUDA storage sharing),
                                     handles traded ONCE over the process group (any backend: gloo works)
-``.channel(key, pieces)``          the device-resident copy table of one exchange: pieces = [(src, peer, name, offset)],
-                                    "copy the contiguous local tensor ``src`` to element ``offset`` of buffer ``name`` on
-                                    rank ``peer``"; cached by key, built on first use
+``.channel(key, pieces)``          the channel (control block, sequence counters) of the logical exchange ``key``, bound to
+                                    the copy table of ``pieces`` = [(src, peer, name, offset)], "copy the contiguous local
+                                    tensor ``src`` to element ``offset`` of buffer ``name`` on rank ``peer``"; one table per
+                                    set of source addresses (workspaces change, captured graphs own theirs), built once
 ``Channel.exchange(side=False)``   push + wait on the current stream (``side``: the push runs on the group's side stream
                                     behind the work already enqueued; call ``.wait()`` where the data is needed)
 
@@ -27,22 +28,39 @@ import torch.distributed as dist
 
 from . import _hip
 
-MAX_CHANNELS = 512
+MAX_CHANNELS = 64
 CTRL_WORDS = 64
 CHUNK = 64 * 1024
 
 
 class Channel:
-    def __init__(self, grp, index, table, n_copies, total_chunks):
-        self.grp, self.index, self.table, self.n, self.total_chunks = grp, index, table, n_copies, total_chunks
+    """One exchange of the step: a control block (flags + device-resident sequence counters) and, per set of source
+    pointers it has been used with, a device-resident copy table.  The engine re-allocates its workspace when the geometry
+    changes and gives every captured hipGraph a workspace of its own: the SAME logical exchange then comes with other
+    source addresses -- it keeps its channel (and its sequence numbers, which all ranks advance in step) and gets one more
+    table; tables are never freed (a captured graph may hold their address; they are ~32 bytes per piece)."""
+
+    def __init__(self, grp, index):
+        self.grp, self.index = grp, index
         self.ctrl_ptr = grp.ctrl[index].data_ptr()
         self.peer_ctrl = torch.tensor([grp.ctrl_peers[j][index].data_ptr() for j in range(grp.world)], dtype=torch.int64,
                                       device=grp.dev)
-        self._pending = False
+        self.tables = {}                 # source-pointer signature -> (table tensor, n_copies, total_chunks, sources)
+        self.cur = None
+        self._join = None
+
+    def bind(self, pieces):
+        sig = tuple((p[0].data_ptr(), p[1], p[2], p[3], p[0].numel()) for p in pieces)
+        ent = self.tables.get(sig)
+        if ent is None:
+            ent = self.tables[sig] = self.grp._build_table(pieces)
+        self.cur = ent
+        return self
 
     def push(self, side=False):
         g = self.grp
         lib = _hip.load()
+        table, n, total_chunks, _ = self.cur
         cur = torch.cuda.current_stream(g.dev)
         stream = cur
         if side and g.world > 1:
@@ -50,15 +68,13 @@ class Channel:
             ev = torch.cuda.Event()
             ev.record(cur)
             stream.wait_event(ev)
-        _hip.check(lib.bya_p2p_push(self.table.data_ptr(), self.n, self.total_chunks, self.peer_ctrl.data_ptr(), g.world, g.rank,
+        _hip.check(lib.bya_p2p_push(table.data_ptr(), n, total_chunks, self.peer_ctrl.data_ptr(), g.world, g.rank,
                                     self.ctrl_ptr, stream.cuda_stream), "bya_p2p_push")
+        self._join = None
         if stream is not cur:
             self._join = torch.cuda.Event()
             self._join.record(stream)
-        else:
-            self._join = None
         g.pushes += 1
-        self._pending = True
         return self
 
     def wait(self):
@@ -68,7 +84,6 @@ class Channel:
             cur.wait_event(self._join)              # (also rejoins the side stream into a graph capture)
             self._join = None
         _hip.check(_hip.load().bya_p2p_wait(self.ctrl_ptr, g.world, cur.cuda_stream), "bya_p2p_wait")
-        self._pending = False
         return self
 
     def exchange(self):
@@ -136,14 +151,17 @@ class P2PGroup:
         return name in self._named
 
     # ---- channels ------------------------------------------------------------------------------------------------------
-    def channel(self, key, pieces=None):
+    def channel(self, key, pieces):
+        """The channel of the logical exchange ``key`` (created on first use: every rank, same order), bound to ``pieces`` =
+        [(contiguous local tensor, peer rank, receive-buffer name, element offset there)]."""
         ch = self._channels.get(key)
-        if ch is not None:
-            return ch
-        if pieces is None:
-            raise KeyError(key)
-        if len(self._channels) >= MAX_CHANNELS:
-            raise RuntimeError("P2P exchange engine: out of channels")
+        if ch is None:
+            if len(self._channels) >= MAX_CHANNELS:
+                raise RuntimeError("P2P exchange engine: out of channels")
+            ch = self._channels[key] = Channel(self, len(self._channels))
+        return ch.bind(pieces)
+
+    def _build_table(self, pieces):
         rows, chunk0 = [], 0
         for src, peer, name, offset in pieces:
             nbytes = src.numel() * src.element_size()
@@ -162,10 +180,7 @@ class P2PGroup:
         if not rows:                                     # nothing to send: still takes part in the flag protocol
             rows, chunk0 = [(self.ctrl.data_ptr(), self.ctrl.data_ptr(), 0, 0)], 1
         table = torch.tensor(rows, dtype=torch.int64, device=self.dev)
-        ch = Channel(self, len(self._channels), table, len(rows), chunk0)
-        ch._sources = [p[0] for p in pieces]              # keep the source tensors alive
-        self._channels[key] = ch
-        return ch
+        return table, len(rows), chunk0, [p[0] for p in pieces]      # (the sources stay alive with the table)
 
     def self_test(self):
         """One tiny all-to-all through the engine, checked: every rank must see every peer's value (raises otherwise).

@@ -96,7 +96,7 @@ class SeqShard:
 
     def _push(self, key, pieces, side=False):
         """One P2P exchange: pieces = [(contiguous local tensor, peer, receive-buffer name, element offset there)]."""
-        ch = self.p2p.channel((key,) + tuple(p[0].data_ptr() for p in pieces), pieces)
+        ch = self.p2p.channel(("seq", key, self.S, self.Tt), pieces)
         _count("p2p_exchange")
         return ch.push(side=side)
 
@@ -317,7 +317,7 @@ class RouterPartition:
         return self.buf(name, shape, like)
 
     def _push(self, key, pieces, side=False):
-        ch = self.p2p.channel((key, self.pairs, self.per_frame) + tuple(p[0].data_ptr() for p in pieces), pieces)
+        ch = self.p2p.channel(("router", key, self.pairs, self.per_frame), pieces)
         _count("p2p_exchange")
         return ch.push(side=side)
 
