@@ -36,6 +36,7 @@
 // VALU cycles (fp32 accumulation of exact bf16 products).
 #include "bya_common.h"
 #include "../../include/bya.h"
+#include <stdlib.h>
 
 #ifndef BYA_ROWGEMM_ABLATE
 #define BYA_ROWGEMM_ABLATE 0     // timing-only ablations (tools/): 1 = no X loads, 2 = no output stores
@@ -344,6 +345,193 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
+
+// =====================================================================================================================
+// N = 512 form of the row GEMM (the router's out-projections, mlp[0], mlp[2]: 420 launches per step): W-STATIONARY.
+// With 8 column chunks per row block the chunk-balanced kernel above gives a CU 4.3 chunks of ~1.6 row blocks: it loads
+// 410 KB of X to use 40 % of it, every chunk costs a workgroup barrier, and the X load of the next row block cannot
+// overlap anything (X fills the registers).  Here a workgroup keeps ONE QUARTER of W (128 output columns x 512 K = the two
+// 64-KiB ring stages, loaded once) in LDS and streams rows past it: the four workgroups of a row group (same XCD: the rows
+// they share come from its L2) cover the 512 columns, 64 row groups cover M.  No barrier after the first; a wave walks its
+// 16-row tiles two at a time, and X travels through an 8-k-step register ring that is refilled 8 k-steps ahead -- across
+// tile pairs too -- so HBM streams steadily under the MFMAs.  (No LayerNorm-folding instance: mlp[0] keeps the
+// chunk-balanced kernel; accumulating row statistics from streamed fragments does not fit two waves per SIMD.)
+#if BYA_ROWGEMM_CH == 64 && BYA_ROWGEMM_HB == 2
+template <bool LN, bool RES, int ACT>
+__global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) {
+    static_assert(!LN, "the W-stationary form has no LayerNorm-folding instance");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_xcd = gridDim.x >> 5;       // row groups per XCD
+    const int quarter = idx & 3, rgrp = xcd * per_xcd + (idx >> 2), ngroups = gridDim.x >> 2;
+    const int col_base = quarter * 128;
+
+    // LDS: [colsum: 128 f32][cvec: 128 f32][W quarter: 2 x 64 KiB in the ring's layout]
+    float* s_lds = reinterpret_cast<float*>(smem);
+    float* c_lds = s_lds + 128;
+    char* ring = smem + 1024;
+    if (tid < 128) {
+        s_lds[tid] = LN ? p.colsum[col_base + tid] : 0.0f;
+        c_lds[tid] = p.cvec[col_base + tid];
+    }
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.X, 0, (int)(((long long)(p.M - 1) * p.ldx + RK) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.N * RK * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.C, 0, (int)(((long long)(p.M - 1) * p.ldc + p.N) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(RES ? p.res : p.C), 0, (int)(((long long)(p.M - 1) * (RES ? p.ldres : p.ldc) + p.N) * 2), 0x00020000);
+    {   // the W quarter: stage st holds columns col_base + 64 st .. + 63 in the ring's row order (see stage_chunk above)
+        const uint32_t l16 = (uint32_t)lane << 4;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int r = 0; r < SR; ++r) {
+                const int R = wave * SR + r, i = R & 15, j = R >> 4;
+                const uint32_t vo = (l16 ^ (uint32_t)(i << 4)) + (uint32_t)(LPC * (i >> 2) + 4 * j + (i & 3)) * (RK * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(ring + st * STAGE_BYTES + (wave * SR + r) * 1024), 16, vo,
+                                                         (col_base + 64 * st) * (RK * 2), 0, 0);
+            }
+    }
+    // this wave's 16-row tiles: a contiguous eighth of the row group's contiguous share of all tiles
+    const int tiles_total = (p.M + 15) / 16;
+    const int g0 = (int)((long long)tiles_total * rgrp / ngroups), g1 = (int)((long long)tiles_total * (rgrp + 1) / ngroups);
+    const int tb = g0 + (int)((long long)(g1 - g0) * wave / NW), te = g0 + (int)((long long)(g1 - g0) * (wave + 1) / NW);
+    const int npair = (te - tb + 1) / 2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // W and the constants are in place; no barrier after this one
+    if (npair == 0) return;
+
+    const uint32_t to = (uint32_t)lane & 15u, go = (uint32_t)lane >> 4;
+    const uint32_t ring_base = (uint32_t)(uintptr_t)LDS_PTR(ring);
+    const uint32_t smem_base = (uint32_t)(uintptr_t)LDS_PTR(smem);
+    uint32_t wa[2][4];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            wa[st][m] = ring_base + st * STAGE_BYTES + to * 1024 + (((go ^ (to & 3)) | ((m ^ (to >> 2)) << 2)) << 4);
+
+    constexpr int D = 8;                                   // k-steps of X in flight = ring slots
+    bf16x8 xr[D][HB];
+    // byte offset of row (tile, slot to) in a matrix of row stride ld; tiles past this wave's range: outside every descriptor
+    auto row_off = [&](int pair, int h, int ld) -> uint32_t {
+        const int tile = tb + 2 * pair + h;
+        return (pair < npair && tile < te) ? ((uint32_t)tile * 16u + to) * (uint32_t)(ld * 2) : 0x7ffff000u;
+    };
+    // (hand-counted s_waitcnt around asm loads was tried: the register copies hipcc makes at the pair loop's back edge read
+    // slots whose loads are still in flight.  With builtin loads hipcc drains the ring at the head of every pair; measured,
+    // that costs nothing -- the kernel is bound by its LDS reads of W, one fragment per two MFMAs.)
+#define XLOAD(DST, VOFF, OFF) DST = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, (VOFF) + (OFF), 0, 0))
+    uint32_t xo[2][HB];                                    // X row offsets of the pair being computed / the next one
+#pragma unroll
+    for (int h = 0; h < HB; ++h) {
+        xo[0][h] = row_off(0, h, p.ldx) + go * 16;
+        xo[1][h] = row_off(1, h, p.ldx) + go * 16;
+    }
+#pragma unroll
+    for (int ks = 0; ks < D; ++ks) {
+        XLOAD(xr[ks][0], xo[0][0], ks * 64);
+        XLOAD(xr[ks][1], xo[0][1], ks * 64);
+    }
+
+    for (int pair = 0; pair < npair; ++pair) {
+        f32x4 acc[2][HB][NJ];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int h = 0; h < HB; ++h)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[st][h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 rv[2][HB][NJ / 2];
+        uint32_t ro[HB], co[HB];
+#pragma unroll
+        for (int h = 0; h < HB; ++h) {
+            ro[h] = row_off(pair, h, RES ? p.ldres : p.ldc) + ((uint32_t)col_base + LPC * go) * 2;
+            co[h] = row_off(pair, h, p.ldc) + ((uint32_t)col_base + LPC * go) * 2;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int slot = ks % D;
+            bf16x8 wf[2][NJ];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) read_kstep(wf[st], wa[st], ks);
+            const bf16x8 x0 = xr[slot][0], x1 = xr[slot][1];
+            lgkm_wait<0>(wf[0]);
+            lgkm_wait<0>(wf[1]);
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[st][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st][j], x0, acc[st][0][j], 0, 0, 0);
+                    acc[st][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st][j], x1, acc[st][1][j], 0, 0, 0);
+                }
+            // refill the slot 8 k-steps ahead: the second half of a pair prefetches the first half of the next pair
+            if (ks + D < 16) {
+                XLOAD(xr[slot][0], xo[0][0], (ks + D) * 64);
+                XLOAD(xr[slot][1], xo[0][1], (ks + D) * 64);
+            } else {
+                XLOAD(xr[slot][0], xo[1][0], (ks + D - 16) * 64);
+                XLOAD(xr[slot][1], xo[1][1], (ks + D - 16) * 64);
+            }
+            if (RES && ks == 7) {                          // the residual of this pair, under the second half of its MFMAs
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int h = 0; h < HB; ++h)
+#pragma unroll
+                        for (int u = 0; u < NJ / 2; ++u)
+                            rv[st][h][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                rsR, ro[h] + (64 * st + 8 * u) * 2, 0, 0));
+            }
+        }
+        // the next pair's offsets move up; the pair after it is looked up (outside the descriptor past the end)
+#pragma unroll
+        for (int h = 0; h < HB; ++h) {
+            xo[0][h] = xo[1][h];
+            xo[1][h] = row_off(pair + 2, h, p.ldx) + go * 16;
+        }
+        // ---- epilogue: lane (g, t) holds token t's columns col_base + 64 st + LPC g + 4 j + e
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int u = 0; u < NJ / 2; ++u) {
+                f32x4 c0, c1;
+                const uint32_t ac = smem_base + (uint32_t)(128 + 64 * st + 8 * u + LPC * go) * 4;
+                lds_read_f<0>(c0, ac);
+                lds_read_f<16>(c1, ac);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1));
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float o = acc[st][h][2 * u + (e >> 2)][e & 3] + ((e >> 2) ? c1[e & 3] : c0[e & 3]);
+                        if (ACT == BYA_ACT_GELU_ERF) o = gelu_erf_f(o);
+                        if (RES) o += (e & 1) ? bfhi(rv[st][h][u][e >> 1]) : bflo(rv[st][h][u][e >> 1]);
+                        v[e] = o;
+                    }
+                    u32x4 ov;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) ov[w2] = pack2bf(v[2 * w2], v[2 * w2 + 1]);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, co[h] + (64 * st + 8 * u) * 2, 0, 0);
+                }
+            }
+    }
+#undef XLOAD
+}
+
+template <bool LN, bool RES, int ACT>
+int launch_rowgemm_q(const RowGemmArgs& a, hipStream_t s) {
+    const size_t lds = 1024 + 2 * STAGE_BYTES;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (bya_allow_big_lds(reinterpret_cast<const void*>(rowgemm512q_kernel<LN, RES, ACT>), 160 * 1024, attr_done) != BYA_OK)
+        return BYA_ERR_LAUNCH;
+    BYA_LAUNCH((rowgemm512q_kernel<LN, RES, ACT>), dim3(256), dim3(64 * NW), lds, s, a);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+#endif
 
 // =====================================================================================================================
 // Fused  LayerNorm -> q|k|v projection -> grouped tiny attention  for the router's temporal and multi-ID sub-blocks
@@ -698,6 +886,19 @@ extern "C" int bya_rowgemm512(const void* X, const void* W, const float* colsum,
     a.C = (bf16_t*)C; a.M = M; a.N = N; a.ldx = ldx; a.ldc = ldc; a.ldres = res ? ldres : ldc;
     a.eps = eps;
     const bool gelu = act == BYA_ACT_GELU_ERF;
+#if BYA_ROWGEMM_CH == 64 && BYA_ROWGEMM_HB == 2
+    // N = 512: the W-stationary, barrier-free form (one W quarter per workgroup).  The rows M * ld must stay below 2 GiB like
+    // everywhere here; tiles outside a wave's range are addressed outside the descriptors.
+    const char* qe = getenv("BYA_ROWGEMM_Q");                     // A/B switch, read per call
+    // measured (profiles/r4_v_rowgemm_q_probe.json): -4 % at 35100 rows, -22 % at 17550, -47 % at 8788, -29 % at 4394 and
+    // 2194, level at 70200 -- above that the chunk-balanced kernel's finer work units win back what its barriers cost
+    if (N == 512 && !ln && M >= 2048 && M <= 65536 && !(qe && qe[0] == '0')) {
+        // (the LayerNorm-folding instance -- mlp[0] -- keeps the chunk-balanced kernel: accumulating the row statistics from
+        // the streamed fragments needs ~40 more registers than two waves per SIMD leave, and spills)
+        if (res) return gelu ? launch_rowgemm_q<false, true, BYA_ACT_GELU_ERF>(a, stream) : launch_rowgemm_q<false, true, BYA_ACT_NONE>(a, stream);
+        return gelu ? launch_rowgemm_q<false, false, BYA_ACT_GELU_ERF>(a, stream) : launch_rowgemm_q<false, false, BYA_ACT_NONE>(a, stream);
+    }
+#endif
     if (ln) {
         if (res) return gelu ? launch_rowgemm<true, true, BYA_ACT_GELU_ERF>(a, stream)
                              : launch_rowgemm<true, true, BYA_ACT_NONE>(a, stream);

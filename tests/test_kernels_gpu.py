@@ -403,6 +403,27 @@ def test_rowgemm512_repeatable_at_router_shape(ops, dev, N, ln, res):
     assert all(torch.equal(first, o) for o in outs)
 
 
+@pytest.mark.parametrize("M", [2048, 2049, 2063, 4394, 8788, 17550, 35100, 52650])
+@pytest.mark.parametrize("res,act", [(False, None), (True, None), (True, "gelu_erf"), (False, "gelu_erf")])
+def test_rowgemm512_w_stationary_form_matches_chunk_balanced(ops, dev, monkeypatch, M, res, act):
+    """N = 512 without LayerNorm takes the W-stationary kernel (one W quarter per workgroup, rows streamed) for
+    2048 <= M <= 65536; BYA_ROWGEMM_Q=0 keeps the chunk-balanced kernel.  Same MFMA order over K per output element, so
+    the two agree BIT FOR BIT -- ragged tile counts (waves with 0, 1, odd numbers of 16-row tiles, a last tile of 1 or 15
+    rows), strided X, residual added in place."""
+    xw = rnd((M, 768), dev, 90 + M % 7)
+    x = xw[:, 128:640]                                       # row stride 768: the loader must use ldx, not 512
+    w, b = rnd((512, 512), dev, 91, 512 ** -0.5), rnd((512,), dev, 92, 0.2)
+    pack = ops.pack_rowgemm512(w, b, None, None)
+    r = rnd((M, 512), dev, 93) if res else None
+    def run(flag):
+        monkeypatch.setenv("BYA_ROWGEMM_Q", flag)
+        out = r.clone() if res else torch.full((M, 512), 7.0, dtype=torch.bfloat16, device=dev)
+        ops.rowgemm512(x, pack, out, res=out if res else None, act=act)
+        torch.cuda.synchronize()
+        return out
+    assert torch.equal(run("1"), run("0"))
+
+
 def _group_attn_inputs(dev, M, seed):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(M, 512, generator=g) * (0.5 + 1.5 * torch.rand(M, 1, generator=g)) + torch.randn(M, 1, generator=g)
