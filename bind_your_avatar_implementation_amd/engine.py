@@ -367,11 +367,20 @@ class DenoiseEngine:
         (diffusers Attention.to_k/to_v on the 32 context tokens of each latent frame)."""
         am = self.m.audio_model
         ap = am.audio_proj_model
-        if audio_embeds.dim() != 5:
-            raise NotImplementedError(
-                "single-stream audio needs tests/input/ae_mute.pt, which the reference does not ship "
-                "(models/audio_model.py:203); pass [B, 2, F, 12, 768] with the silent stream zeroed")
-        a = self._bf(audio_embeds)
+        mono = audio_embeds.dim() == 4
+        if mono:
+            # models/transformer.py:674-676, 874-878: one stream per sample, the second stream of every sample is the
+            # "mute" embedding (models/audio_model.py:201-221: tests/input/ae_mute.pt cut to 4 T + 1 frames) -- here a
+            # second row of the projector's batch, so the silent stream costs no extra launch
+            mute = am.mute_audio_embeds
+            if mute is None:
+                mute = torch.load("tests/input/ae_mute.pt")           # the reference's own relative path and error
+            mute = self._bf(mute[:T * 4 + 1].to(self.dev))
+            if mute.shape != audio_embeds.shape[1:]:
+                raise AssertionError(f"cur_audio_context_tokens.shape: {tuple(audio_embeds.shape[1:])} frames x blocks x "
+                                     f"channels, mute_context_tokens.shape: {tuple(mute.shape)}")
+            audio_embeds = torch.stack([self._bf(audio_embeds), mute.unsqueeze(0).expand_as(audio_embeds)], dim=1)
+        a = self._bf(audio_embeds).contiguous()
         bs, ni, F, blk, ch = a.shape
         assert bs == B and ni == n_id
         assert 1 + (T - 1) * 4 + (am.window_size - am.window_stride) == F, \
@@ -402,6 +411,8 @@ class DenoiseEngine:
         tok = ap.context_tokens
         ctx = E(G * T * tok, ap.output_dim)
         self._ln(cur.view(G * T * tok, ap.output_dim), ctx, ap.norm)
+        if mono:                                  # get_mute_audio_feat: + mute_learnable_tokens on the silent stream
+            ctx.view(B, n_id, T, tok, ap.output_dim)[:, 1] += am.mute_learnable_tokens.view(1, 1, tok, ap.output_dim)
         self.last_audio_ctx = ctx.view(B, n_id, T, tok, ap.output_dim)
         rows, inner = G * T * tok, am.layers[0]["attn"].to_k.weight.shape[0]
         kv = E(2 * len(am.layers), rows, inner)                 # [k_0, v_0, k_1, v_1, ...], each [rows, inner] contiguous

@@ -113,3 +113,13 @@ def synth_inputs(batch=1, frames=13, height=60, width=90, in_channels=48, text_l
         audio_embeds=audio,
         af_matrix=torch.eye(n_id, device=device, dtype=dtype)[None].repeat(batch, 1, 1),
     )
+
+
+def mono_audio_extras(seed=0, device="cpu"):
+    """Synthetic stand-ins for the two tensors the reference's single-stream audio path adds
+    (models/audio_model.py:201-221): the "mute" wav2vec embedding the reference reads from
+    ``tests/input/ae_mute.pt`` (not shipped; 60 frames here so the ``[:num_frames * 4 + 1]`` cut is exercised) and a
+    non-zero ``mute_learnable_tokens`` (zeros at init, trained in the checkpoints).  Returns (ae_mute, tokens)."""
+    ae = synth_tensor("modin.ae_mute.proj", (60, 12, 768), seed, device) * (768 ** 0.5) * 0.26
+    tok = synth_tensor("modin.mute_tokens.proj", (1, 32, 768), seed, device) * (768 ** 0.5) * 0.3
+    return _bf16_round(ae), _bf16_round(tok)

@@ -200,6 +200,10 @@ class _AudioModel(nn.Module):
                            "attn": _Attn(dim, heads * head_dim, kv_dim=audio_dim, bias=True, **fk)})
             for _ in range(num_layers)])
         self.mute_learnable_tokens = nn.Parameter(torch.empty(1, 32, 768, **fk), requires_grad=False)
+        # single-stream audio (models/audio_model.py:201-221): the "mute" embedding the reference loads from
+        # tests/input/ae_mute.pt.  Set it with BindyouravatarTransformer3DModel.set_mute_audio_embeds(); left unset,
+        # the same relative path is read, as in the reference
+        self.mute_audio_embeds = None
 
 
 # ------------------------------------------------------------------------------------------ the model
@@ -466,6 +470,15 @@ class BindyouravatarTransformer3DModel(nn.Module):
             return False
         import torch.distributed as dist
         return dist.is_initialized() and dist.get_backend(group) == "nccl"
+
+    def set_mute_audio_embeds(self, ae_mute):
+        """The "mute" wav2vec embedding [>= 4 * latent_frames + 1, 12, 768] that completes a single-stream (4-D)
+        ``audio_embeds`` call: the reference reads it from ``tests/input/ae_mute.pt`` on first use
+        (models/audio_model.py:203), which its repository does not ship.  Not part of the state dict."""
+        self.audio_model.mute_audio_embeds = ae_mute
+        if self._engine is not None:
+            self._engine.release()
+        return self
 
     # ---- explicit step-invariant conditioning cache (SURVEY.md section 8f row 2) ---------------------------------
     def precompute_conditioning(self, id_cond=None, id_vit_hidden=None, audio_embeds=None, latent_frames=13):

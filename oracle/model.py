@@ -258,6 +258,22 @@ class AudioAwareModel(nn.Module):
                                   heads=num_attention_heads, bias=True)})
             for _ in range(num_layers)])
         self.mute_learnable_tokens = nn.Parameter(torch.zeros(1, 32, 768))
+        self.mute_context_tokens = None
+        self.mute_audio_embeds = None          # the content of tests/input/ae_mute.pt, when the caller holds it in memory
+
+    def _init_mute_audio_feat(self, cur, num_frames):
+        """models/audio_model.py:201-211: the silent second stream of a single-stream call, projected once."""
+        mute = self.mute_audio_embeds if self.mute_audio_embeds is not None else torch.load("tests/input/ae_mute.pt")
+        mute = mute[:num_frames * 4 + 1].to(cur.device, dtype=cur.dtype).unsqueeze(0)
+        ctx = self.proj_in(self.sliding_windows(mute, num_frames).contiguous())
+        assert cur.shape == ctx.shape, f"cur_audio_context_tokens.shape: {cur.shape}, mute_context_tokens.shape: {ctx.shape}"
+        self.mute_context_tokens = ctx
+
+    def get_mute_audio_feat(self, cur, num_frames):
+        """models/audio_model.py:213-221 in eval mode (the dropout is the identity): [1, f, 32, 768]."""
+        if self.mute_context_tokens is None:
+            self._init_mute_audio_feat(cur, num_frames)
+        return self.mute_context_tokens + self.mute_learnable_tokens.repeat(num_frames, 1, 1).unsqueeze(0)
 
     def sliding_windows(self, audio_embeds, num_frames):
         assert 1 + (num_frames - 1) * 4 + (self.window_size - self.window_stride) == audio_embeds.shape[1], \
@@ -422,11 +438,16 @@ class OracleTransformer(nn.Module):
         use_audio = self.is_train_audio and audio_embeds is not None
         if use_audio:
             a = audio_embeds.to(hidden_states.dtype)
-            assert a.ndim == 5, "single-stream audio needs tests/input/ae_mute.pt, absent from the reference"
-            bs, ni, fr, blk, ad = a.shape
-            a = self.audio_model.sliding_windows(a.view(bs * ni, fr, blk, ad), t)
-            ctx = self.audio_model.proj_in(a)
-            ctx = ctx.view(bs, ni, *ctx.shape[-3:])                                       # [B, n_id, T, 32, 768]
+            if a.ndim == 5:
+                bs, ni, fr, blk, ad = a.shape
+                a = self.audio_model.sliding_windows(a.view(bs * ni, fr, blk, ad), t)
+                ctx = self.audio_model.proj_in(a)
+                ctx = ctx.view(bs, ni, *ctx.shape[-3:])                                   # [B, n_id, T, 32, 768]
+            else:
+                # models/transformer.py:674-676, 874-878: one stream per sample; the second is the "mute" stream
+                ctx = self.audio_model.proj_in(self.audio_model.sliding_windows(a, t))    # [B, T, 32, 768]
+                ctx = torch.stack([torch.cat([c.unsqueeze(0), self.audio_model.get_mute_audio_feat(c.unsqueeze(0), t)])
+                                   for c in ctx])
             taps["audio_ctx"] = ctx
 
         emb = self.time_embedding(self.time_proj(timestep).to(hidden_states.dtype), timestep_cond)

@@ -17,7 +17,7 @@ nothing here is imported by the test-suite at run time).  What it does:
   4. runs ``oracle.model.OracleTransformer`` on the same weights/inputs and prints the deviation,
      which ``tests/test_oracle_golden.py`` re-checks from the fixtures.
 
-Usage:  python tests/golden/make_golden.py [--case base|cfg_forcing|modules|masks|depth|config0|bars] [--layers 2]
+Usage:  python tests/golden/make_golden.py [--case base|cfg_forcing|modules|masks|depth|config0|config0_mono|prepare_latents|bars] [--layers 2]
 
 ``depth``   : the full 42-layer model at the reference geometry (fp32 reference + the oracle run in bf16 on the same
               weights: the fixture carries the reference output, strided per-block taps and the bf16 path's own error,
@@ -296,7 +296,7 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def bf16_oracle_pass(layers, seed, inp, step, router_tap=None, **over):
+def bf16_oracle_pass(layers, seed, inp, step, router_tap=None, prep=None, **over):
     """The restatement with bf16 parameters and activations (what the reference's own bf16 inference path computes,
     infer.py:477) on the same synthetic weights: its distance from the fp32 result is the tolerance bar."""
     with torch.device("meta"):
@@ -304,6 +304,8 @@ def bf16_oracle_pass(layers, seed, inp, step, router_tap=None, **over):
     orc = orc.to_empty(device="cpu").to(torch.bfloat16)
     fill(orc, seed)
     orc.eval()
+    if prep is not None:
+        prep(orc)
     taps = StridedTaps(step)
     if router_tap is not None:
         orc.router.register_forward_hook(lambda m, a, o: router_tap.append(o.detach().float().clone()))
@@ -314,11 +316,14 @@ def bf16_oracle_pass(layers, seed, inp, step, router_tap=None, **over):
     return out.float(), taps
 
 
-def run_deep(case, layers, seed, step, over, inp):
-    """fp32 REFERENCE + bf16 oracle on one configuration; strided taps only (memory)."""
+def run_deep(case, layers, seed, step, over, inp, prep=None):
+    """fp32 REFERENCE + bf16 oracle on one configuration; strided taps only (memory).  ``prep(model)`` is applied to
+    the reference and to the oracle after their weights are in place."""
     install_standins()
     from models.transformer import BindyouravatarTransformer3DModel
     ref, _ = build(BindyouravatarTransformer3DModel, layers, seed, **over)
+    if prep is not None:
+        prep(ref)
     taps = {}
 
     def hook(name):
@@ -343,7 +348,7 @@ def run_deep(case, layers, seed, step, over, inp):
         fx[k + ".strided"] = v
     for j, r in enumerate(rtaps[:2]):
         fx[f"router.call{j}"] = r.numpy()
-    out16, taps16 = bf16_oracle_pass(layers, seed, inp, step, **over)
+    out16, taps16 = bf16_oracle_pass(layers, seed, inp, step, prep=prep, **over)
     fx["bf16_err_output"] = np.array(rel(out16, out))
     errs = []
     for i in range(layers):
@@ -426,6 +431,33 @@ def config0_inputs(seed):
     inp["id_vit_hidden"][1] = [torch.zeros_like(t) for t in inp["id_vit_hidden"][1]]
     inp["audio_embeds"][:, 1] = 0
     return inp
+
+
+def run_config0_mono(seed):
+    """BASELINE.json configs[0] as the reference itself takes it: ONE audio stream ([B, F, 12, 768]); the reference
+    completes it with the "mute" stream it reads from tests/input/ae_mute.pt relative to the working directory
+    (models/audio_model.py:201-221).  That file is not shipped: a seeded stand-in is written into a scratch directory and
+    the reference runs from there, so its own torch.load finds it."""
+    import tempfile
+    from bind_your_avatar_implementation_amd.synth import mono_audio_extras
+    ae_mute, tokens = mono_audio_extras(seed)
+    inp = config0_inputs(seed)
+    inp["audio_embeds"] = inp["audio_embeds"][:, 0].contiguous()
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "tests", "input"))
+    torch.save(ae_mute, os.path.join(tmp, "tests", "input", "ae_mute.pt"))
+
+    def prep(model):
+        am = model.audio_model
+        am.mute_learnable_tokens.data.copy_(tokens.to(am.mute_learnable_tokens.dtype))
+        if hasattr(am, "mute_audio_embeds"):
+            am.mute_audio_embeds = ae_mute       # the oracle takes the tensor; the reference reads the file
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        run_deep("config0_mono", 1, seed, 970, dict(cross_attn_interval=1), inp, prep=prep)
+    finally:
+        os.chdir(cwd)
 
 
 def run_bars(seed):
@@ -561,7 +593,7 @@ def run_masks(seed):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--case", default="base", choices=["base", "cfg_forcing", "modules", "masks", "depth", "config0", "prepare_latents",
+    ap.add_argument("--case", default="base", choices=["base", "cfg_forcing", "modules", "masks", "depth", "config0", "config0_mono", "prepare_latents",
                                                         "bars"])
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
@@ -579,6 +611,8 @@ if __name__ == "__main__":
         run_deep("depth", 42 if a.layers == 2 else a.layers, a.seed, 9973, {}, synth_inputs(batch=1, seed=a.seed))
     elif a.case == "config0":
         run_deep("config0", 1, a.seed, 970, dict(cross_attn_interval=1), config0_inputs(a.seed))
+    elif a.case == "config0_mono":
+        run_config0_mono(a.seed)
     elif a.case == "bars":
         run_bars(a.seed)
     else:
