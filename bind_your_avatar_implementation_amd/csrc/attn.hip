@@ -556,6 +556,184 @@ __device__ __forceinline__ void attn_mix_body(const MixArgs& p, char* smem) {
     }
 }
 
+// ---- the <= 32-key form (both callers: 32 audio context tokens per frame, 32 face tokens per identity) --------------
+// attn_mix_body runs ONE 128-row query tile per workgroup: stage K / V (64-row tiles, half of them padding), rendezvous,
+// attention on a 64-key tile with the upper half masked, store -- 6864 workgroups per audio launch, each a serial chain
+// of memory round trips with a barrier in the middle, twice the MFMAs and exps the 32 keys need: 87 us for 218 MB.
+// Here a workgroup owns one (group, head) and a CHUNK of its query rows: the K / V of every identity are staged once
+// (32 rows each) and stay in LDS, after the one rendezvous every wave walks its own 32-row tiles (tile w, w + 4, ... of the
+// chunk) with no further barrier: per tile 4 K-fragment reads, D / 16 MFMAs for S^T, one softmax over 32 keys (two lanes per
+// query), D / 16 MFMAs for O^T, per identity.  blockIdx runs over the heads fastest, so the workgroups in flight
+// together read the 128-byte head segments of the SAME rows (whole 6-KiB rows over a short time, not one segment per
+// row spread over the launch).  Arithmetic per element is that of attn_tile<TAIL> on a first tile (the two-term bf16
+// maximum, the order of the row sum, k-steps 0 and 1 of P.V) -- so results are BIT-IDENTICAL to attn_mix_body and, for
+// one-hot masks, to bya_attn_fwd's rows (tests/test_kernels_gpu.py).
+template <int D>
+__device__ __forceinline__ void stage_kv32(const bf16_t* __restrict__ src, long long row_stride, int kv_max, char* lds_tile,
+                                           int wave, int lane, bool is_v) {
+    constexpr int ROW_BYTES = D * 2, ROWS_PER_INSTR = 1024 / ROW_BYTES, CHUNKS = ROW_BYTES / 16;
+    for (int q = wave; q < 32 / ROWS_PER_INSTR; q += 4) {
+        const int rbase = q * ROWS_PER_INSTR;
+        const int rl = rbase + lane / CHUNKS;
+        const int slot = lane % CHUNKS;
+        const int chunk = slot ^ (is_v ? vswz<D>(rl) : kswz<D>(rl));
+        const int gr = rl < kv_max ? rl : kv_max;
+        const bf16_t* g = src + (long long)gr * row_stride + chunk * 8;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(lds_tile + rbase * ROW_BYTES), 16, 0, 0);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void attn_mix32_body(const MixArgs& p, char* smem) {
+    constexpr int ROW_BYTES = D * 2, KV_BYTES = 32 * ROW_BYTES, DSTEPS = D / 16, DT = D / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hf = lane >> 5;
+    int bid = blockIdx.x;
+    const int head = bid % p.heads; bid /= p.heads;
+    const int chunk = bid % p.nqt;                               // nqt = row chunks per (group, head) in this form
+    const int grp = bid / p.nqt;
+    const int n32 = (p.Sq + 31) >> 5;
+    const int t0 = (int)((long long)n32 * chunk / p.nqt), t1 = (int)((long long)n32 * (chunk + 1) / p.nqt);
+    const bf16_t* Q = p.q + grp * p.q_grp + (long long)head * D;
+    bf16_t* Z = p.z + grp * p.z_grp + (long long)head * D;
+
+    for (int id = 0; id < p.n_id; ++id) {
+        stage_kv32<D>(p.k + id * p.k_id + grp * p.k_grp + (long long)head * D, p.k_row, p.Skv - 1, smem + id * 2 * KV_BYTES,
+                      wave, lane, false);
+        stage_kv32<D>(p.v + id * p.v_id + grp * p.v_grp + (long long)head * D, p.v_row, p.Skv - 1,
+                      smem + id * 2 * KV_BYTES + KV_BYTES, wave, lane, true);
+    }
+    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    uint32_t voff[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        const int row = 4 * hf + tq;
+        const int ch = 4 * d + 2 * (g & 1) + (tp >> 1);
+        voff[d] = row * ROW_BYTES + ((ch ^ vswz<D>(row)) << 4) + (tp & 1) * 8;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
+    uint32_t koff[DSTEPS];
+#pragma unroll
+    for (int s = 0; s < DSTEPS; ++s) koff[s] = r * ROW_BYTES + (((2 * s + hf) ^ kswz<D>(r)) << 4);
+    const float c = p.scale_log2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                             // K / V of every identity are in LDS; no barrier below
+
+    // (measured and dropped: q as whole head segments by LDS-DMA into the wave's patch + ds_read_b128 fragments -- audio
+    // level, face 42 -> 49 us; q requested one tile ahead in registers -- +35 registers, one wave per SIMD less, level)
+    for (int t = t0 + wave; t < t1; t += 4) {
+        int qrow = t * 32 + r;
+        const bool q_valid = qrow < p.Sq;
+        qrow = q_valid ? qrow : p.Sq - 1;
+        bf16x8 qf[DSTEPS];
+#pragma unroll
+        for (int s = 0; s < DSTEPS; ++s)
+            qf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Q + (long long)qrow * p.q_row + s * 16 + hf * 8));
+        float w[4];
+        routing_weights_of(p.mode, p.n_id, p.af, p.r + ((long long)grp * p.Sq + qrow) * p.n_id, w);
+        if (p.wsum && head == 0 && hf == 0 && q_valid) {
+            float ws = 0.f;
+            for (int i = 0; i < p.n_id; ++i) ws += w[i];
+            p.wsum[(long long)grp * p.Sq + qrow] = ws;
+        }
+        char* zb = smem + p.n_id * 2 * KV_BYTES + wave * KV_BYTES;
+        constexpr int CHUNKS = ROW_BYTES / 16;
+        f32x16 zacc[DT];
+        for (int id = 0; id < p.n_id; ++id) {
+            const uint32_t kb = lds0 + id * 2 * KV_BYTES, vb = kb + KV_BYTES;
+            // S^T = K . Q^T (32 keys x 32 queries): lane (q = r, hf) gets keys (i & 3) + 8 (i >> 2) + 4 hf
+            bf16x8 kf[DSTEPS];
+#pragma unroll
+            for (int s = 0; s < DSTEPS; ++s) kf[s] = lds_read128<0>(kb + koff[s]);
+            f32x16 sacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+            lgkm_wait<0>();
+#pragma unroll
+            for (int s = 0; s < DSTEPS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sacc, 0, 0, 0);
+            // the V fragments fly under the softmax
+            VFrag<D> fa, fb;
+            uint32_t vbase[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d) vbase[d] = vb + voff[d];
+            v_issue<D, 0>(fa, vbase);
+            v_issue<D, 1>(fb, vbase);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kv = (i & 3) + 8 * (i >> 2) + 4 * hf;
+                if (kv >= p.Skv) sacc[i] = -INFINITY;
+                mx = fmaxf(mx, sacc[i]);
+            }
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            // the reference point attn_tile takes on a first tile: the maximum as a two-term bf16 value
+            const float m_hi = bf2f(f2bf(mx));
+            const float m_lo = bf2f(f2bf(mx - m_hi));
+            const float m_new = m_hi + m_lo;
+            float psum = 0.f;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f((sacc[tt * 8 + e] - m_new) * c);
+                    psum += pv;
+                    pf[tt][e] = (__bf16)pv;
+                }
+            const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(psum), __float_as_uint(psum), false, false);
+            const float sc = w[id] / (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1]));
+            f32x16 oacc[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+            lgkm_wait<2 * DT>();
+            pv_mfma<D>(fa, pf[0], oacc);
+            lgkm_wait<0>();
+            pv_mfma<D>(fb, pf[1], oacc);
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) zacc[d][i] = id == 0 ? fmaf(sc, oacc[d][i], 0.f) : fmaf(sc, oacc[d][i], zacc[d][i]);
+        }
+        // ---- z through this wave's LDS patch, stored as WHOLE head segments: a lane holds 8-byte pieces of its row (d = 32 dt
+        // + 8 gq + 4 hf ..+3); stored as they stand that is 8 DT instructions each touching 32 rows with 16 bytes -- sixteen
+        // partial-line requests per 128-byte segment.  Re-read row-major, 16 bytes per lane: every request a full line.
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                u32x2 o;
+                o[0] = pack2bf(zacc[d][gq * 4 + 0], zacc[d][gq * 4 + 1]);
+                o[1] = pack2bf(zacc[d][gq * 4 + 2], zacc[d][gq * 4 + 3]);
+                *reinterpret_cast<u32x2*>(zb + r * ROW_BYTES + (((4 * d + gq) ^ (r & 7)) << 4) + 8 * hf) = o;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 32 * CHUNKS / 64; ++j) {
+            const int idx = j * 64 + lane, row = idx / CHUNKS, ch = idx % CHUNKS;
+            const u32x4 o = *reinterpret_cast<const u32x4*>(zb + row * ROW_BYTES + ((ch ^ (row & 7)) << 4));
+            if (t * 32 + row < p.Sq) *reinterpret_cast<u32x4*>(Z + (long long)(t * 32 + row) * p.z_row + ch * 8) = o;
+        }
+        __builtin_amdgcn_wave_barrier();                         // the patch is rewritten by the next tile
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_kv_mix32_kernel_d64(MixArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_mix32_body<64>(p, smem);
+}
+__global__ __launch_bounds__(256) void attn_kv_mix32_kernel_d128(MixArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_mix32_body<128>(p, smem);
+}
+
 __global__ __launch_bounds__(256, 2) void attn_kv_mix_kernel_d64(MixArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_mix_body<64>(p, smem);
@@ -938,6 +1116,18 @@ extern "C" int bya_attn_kv_mix(const void* q, const void* k, const void* v, cons
     a.q_grp = d->q_grp; a.q_row = d->q_row; a.k_id = d->k_id; a.k_grp = d->k_grp; a.k_row = d->k_row;
     a.v_id = d->v_id; a.v_grp = d->v_grp; a.v_row = d->v_row; a.z_grp = d->z_grp; a.z_row = d->z_row;
     a.scale_log2 = d->scale * 1.4426950408889634f;
+    const char* e32 = getenv("BYA_KV_MIX32");                    // A/B switch, read per call
+    if (d->Skv <= 32 && !(e32 && e32[0] == '0') && !((uintptr_t)z & 15) && (d->z_grp | d->z_row) % 8 == 0) {
+        // row chunks per (group, head): about three 32-row tiles per wave, and at least ~4 workgroups per CU in total
+        const int n32 = (d->Sq + 31) / 32;
+        int nqc = (n32 + 11) / 12;
+        a.nqt = nqc < 1 ? 1 : nqc;
+        const dim3 grid32((unsigned)((long long)a.nqt * a.heads * a.n_grp));
+        const size_t lds32 = (size_t)(a.n_id * 2 + 4) * 32 * d->head_dim * 2;    // K, V per identity + a z patch per wave
+        if (d->head_dim == 64) BYA_LAUNCH(attn_kv_mix32_kernel_d64, grid32, dim3(256), lds32, stream, a);
+        else BYA_LAUNCH(attn_kv_mix32_kernel_d128, grid32, dim3(256), lds32, stream, a);
+        return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+    }
     const dim3 grid((unsigned)((long long)a.nqt * a.heads * a.n_grp));
     const size_t lds = (size_t)2 * 2 * KV_TILE * d->head_dim * 2;
     if (d->head_dim == 64) BYA_LAUNCH(attn_kv_mix_kernel_d64, grid, dim3(256), lds, stream, a);

@@ -1062,6 +1062,37 @@ def test_attn_kv_mix_equals_attention_then_routed_mix(ops, dev, mode, D, H, n_id
     check(z2.view(N, E), ref, tol=ATTN_TOL, what=f"attn_kv_mix {mode} vs fp32")
 
 
+@pytest.mark.parametrize("mode,D,H,n_id,grp,Sq,Skv", [("audio", 64, 48, 2, 13, 1350, 32), ("audio", 64, 6, 4, 3, 333, 32),
+                                                      ("audio", 64, 5, 3, 2, 97, 17), ("face", 128, 16, 2, 1, 17550, 32),
+                                                      ("face", 128, 2, 1, 1, 31, 32), ("face", 128, 3, 4, 2, 1000, 9)])
+def test_attn_kv_mix_32_key_form_matches_one_tile_per_workgroup(ops, dev, monkeypatch, mode, D, H, n_id, grp, Sq, Skv):
+    """Up to 32 keys per identity bya_attn_kv_mix runs the persistent form (K / V of every identity resident in LDS, every
+    wave walking its own 32-row tiles, z stored as whole head segments through LDS); BYA_KV_MIX32=0 keeps the
+    one-128-row-tile-per-workgroup kernel on 64-key tiles.  Same arithmetic per element -> BIT-IDENTICAL z and weight
+    sums, at the step's two shapes, with ragged row counts, 1-4 identities, fewer than 32 keys, strided q / k / v / z."""
+    E = H * D
+    pad = 64                                                      # rows are wider than the heads they carry
+    qw, zw = rnd((grp, Sq, E + pad), dev, 1), torch.empty(grp, Sq, E + pad, dtype=torch.bfloat16, device=dev)
+    kw, vw = rnd((n_id, grp, Skv, E + pad), dev, 2), rnd((n_id, grp, Skv, E + pad), dev, 3)
+    g = torch.Generator().manual_seed(Sq + n_id)
+    r = torch.sigmoid(torch.randn(grp * Sq, n_id, generator=g)).to(torch.bfloat16).to(dev)
+    af = None if mode == "face" else torch.roll(torch.eye(n_id), 1, dims=1).to(torch.bfloat16).to(dev)
+    W = E + pad
+    def run(flag):
+        monkeypatch.setenv("BYA_KV_MIX32", flag)
+        zw.fill_(3.0)
+        ws = torch.full((grp * Sq,), -1.0, dtype=torch.float32, device=dev)
+        ops.attn_kv_mix(qw[..., pad:], kw[..., :E], vw[..., 8:], r, af, zw[..., 16:], ws, head_dim=D, heads=H, n_id=n_id, n_grp=grp,
+                        Sq=Sq, Skv=Skv, q_strides=(Sq * W, W), k_strides=(grp * Skv * W, Skv * W, W),
+                        v_strides=(grp * Skv * W, Skv * W, W), z_strides=(Sq * W, W), scale=D ** -0.5)
+        torch.cuda.synchronize()
+        return zw.clone(), ws
+    z1, w1 = run("1")
+    z0, w0 = run("0")
+    assert torch.equal(z1, z0) and torch.equal(w1, w0)
+    assert bool((z1[..., :16] == 3.0).all()) and bool((z1[..., 16 + E:] == 3.0).all())     # nothing outside the heads' columns
+
+
 # ----------------------------------------------------------------------------------------------- CFG + scheduler step
 @pytest.mark.parametrize("cfg", [False, True])
 def test_cfg_ddim_step_bit_exact(ops, dev, cfg):
