@@ -421,18 +421,9 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
     const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     const float l_tot = __uint_as_float(lsw[0]) + __uint_as_float(lsw[1]);
     const float inv = 1.0f / l_tot;
-    if (q_valid) {
-        bf16_t* orow = O + (long long)(q0 + r) * p.o_row;
+    bf16_t* orow = O + (long long)(q_valid ? q0 + r : 0) * p.o_row;
 #pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                u32x2 w;
-                w[0] = pack2bf(oacc[d][gq * 4 + 0] * inv, oacc[d][gq * 4 + 1] * inv);
-                w[1] = pack2bf(oacc[d][gq * 4 + 2] * inv, oacc[d][gq * 4 + 3] * inv);
-                *reinterpret_cast<u32x2*>(orow + d * 32 + gq * 8 + hf * 4) = w;
-            }
-    }
+    for (int d = 0; d < DT; ++d) store_o_tile(orow + d * 32, oacc[d], inv, hf, q_valid, p.o_wide != 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -997,18 +988,9 @@ __device__ __forceinline__ void attn_fwd_body2(const AttnArgs& p, char* smem) {
     for (int qb = 0; qb < 2; ++qb) {
         const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qb]), __float_as_uint(l_run[qb]), false, false);
         const float inv = 1.0f / (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1]));
-        if (q_valid[qb]) {
-            bf16_t* orow = O + (long long)(q0 + qb * 32 + r) * p.o_row;
+        bf16_t* orow = O + (long long)(q_valid[qb] ? q0 + qb * 32 + r : 0) * p.o_row;
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    u32x2 w;
-                    w[0] = pack2bf(oacc[qb][d][gq * 4 + 0] * inv, oacc[qb][d][gq * 4 + 1] * inv);
-                    w[1] = pack2bf(oacc[qb][d][gq * 4 + 2] * inv, oacc[qb][d][gq * 4 + 3] * inv);
-                    *reinterpret_cast<u32x2*>(orow + d * 32 + gq * 8 + hf * 4) = w;
-                }
-        }
+        for (int d = 0; d < 2; ++d) store_o_tile(orow + d * 32, oacc[qb][d], inv, hf, q_valid[qb], p.o_wide != 0);
     }
 }
 
@@ -1090,6 +1072,8 @@ extern "C" int bya_attn_fwd(const void* q, const void* k, const void* v, void* o
     a.k_s1 = d->k_s1; a.k_s2 = d->k_s2; a.k_row = d->k_row;
     a.v_s1 = d->v_s1; a.v_s2 = d->v_s2; a.v_row = d->v_row;
     a.o_s1 = d->o_s1; a.o_s2 = d->o_s2; a.o_row = d->o_row;
+    const char* ew = getenv("BYA_ATTN_WIDE_STORE");              // A/B switch, read per call
+    a.o_wide = !((uintptr_t)o & 15) && (d->o_s1 | d->o_s2 | d->o_row) % 8 == 0 && !(ew && ew[0] == '0');
     a.scale_log2 = d->scale * 1.4426950408889634f;
     a.prescaled = d->scores_prescaled;
     if (a.prescaled && d->head_dim != 64) return BYA_ERR_UNSUPPORTED;

@@ -395,18 +395,9 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
             const float l_half = psum[b][0] + psum[b][1];
             const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_half), __float_as_uint(l_half), false, false);
             const float inv = 1.0f / (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1]) - pad_keys);
-            if (q_valid[b]) {
-                bf16_t* orow = Op + (long long)(q0 + b * 32 + r) * p.o_row;
+            bf16_t* orow = Op + (long long)(q_valid[b] ? q0 + b * 32 + r : 0) * p.o_row;
 #pragma unroll
-                for (int d = 0; d < 2; ++d)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        u32x2 w;
-                        w[0] = pack2bf(oacc[b][d][gq * 4 + 0] * inv, oacc[b][d][gq * 4 + 1] * inv);
-                        w[1] = pack2bf(oacc[b][d][gq * 4 + 2] * inv, oacc[b][d][gq * 4 + 3] * inv);
-                        *reinterpret_cast<u32x2*>(orow + d * 32 + gq * 8 + hf * 4) = w;
-                    }
-            }
+            for (int d = 0; d < 2; ++d) store_o_tile(orow + d * 32, oacc[b][d], inv, hf, q_valid[b], p.o_wide != 0);
         }
         if (!SK) break;
     }

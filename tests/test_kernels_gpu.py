@@ -992,6 +992,35 @@ def test_attn_stream_k_matches_one_workgroup_per_item(ops, dev, S, H, monkeypatc
     assert ops.attn_workspace_status() == 0
 
 
+@pytest.mark.parametrize("D,H,Sq,Skv,kw", [(64, 8, 1350, 1350, {}), (64, 3, 333, 97, dict(prescaled=True)),
+                                           (128, 2, 577, 32, {}), (64, 48, 1031, 1031, dict(prescaled=True, score_bound=11.8))])
+@pytest.mark.parametrize("o_off", [0, 4])
+def test_attn_wide_epilogue_stores_match_the_8_byte_ones(ops, dev, monkeypatch, D, H, Sq, Skv, kw, o_off):
+    """The attention epilogues store 16 bytes per lane after a v_permlane32_swap exchange between the half-waves (32
+    contiguous bytes per row and instruction instead of 16); BYA_ATTN_WIDE_STORE=0, or an output that is only 8-byte
+    aligned (o_off = 4 elements), keeps the 8-byte stores.  Same values, same addresses: bit-identical, ragged last
+    q tile included, and nothing written outside the heads' columns (generic d64 / d128 kernels and the joint w4 kernel)."""
+    E = H * D
+    q, k, v = rnd((1, Sq, E), dev, 11), rnd((1, Skv, E), dev, 12), rnd((1, Skv, E), dev, 13)
+    if "score_bound" in kw:
+        nrm = lambda t: (t.float() / t.float().view(1, -1, H, D).norm(dim=-1, keepdim=True).repeat_interleave(D, -1).view(t.shape) * 8)
+        q, k = nrm(q).to(torch.bfloat16), (nrm(k) * (0.125 * 1.4426950408889634)).to(torch.bfloat16)
+    W = E + 16
+    buf = torch.empty(Sq * W + 8, dtype=torch.bfloat16, device=dev)
+    def run(flag):
+        monkeypatch.setenv("BYA_ATTN_WIDE_STORE", flag)
+        buf.fill_(5.0)
+        o = buf[o_off:o_off + Sq * W].view(1, Sq, W)[..., 8:8 + E]
+        ops.attention(q, k, v, o, head_dim=D, heads=H, nb1=1, nb2=1, Sq=Sq, Skv=Skv, q_strides=(0, 0, E), k_strides=(0, 0, E),
+                      v_strides=(0, 0, E), o_strides=(0, 0, W), scale=D ** -0.5, **kw)
+        torch.cuda.synchronize()
+        return buf.clone()
+    a, b = run("1"), run("0")
+    assert torch.equal(a, b)
+    rows = a[o_off:o_off + Sq * W].view(Sq, W)
+    assert bool((rows[:, :8] == 5.0).all()) and bool((rows[:, 8 + E:] == 5.0).all()) and not bool((rows[:, 8:8 + E] == 5.0).all())
+
+
 @pytest.mark.parametrize("mode,D,H,n_id,grp,Sq", [("audio", 64, 48, 2, 13, 150), ("audio", 64, 6, 3, 4, 333),
                                                   ("face", 128, 16, 2, 1, 1000), ("face", 128, 16, 3, 1, 130)])
 def test_attn_kv_mix_equals_attention_then_routed_mix(ops, dev, mode, D, H, n_id, grp, Sq):

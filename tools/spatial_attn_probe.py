@@ -44,6 +44,9 @@ fl = 4.0 * pairs * 8 * pf * pf * 64
 res = {}
 for name, env, kw in [("running_max (today)", {}, {}),
                       ("prescaled running_max", {}, dict(prescaled=True)),
+                      ("prescaled running_max, 8-byte epilogue stores", {"BYA_ATTN_WIDE_STORE": "0"}, dict(prescaled=True)),
+                      ("prescaled running_max (again)", {}, dict(prescaled=True)),
+                      ("prescaled running_max, 8-byte epilogue stores (again)", {"BYA_ATTN_WIDE_STORE": "0"}, dict(prescaled=True)),
                       ("static bound, two-block", {"BYA_ATTN_W4": "0"}, dict(prescaled=True, score_bound=20.0)),
                       ("static bound, w4 per item", {"BYA_ATTN_STREAMK": "0"}, dict(prescaled=True, score_bound=20.0)),
                       ("static bound, w4 stream-K", {}, dict(prescaled=True, score_bound=20.0))]:
@@ -54,5 +57,13 @@ for name, env, kw in [("running_max (today)", {}, {}),
         del os.environ[k_]
     res[name] = dict(us=round(us, 1), tflops=round(fl / us / 1e6, 0))
     print(name, res[name], flush=True)
+run(prescaled=True)
+wide = out.clone()
+os.environ["BYA_ATTN_WIDE_STORE"] = "0"
+out.zero_()
+run(prescaled=True)
+del os.environ["BYA_ATTN_WIDE_STORE"]
+res["wide_stores_bit_identical"] = bool(torch.equal(wide, out))
+print("16-byte epilogue stores bit-identical to the 8-byte ones:", res["wide_stores_bit_identical"])
 if len(sys.argv) > 1:
     json.dump(res, open(sys.argv[1], "w"), indent=1)
