@@ -56,7 +56,16 @@ constexpr int RK = 512;                   // K
 #endif
 constexpr int CH = BYA_ROWGEMM_CH;
 constexpr int NJ = CH / 16;               // 16-column W fragments per chunk
-constexpr int LPC = CH / 4;               // consecutive output columns a lane ends up with
+constexpr int LPC = CH / 4;               // output columns a lane ends up with per chunk (the fused attention kernel below
+                                          // keeps them consecutive: LPC g + 4 j + e)
+// Row GEMMs: which output column of a chunk sits in MFMA tile j, tile row i = 4 g + e (LDS row (i, j) of a stage), and the
+// first of the 8 columns lane group g stores with its u-th 16-byte access.  The four lane groups of a token write 8 g ..+7
+// of the chunk's half u: 64 CONTIGUOUS bytes per row and instruction (and per residual load).  (Until round 4 a lane
+// owned 16 consecutive columns -- 16-byte pieces at a 32-byte stride, eight partial requests per 128-byte line.)
+__device__ __forceinline__ constexpr uint32_t wrow_of(int i, int j) {
+    return (uint32_t)((CH / 2) * (j >> 1) + 8 * (i >> 2) + 4 * (j & 1) + (i & 3));
+}
+__device__ __forceinline__ constexpr uint32_t lane_col(uint32_t g, int u) { return (uint32_t)(CH / 2) * (uint32_t)u + 8u * g; }
 constexpr int STAGE_BYTES = CH * RK * 2;  // 64 / 32 KiB
 #ifndef BYA_ROWGEMM_HB
 #define BYA_ROWGEMM_HB 2                 // 16-row halves per wave: 2 = 32 rows of X in 128 registers, 4 = 64 rows in 256
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(64 * NW, HB == 4 ? 1 : 2) void rowgemm512_kernel(Ro
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
             const int R = wave * SR + r, i = R & 15, j = R >> 4;        // wave-uniform
-            const uint32_t vo = (l16 ^ (uint32_t)(i << 4)) + (uint32_t)(LPC * (i >> 2) + 4 * j + (i & 3)) * (RK * 2);
+            const uint32_t vo = (l16 ^ (uint32_t)(i << 4)) + wrow_of(i, j) * (RK * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dst + r * 1024), 16, vo, col0 * (RK * 2), 0, 0);
         }
     };
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(64 * NW, HB == 4 ? 1 : 2) void rowgemm512_kernel(Ro
                     for (int u = 0; u < NJ / 2; ++u)
                         rv[h][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                             rsR, ((uint32_t)(r0 + h * 16) + to) * (uint32_t)(p.ldres * 2) +
-                                     ((uint32_t)(cc * CH + 8 * u) + LPC * go) * 2, 0, 0));
+                                     ((uint32_t)(cc * CH) + lane_col(go, u)) * 2, 0, 0));
             }
             if (q + 1 < q1) stage_chunk(q + 1, stg ^ 1);
 
@@ -269,7 +278,6 @@ __global__ __launch_bounds__(64 * NW, HB == 4 ? 1 : 2) void rowgemm512_kernel(Ro
 #pragma unroll
             for (int m = 0; m < 4; ++m)
                 wa[m] = ring_base + stg * STAGE_BYTES + to * 1024 + (((go ^ (to & 3)) | ((m ^ (to >> 2)) << 2)) << 4);
-            const uint32_t sc_base = smem_base + go * (LPC * 4);               // LPC floats per lane group per chunk
             f32x4 acc[HB][NJ];
 #pragma unroll
             for (int h = 0; h < HB; ++h)
@@ -296,11 +304,11 @@ __global__ __launch_bounds__(64 * NW, HB == 4 ? 1 : 2) void rowgemm512_kernel(Ro
                         acc[h][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][j], xf[h][ks], acc[h][j], 0, 0, 0);
             }
 
-            // ---- epilogue: lane (g, t) holds token t's columns chunk0 + LPC*g + 4j + e
+            // ---- epilogue: lane (g, t) holds token t's columns chunk0 + lane_col(g, u) + 4 (j & 1) + e, j = 2 u, 2 u + 1
 #pragma unroll
             for (int u = 0; u < NJ / 2; ++u) {                   // 8 columns at a time: j = 2u, 2u+1
                 f32x4 s0, s1, c0, c1;
-                const uint32_t a = sc_base + (uint32_t)(cc * CH + 8 * u) * 4, ac = a + (uint32_t)p.N * 4;
+                const uint32_t a = smem_base + ((uint32_t)(cc * CH) + lane_col(go, u)) * 4, ac = a + (uint32_t)p.N * 4;
                 lds_read_f<0>(s0, a);
                 lds_read_f<16>(s1, a);
                 lds_read_f<0>(c0, ac);
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(64 * NW, HB == 4 ? 1 : 2) void rowgemm512_kernel(Ro
                     if (ov[0] == 0x12345678u && ov[3] == 0x9abcdef0u)
 #endif
                     __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, ((uint32_t)(r0 + h * 16) + to) * (uint32_t)(p.ldc * 2) +
-                                                                        ((uint32_t)(cc * CH + 8 * u) + LPC * go) * 2, 0, 0);
+                                                                        ((uint32_t)(cc * CH) + lane_col(go, u)) * 2, 0, 0);
                 }
             }
         }
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) 
 #pragma unroll
             for (int r = 0; r < SR; ++r) {
                 const int R = wave * SR + r, i = R & 15, j = R >> 4;
-                const uint32_t vo = (l16 ^ (uint32_t)(i << 4)) + (uint32_t)(LPC * (i >> 2) + 4 * j + (i & 3)) * (RK * 2);
+                const uint32_t vo = (l16 ^ (uint32_t)(i << 4)) + wrow_of(i, j) * (RK * 2);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(ring + st * STAGE_BYTES + (wave * SR + r) * 1024), 16, vo,
                                                          (col_base + 64 * st) * (RK * 2), 0, 0);
             }
@@ -448,8 +456,8 @@ __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) 
         uint32_t ro[HB], co[HB];
 #pragma unroll
         for (int h = 0; h < HB; ++h) {
-            ro[h] = row_off(pair, h, RES ? p.ldres : p.ldc) + ((uint32_t)col_base + LPC * go) * 2;
-            co[h] = row_off(pair, h, p.ldc) + ((uint32_t)col_base + LPC * go) * 2;
+            ro[h] = row_off(pair, h, RES ? p.ldres : p.ldc) + ((uint32_t)col_base + lane_col(go, 0)) * 2;
+            co[h] = row_off(pair, h, p.ldc) + ((uint32_t)col_base + lane_col(go, 0)) * 2;
         }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) 
 #pragma unroll
                         for (int u = 0; u < NJ / 2; ++u)
                             rv[st][h][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                rsR, ro[h] + (64 * st + 8 * u) * 2, 0, 0));
+                                rsR, ro[h] + (64 * st + (CH / 2) * u) * 2, 0, 0));
             }
         }
         // the next pair's offsets move up; the pair after it is looked up (outside the descriptor past the end)
@@ -492,13 +500,13 @@ __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) 
             xo[0][h] = xo[1][h];
             xo[1][h] = row_off(pair + 2, h, p.ldx) + go * 16;
         }
-        // ---- epilogue: lane (g, t) holds token t's columns col_base + 64 st + LPC g + 4 j + e
+        // ---- epilogue: lane (g, t) holds token t's columns col_base + 64 st + lane_col(g, u) + 4 (j & 1) + e
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int u = 0; u < NJ / 2; ++u) {
                 f32x4 c0, c1;
-                const uint32_t ac = smem_base + (uint32_t)(128 + 64 * st + 8 * u + LPC * go) * 4;
+                const uint32_t ac = smem_base + ((uint32_t)(128 + 64 * st) + lane_col(go, u)) * 4;
                 lds_read_f<0>(c0, ac);
                 lds_read_f<16>(c1, ac);
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1));
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) 
                     u32x4 ov;
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) ov[w2] = pack2bf(v[2 * w2], v[2 * w2 + 1]);
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, co[h] + (64 * st + 8 * u) * 2, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, co[h] + (64 * st + (CH / 2) * u) * 2, 0, 0);
                 }
             }
     }
