@@ -17,7 +17,7 @@ SOURCES = ["gemm.hip", "gemm_v4.hip", "gemm_fp8.hip", "gemm_fp8_v4.hip", "attn.h
 # MFMA-heavy workgroups resident on the same CUs (19-20 of 20 runs; 0 of 20 for the same source built with
 # -fno-slp-vectorize; tools/timeslice/repro.py, profiles/r2_timeslice_repro_run*.json).  These
 # kernels are HBM-bound, the packed forms bought nothing.
-NO_SLP_SOURCES = {"norm.hip", "misc.hip", "router.hip", "gemm_fp8.hip", "vae.hip"}     # (gemm_fp8: its row quantiser)
+NO_SLP_SOURCES = {"norm.hip", "misc.hip", "router.hip", "gemm_fp8.hip", "vae.hip", "rowgemm.hip"}     # (gemm_fp8: its row quantiser)
 # translation units whose kernels keep their accumulators in AGPRs (one wave per SIMD, 512 registers)
 AGPR_SOURCES = {"gemm_v4.hip", "gemm_fp8_v4.hip", "attn_w4.hip"}
 

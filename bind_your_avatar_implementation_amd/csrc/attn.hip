@@ -1108,6 +1108,13 @@ extern "C" int bya_attn_kv_mix(const void* q, const void* k, const void* v, cons
         a.nqt = nqc < 1 ? 1 : nqc;
         const dim3 grid32((unsigned)((long long)a.nqt * a.heads * a.n_grp));
         const size_t lds32 = (size_t)(a.n_id * 2 + 4) * 32 * d->head_dim * 2;    // K, V per identity + a z patch per wave
+        if (lds32 > 64 * 1024) {                                 // four identities at head_dim 128: 96 KiB
+            static std::atomic<unsigned long long> big64{0}, big128{0};
+            const int rc = d->head_dim == 64
+                ? bya_allow_big_lds(reinterpret_cast<const void*>(attn_kv_mix32_kernel_d64), 160 * 1024, big64)
+                : bya_allow_big_lds(reinterpret_cast<const void*>(attn_kv_mix32_kernel_d128), 160 * 1024, big128);
+            if (rc != BYA_OK) return rc;
+        }
         if (d->head_dim == 64) BYA_LAUNCH(attn_kv_mix32_kernel_d64, grid32, dim3(256), lds32, stream, a);
         else BYA_LAUNCH(attn_kv_mix32_kernel_d128, grid32, dim3(256), lds32, stream, a);
         return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
