@@ -449,12 +449,11 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
     // Pipelined 256x256 tiles, one workgroup per CU.  When the last round of tiles would leave most CUs idle
     // (N = 3072 at 17776 rows: 840 tiles = 3.28 rounds), the rows of the complete rounds go to the pipelined kernel
     // and the remaining rows to the 128x128 kernel, whose many small tiles fill all CUs at once.
-    static const bool no_tail = getenv("BYA_GEMM_NO_TAIL") != nullptr;
     const int tn = (a.N + 255) / 256, tm = (a.M + 255) / 256;
     const long long tiles = (long long)tm * tn;
     const long long full = tiles / 256;
     // (with a split-K workspace the persistent kernel cuts that last round along K itself: no row split)
-    if (!no_tail && !splitk && d->batch == 1 && full >= 1 && tiles % 256 != 0) {
+    if (!splitk && d->batch == 1 && full >= 1 && tiles % 256 != 0) {
         const int main_tm = (int)(full * 256 / tn);
         const int m0 = main_tm * 256;
         if (m0 > 0 && m0 < a.M) {

@@ -106,8 +106,7 @@ extern "C" int bya_gemm_fp8(const void* A8, const float* a_scale, const void* W8
     const char* kv = getenv("BYA_FP8_KERNEL");
     const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch;
     const bool big = !(kv && kv[0] == '1') && tiles256 >= 200;        // (about a round of its 256 workgroups, or more)
-    const char* gm_env = getenv("BYA_FP8_GM");
-    const int gm = gm_env ? atoi(gm_env) : 4;
+    const int gm = 4;                                                 // row-tiles per group of the persistent kernel's tile order
     return gemm_row_chunks(a, d->batch, 1, [&](const GemmArgs& piece, int batch, long long row0) {
         if (big && bya_gemm256p_fp8_eligible(&piece))
             return bya_launch_gemm256p_fp8(&piece, a_scale + row0, w_scale, batch, gm, stream);

@@ -9,7 +9,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK8 = 128;          // fp8 elements (= bytes) per K-tile
-constexpr int FP8_GROUP_M = 8;    // row-tiles per group of the tile order (BYA_FP8_GM overrides per call)
+constexpr int FP8_GROUP_M = 8;    // row-tiles per group of the tile order (2 / 4 / 8 measured level: tools/fp8_gemm_zeros_probe.py)
 constexpr float FP8_MAX = 448.0f; // largest finite e4m3fn
 
 template <int ROWS, int NWAVES>
@@ -130,9 +130,7 @@ int launch_fp8(const GemmArgs& a, const float* sa, const float* sw, int batch, h
     static std::atomic<unsigned long long> attr_done{0};
     if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm_fp8_kernel<BM, BN, WAVES_M, WAVES_N>), (int)lds, attr_done) != BYA_OK)
         return BYA_ERR_LAUNCH;
-    const char* gm_env = getenv("BYA_FP8_GM");              // A/B switch, read per call
-    int gm = gm_env ? atoi(gm_env) : FP8_GROUP_M;
-    gm = gm < 1 ? 1 : gm;
+    const int gm = FP8_GROUP_M;
     BYA_LAUNCH((gemm_fp8_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(64 * WAVES_M * WAVES_N), lds, s, a, sa, sw, gm);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

@@ -26,7 +26,7 @@ on the receiver -- capturable in a hipGraph, ~5 us of launch instead of ~20 us p
 projection travels as ONE exchange instead of three.  ``torch`` keeps the round-3 path: ``torch.distributed`` collectives
 (RCCL on the ``nccl`` backend, host-staged on ``gloo``).
 
-``FORCE_COLLECTIVES`` (``BYA_SP_FORCE_COLLECTIVES=1``): take the collective code path even with ONE rank -- a 1-rank
+``FORCE_COLLECTIVES`` (a module attribute, set by tests/test_rccl_gpu.py): take the collective code path even with ONE rank -- a 1-rank
 RCCL communicator on one GPU then executes every exchange (symbol resolution, dtypes, split lists, async handles on the
 communicator's stream) although nothing moves between devices; used by ``tests/test_rccl_gpu.py``.
 """
@@ -37,7 +37,7 @@ import torch
 import torch.distributed as dist
 
 
-FORCE_COLLECTIVES = os.environ.get("BYA_SP_FORCE_COLLECTIVES") == "1"
+FORCE_COLLECTIVES = False
 COLLECTIVE_CALLS = {}          # kind -> number of device-side collectives issued (not host-staged ones); read by the tests
 
 

@@ -459,17 +459,11 @@ class BindyouravatarTransformer3DModel(nn.Module):
         resident sequence numbers: bya_p2p_push / bya_p2p_wait), replay from a hipGraph.  With the ``torch`` transport the
         sharded step stays eager: capturing it needs RCCL collectives inside a stream capture, and on this stack (PyTorch
         2.10-ROCm 7.0, RCCL of ROCm 7.2) even a lone ``all_to_all_single`` under ``torch.cuda.graph`` never returns
-        (tools/rccl_graph_probe.py, profiles/r3_rccl_graph_probe.txt); BYA_GRAPH_SHARDED=1 lifts that guard for a stack where
-        the probe passes."""
+        (tools/rccl_graph_probe.py, profiles/r3_rccl_graph_probe.txt)."""
         group = getattr(self, "_seq_group", None)
         if getattr(self, "_seq_world", 1) == 1 and group is None:
             return True
-        if getattr(self, "_seq_p2p", None) is not None:
-            return True
-        if os.environ.get("BYA_GRAPH_SHARDED") != "1":
-            return False
-        import torch.distributed as dist
-        return dist.is_initialized() and dist.get_backend(group) == "nccl"
+        return getattr(self, "_seq_p2p", None) is not None
 
     def set_mute_audio_embeds(self, ae_mute):
         """The "mute" wav2vec embedding [>= 4 * latent_frames + 1, 12, 768] that completes a single-stream (4-D)

@@ -164,3 +164,17 @@ def test_valu_only_kernels_hold_no_packed_fp32(lib_path):
             assert src in recorded and n <= 1.25 * recorded[src] + 16, (src, n, recorded.get(src))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_library_path_override_fails_loudly_when_the_file_is_missing(tmp_path):
+    """BYA_HIP_LIB points the loader at another build of the library (A/B runs of two builds in one call); a path that does
+    not exist must fail like a missing in-tree build does -- there is no fallback to look for."""
+    import subprocess
+    import sys
+    code = ("import torch\n"
+            "from bind_your_avatar_implementation_amd import _hip\n"
+            "try:\n    _hip.load()\nexcept Exception as e:\n    print(type(e).__name__, str(e)[:200]); raise SystemExit(3)\n"
+            "print('loaded')\n")
+    env = dict(os.environ, BYA_HIP_LIB=str(tmp_path / "nope.so"), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=300)
+    assert r.returncode == 3 and "nope.so" in r.stdout and "no fallback" in r.stdout, (r.stdout, r.stderr[-500:])

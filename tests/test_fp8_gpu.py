@@ -120,14 +120,20 @@ def test_gemm_fp8_persistent_kernel_equals_the_128_tile_kernel(dev, monkeypatch)
     assert torch.isfinite(outs["v4"].float()).all() and frac < 1e-4 and float(diff.max()) <= 0.0625
 
 
-def test_fp8_linear_selection(dev):
+def test_fp8_linear_selection(dev, monkeypatch):
     """enable_fp8_weights(linears=...): the default is the four DiT Linears, "all" adds the two query projections, an unknown
-    name is refused when the engine packs."""
+    name is refused when the engine packs; BYA_FP8_LINEARS is the same choice for a caller that cannot reach the model
+    object (a comma list, read when the engine packs; an explicit ``linears=`` wins)."""
     from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel
     from bind_your_avatar_implementation_amd.synth import synth_inputs
     from test_forward_gpu import SMALL_KW, to_dev
     model = BindyouravatarTransformer3DModel(**SMALL_KW, device=dev).init_synthetic(seed=2, fast=True)
     gi = to_dev(synth_inputs(batch=1, frames=3, height=16, width=24, seed=3), dev)
+    monkeypatch.setenv("BYA_FP8_LINEARS", "ff2,pq")
+    model.enable_fp8_weights()
+    model(**gi)
+    assert set(model._engine.w8) == {"ff2", "pq"}
+    monkeypatch.delenv("BYA_FP8_LINEARS")
     model.enable_fp8_weights()
     model(**gi)
     assert set(model._engine.w8) == {"qkv", "out", "ff1", "ff2"}

@@ -711,6 +711,29 @@ def test_qknorm_rope(ops, dev):
     check(k, 0.18 * ref(k0, kw, kb), what="qknorm_rope k * k_scale (single rounding)")
 
 
+@pytest.mark.parametrize("env", [{"BYA_QKNORM_DBG": "1"}, {"BYA_QKNORM_DBG": "2"}, {"BYA_QKNORM_TABLE_SC1": "1"}])
+def test_qknorm_rope_diagnostic_variants_are_bit_identical(ops, dev, monkeypatch, env):
+    """The experiment instances of bya_qknorm_rope that tools/timeslice/repro.py switches between (the cos / sin loads
+    drained before anything else touches their address registers; 32-bit index arithmetic; table rows read past the
+    vector L1) differ in scheduling and cache policy only: same bits as the product kernel."""
+    from bind_your_avatar_implementation_amd.synth import rope_table
+    B, T, H, grid = 1, 226, 48, (2, 6, 10)
+    S = T + grid[0] * grid[1] * grid[2]
+    q0, k0 = rnd((B, S, H * 64), dev, 70), rnd((B, S, H * 64), dev, 71)
+    qw, qb, kw, kb = (rnd((64,), dev, 72 + i, 0.3) + (1 if i % 2 == 0 else 0) for i in range(4))
+    cos, sin = (t.to(dev) for t in rope_table(grid))
+    def run():
+        q, k = q0.clone(), k0.clone()
+        ops.qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads=H, text_rows=T, eps=1e-6, k_scale=0.18)
+        torch.cuda.synchronize()
+        return q, k
+    qa, ka = run()
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    qb_, kb_ = run()
+    assert torch.equal(qa, qb_) and torch.equal(ka, kb_)
+
+
 # ----------------------------------------------------------------------------------------------- small linears
 def test_linear_small_m_and_timestep(ops, dev):
     B, dim = 2, 3072
