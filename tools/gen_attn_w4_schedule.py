@@ -43,7 +43,8 @@ RB = 128                                                   # bytes per K / V row
 # become meaningless, only the time is read.  1: v_exp -> v_mov, 2: no row-sum adds, 4: no converts, 8: no LDS reads / DMA /
 # rendezvous inside the loop, 16: Q fragments in VGPRs instead of AGPRs, 32: no VALU at all; finer: 128: no s_barrier,
 # 256: no LDS-DMA, 512: no ds_reads, 1024: no lgkmcnt waits, 2048: no vmcnt wait, 4096: no K reads, 8192: no V reads,
-# 16384: all V reads in one burst behind the first MFMA of QK_1.
+# 16384: all V reads in one burst behind the first MFMA of QK_1, 32768: V fragments by eight ds_read_b128 instead of sixteen
+# ds_read_b64_tr_b16 (what a V^T layout in memory would allow; addresses meaningless here).
 ABLATE = 0
 
 
@@ -136,7 +137,12 @@ def group_a(variant, b):
             acc = st.out(f"sacc[{sb}][{u}]")
             k, q = st.inp(f"kf[{u}][{s}]"), st.inp(f"qf[{b}][{s}]", "v" if ABLATE & 16 else "a")
             st.add("v_mfma_f32_32x32x16_bf16 {0}, {1}, {2}, " + ("0" if s == 0 else "{0}"), acc, k, q)
-            if b == 1 and not ABLATE & (8 | 512 | 8192):
+            if b == 1 and ABLATE & 32768:
+                for j in ((2 * g, 2 * g + 1) if g < 4 else ()):
+                    ks, d = divmod(j, 2)
+                    # the K-fragment address pattern (a conflict-free b128 A-operand read of a [64][128 B] tile), on the V tile
+                    st.add("ds_read_b128 {0}, {1} offset:" + str(d * 32 * RB + 64 * RB), st.out(f"vq[{d}][{ks}]"), st.inp(f"kaddr[{ks}]"))
+            elif b == 1 and not ABLATE & (8 | 512 | 8192):
                 for d, ks, h in (reads if g == 0 else []) if ABLATE & 16384 else reads[cut[g]:cut[g + 1]]:
                     st.add("ds_read_b64_tr_b16 {0}, {1} offset:" + str((ks * 16 + h * 8) * RB),
                            st.out(f"vh[{d}][{ks}][{h}]"), st.inp(f"vaddr[{d}]"))
@@ -154,7 +160,10 @@ def group_b(variant, b):
     pv_blk, pv_pb = (b - 1) % 4, (b - 1) & 1
     for ks in range(4):
         for d in range(2):
-            st.pre.append(f"const u32x4 vv{d}_{ks} = {{vh[{d}][{ks}][0][0], vh[{d}][{ks}][0][1], vh[{d}][{ks}][1][0], vh[{d}][{ks}][1][1]}};")
+            if ABLATE & 32768:
+                st.pre.append(f"const u32x4 vv{d}_{ks} = vq[{d}][{ks}];")
+            else:
+                st.pre.append(f"const u32x4 vv{d}_{ks} = {{vh[{d}][{ks}][0][0], vh[{d}][{ks}][0][1], vh[{d}][{ks}][1][0], vh[{d}][{ks}][1][1]}};")
     for g in range(8):
         ks, d = divmod(g, 2)
         acc = st.out(f"oacc[{pv_blk}][{d}]", "+a")
