@@ -134,6 +134,92 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
     }
 }
 
+// Affine / AdaLN form with the parameter vectors in REGISTERS (the DiT's norm1 / norm2 / norm_out and the audio / face norm_q:
+// ~150 launches per step, 218 MB each).  layernorm_kernel above re-reads w, b, scale and shift for every row -- 24 KB of L1 / L2 traffic per 6-KB row, four
+// times the row itself.  Here a wave owns a contiguous range of rows and keeps  A = w (1 + scale),  B = b (1 + scale) + shift
+// in fp32 (2 x 48 registers at D = 3072); they are rebuilt when the range crosses the text / video split or a batch
+// boundary (different modulation vectors).  Per element:  y = fma((x - mean) rstd, A, B)  -- the same value as
+// ((x - mean) rstd w + b)(1 + scale) + shift up to fp32 reassociation (one rounding to bf16 either way).
+template <int NV, bool MOD>
+__global__ __launch_bounds__(256) void layernorm_adaln_rows_kernel(LnArgs p, int rows_per_wave) {
+    constexpr int VEC = 8, D = 64 * VEC * NV;
+    const int lane = threadIdx.x & 63;
+    const long long total = p.rows_per_batch * p.batch;
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long r0 = gw * rows_per_wave, r1 = r0 + rows_per_wave;
+    if (r1 > total) r1 = total;
+    float A[NV][VEC], B[NV][VEC];
+    long long cur_set = -1;
+    for (long long row_lin = r0; row_lin < r1; ++row_lin) {
+        const int z = (int)(row_lin / p.rows_per_batch);
+        const long long row = row_lin - (long long)z * p.rows_per_batch;
+        const bool first = row < p.split;
+        const long long set = 2 * (long long)z + (first ? 0 : 1);
+        const bf16_t* x = p.x + z * p.x_bs + row * p.ldx;
+        float v[NV][VEC];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) load_vec<VEC>(x + (i * 64 + lane) * VEC, v[i]);
+        if (set != cur_set) {
+            cur_set = set;
+            const bf16_t* shift = MOD ? (first ? p.shift0 : p.shift1) + z * p.mod_bs : nullptr;
+            const bf16_t* scale = MOD ? (first ? p.scale0 : p.scale1) + z * p.mod_bs : nullptr;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int col = (i * 64 + lane) * VEC;
+                float wv[VEC], bv[VEC];
+                load_vec<VEC>(p.w + col, wv);
+                load_vec<VEC>(p.b + col, bv);
+                if constexpr (MOD) {
+                    float sc[VEC], sh[VEC];
+                    load_vec<VEC>(scale + col, sc);
+                    load_vec<VEC>(shift + col, sh);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        A[i][e] = wv[e] * (1.0f + sc[e]);
+                        B[i][e] = fmaf(bv[e], 1.0f + sc[e], sh[e]);
+                    }
+                } else {                                       // plain affine LayerNorm: the same fma as layernorm_kernel
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { A[i][e] = wv[e]; B[i][e] = bv[e]; }
+                }
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sum += v[i][e];
+        const float mean = wave_sum(sum) * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+        const float rstd = rsqrtf(wave_sum(sq) * (1.0f / D) + p.eps);
+        bf16_t* y = p.y + z * p.y_bs + row * p.ldy;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = fmaf((v[i][e] - mean) * rstd, A[i][e], B[i][e]);
+            *reinterpret_cast<u32x4*>(y + (i * 64 + lane) * VEC) = pack8(o);
+        }
+    }
+}
+
+template <int NV>
+int launch_ln_adaln_rows(const LnArgs& a, hipStream_t s) {
+    const long long total = a.rows_per_batch * a.batch;
+    // about 16 waves per CU in flight (4096 waves), at least 2 rows each so the parameter set-up is amortised
+    int rpw = (int)((total + 4095) / 4096);
+    rpw = rpw < 2 ? 2 : rpw;
+    const long long waves = (total + rpw - 1) / rpw;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (a.shift0) BYA_LAUNCH((layernorm_adaln_rows_kernel<NV, true>), grid, dim3(256), 0, s, a, rpw);
+    else BYA_LAUNCH((layernorm_adaln_rows_kernel<NV, false>), grid, dim3(256), 0, s, a, rpw);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
 template <int VEC, int NV, bool Q8 = false>
 int launch_ln(const LnArgs& a, hipStream_t s) {
     const long long total = a.rows_per_batch * a.batch;
@@ -263,7 +349,12 @@ extern "C" int bya_layernorm(const void* x, void* y, const void* w, const void* 
         case 768: return launch_ln<4, 3>(a, stream);
         case 1024: return launch_ln<8, 2>(a, stream);
         case 2048: return launch_ln<8, 4>(a, stream);
-        case 3072: return launch_ln<8, 6>(a, stream);
+        case 3072: {
+            const char* e = getenv("BYA_LN_ROWS");               // A/B switch, read per call
+            // (whatever the row count: a shard of the sequence must round exactly like the whole)
+            if (a.w && a.b && !(e && e[0] == '0')) return launch_ln_adaln_rows<6>(a, stream);
+            return launch_ln<8, 6>(a, stream);
+        }
         default: return BYA_ERR_UNSUPPORTED;
     }
 }

@@ -683,6 +683,47 @@ def test_layernorm_adaln_zero(ops, dev):
     check(out, ref, what="AdaLN-zero")
 
 
+def test_layernorm_adaln_rows_kernel(ops, dev, monkeypatch):
+    """The AdaLN LayerNorm of the DiT width keeps A = w (1 + scale), B = b (1 + scale) + shift in registers and walks several
+    rows per wave (BYA_LN_ROWS=0: one row per wave, parameters re-read per row).  Against fp32 at the usual bar; against
+    the old kernel at most one bf16 step apart on a handful of elements (fp32 reassociation); and INDEPENDENT of how the rows
+    are cut into launches -- a shard of the sequence must round exactly like the whole (ranges that cross the text / video
+    split and a batch boundary, strided input and output)."""
+    B, S, T, D = 2, 1237, 226, 3072
+    xw, ow = rnd((B, S, D + 64), dev, 63), torch.empty(B, S, D + 64, dtype=torch.bfloat16, device=dev)
+    x, out = xw[..., 32:32 + D], ow[..., 8:8 + D]
+    w, b = rnd((D,), dev, 64, 0.2) + 1, rnd((D,), dev, 65, 0.2)
+    mods = rnd((B, 6 * D), dev, 66, 0.3)
+    kw = dict(eps=1e-5, shift0=mods[:, 3 * D:], scale0=mods[:, 4 * D:], shift1=mods[:, 0:], scale1=mods[:, D:],
+              mod_batch_stride=mods.stride(0))
+    ow.fill_(9.0)
+    ops.layernorm(x, out, w, b, split=T, **kw)
+    rows = out.clone()
+    assert bool((ow[..., :8] == 9.0).all()) and bool((ow[..., 8 + D:] == 9.0).all())
+    ln = F.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5)
+    m = mods.float()
+    ref = torch.cat([ln[:, :T] * (1 + m[:, None, 4 * D:5 * D]) + m[:, None, 3 * D:4 * D],
+                     ln[:, T:] * (1 + m[:, None, D:2 * D]) + m[:, None, 0:D]], 1)
+    check(rows, ref, what="AdaLN rows kernel")
+    monkeypatch.setenv("BYA_LN_ROWS", "0")
+    ops.layernorm(x, out, w, b, split=T, **kw)
+    monkeypatch.delenv("BYA_LN_ROWS")
+    d = (out.float() - rows.float()).abs()
+    assert float((d > 0).float().mean()) < 1e-3 and bool((d <= 2.0 ** -7 * rows.float().abs().clamp_min(2.0 ** -7)).all())
+    # without modulation the rows kernel is the plain affine LayerNorm, bit for bit the one-row-per-wave kernel
+    a1, a0 = torch.empty(B, S, D, dtype=torch.bfloat16, device=dev), torch.empty(B, S, D, dtype=torch.bfloat16, device=dev)
+    ops.layernorm(x, a1, w, b, eps=1e-5)
+    monkeypatch.setenv("BYA_LN_ROWS", "0")
+    ops.layernorm(x, a0, w, b, eps=1e-5)
+    monkeypatch.delenv("BYA_LN_ROWS")
+    assert torch.equal(a1, a0)
+    # any cut of the rows into launches gives the same bits
+    for lo, hi in ((0, 100), (100, 226), (226, 227), (227, 900), (900, S)):
+        part = torch.empty(B, hi - lo, D, dtype=torch.bfloat16, device=dev)
+        ops.layernorm(x[:, lo:hi], part, w, b, split=max(0, min(T - lo, hi - lo)), **kw)
+        assert torch.equal(part, rows[:, lo:hi]), (lo, hi)
+
+
 def test_qknorm_rope(ops, dev):
     from bind_your_avatar_implementation_amd.synth import rope_table
     B, T, H = 2, 26, 48
