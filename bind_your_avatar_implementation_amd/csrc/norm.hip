@@ -75,19 +75,31 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
         float o[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = (v[i][e] - mean) * rstd;
-        if (p.w) {
-            float wv[VEC], bv[VEC];
+        if (p.w && p.b && shift) {
+            // affine + modulation as ONE fma with A = w (1 + scale), B = b (1 + scale) + shift: the arithmetic of
+            // layernorm_adaln_rows_kernel below (which keeps A, B in registers), so the two kernels and the fp8 form agree bit for bit
+            float wv[VEC], bv[VEC], sc[VEC], sh[VEC];
             load_vec<VEC>(p.w + col, wv);
-            if (p.b) load_vec<VEC>(p.b + col, bv);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) o[e] = o[e] * wv[e] + (p.b ? bv[e] : 0.f);
-        }
-        if (shift) {
-            float sc[VEC], sh[VEC];
+            load_vec<VEC>(p.b + col, bv);
             load_vec<VEC>(scale + col, sc);
             load_vec<VEC>(shift + col, sh);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) o[e] = o[e] * (1.0f + sc[e]) + sh[e];
+            for (int e = 0; e < VEC; ++e) o[e] = fmaf(o[e], wv[e] * (1.0f + sc[e]), fmaf(bv[e], 1.0f + sc[e], sh[e]));
+        } else {
+            if (p.w) {
+                float wv[VEC], bv[VEC];
+                load_vec<VEC>(p.w + col, wv);
+                if (p.b) load_vec<VEC>(p.b + col, bv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = o[e] * wv[e] + (p.b ? bv[e] : 0.f);
+            }
+            if (shift) {
+                float sc[VEC], sh[VEC];
+                load_vec<VEC>(scale + col, sc);
+                load_vec<VEC>(shift + col, sh);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = o[e] * (1.0f + sc[e]) + sh[e];
+            }
         }
         if constexpr (Q8) {
             // keep the result -- rounded to bf16 exactly as the bf16 kernel would store it -- for the row maximum
@@ -138,8 +150,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs p) {
 // ~150 launches per step, 218 MB each).  layernorm_kernel above re-reads w, b, scale and shift for every row -- 24 KB of L1 / L2 traffic per 6-KB row, four
 // times the row itself.  Here a wave owns a contiguous range of rows and keeps  A = w (1 + scale),  B = b (1 + scale) + shift
 // in fp32 (2 x 48 registers at D = 3072); they are rebuilt when the range crosses the text / video split or a batch
-// boundary (different modulation vectors).  Per element:  y = fma((x - mean) rstd, A, B)  -- the same value as
-// ((x - mean) rstd w + b)(1 + scale) + shift up to fp32 reassociation (one rounding to bf16 either way).
+// boundary (different modulation vectors).  Per element:  y = fma((x - mean) rstd, A, B)  -- ((x - mean) rstd w + b)(1 + scale)
+// + shift up to fp32 reassociation, one rounding to bf16; layernorm_kernel computes the very same fma, so the kernels agree.
 template <int NV, bool MOD>
 __global__ __launch_bounds__(256) void layernorm_adaln_rows_kernel(LnArgs p, int rows_per_wave) {
     constexpr int VEC = 8, D = 64 * VEC * NV;
