@@ -7,6 +7,7 @@
 //                      tiles, so each wave keeps one (sequence, head) in registers with the head dim on the lanes.
 #include "bya_common.h"
 #include "../../include/bya.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -90,6 +91,116 @@ __global__ __launch_bounds__(256) void router_scores_kernel(const bf16_t* __rest
             *reinterpret_cast<u32x4*>(orow + f0) = pack8(o);
             *reinterpret_cast<u32x4*>(orow + f0 + 8) = pack8(o + 8);
         }
+}
+
+// router_scores with the identity's keys in LDS.  The kernel above is one wave round of DEPENDENT loads: every wave fetches its
+// 64 q fragments and, again, all 128 key fragments (128 KB from L2) with ~30 registers left for loads in flight beside the 128
+// accumulators -- 98 us for 4.6 GFLOP and ~220 MB.  Here a workgroup of 8 waves owns ONE identity: its 32 re-projected keys
+// (32 x 4 KB = 128 KB) are staged once by LDS-DMA (source-side XOR swizzle of the 16-byte chunk index with row & 15: the
+// sixteen rows of a fragment read hit sixteen different chunks), and the waves walk the identity's 16-token tiles on their
+// own: per tile 64 global loads (q only; nothing else competes for the vector-memory queue), 128 ds_read_b128, 128 MFMAs,
+// the same LayerNorm + positional epilogue.  Same MFMA order per accumulator -> bit-identical.
+__global__ __launch_bounds__(512) void router_scores_lds_kernel(const bf16_t* __restrict__ qr, const bf16_t* __restrict__ kr,
+                                                                const bf16_t* __restrict__ ln_w, const bf16_t* __restrict__ ln_b,
+                                                                const bf16_t* __restrict__ pos, bf16_t* __restrict__ out,
+                                                                int n_id, long long N, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int id = blockIdx.x % n_id, wi = blockIdx.x / n_id, per_id = gridDim.x / n_id;
+    if (wi >= per_id) return;                                  // (grid not a multiple of n_id: the last few workgroups idle)
+    constexpr int ROWB = R_QK * 2;                             // 4096 bytes per key row
+    {   // rows 4 wave .. 4 wave + 3, four 1-KiB pieces each; LDS chunk p of row r holds source chunk p ^ (r & 15)
+        const char* ksrc = reinterpret_cast<const char*>(kr + (long long)id * R_TOK * R_QK);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wave * 4 + rr, pchunk = 64 * i + lane;
+                const char* g = ksrc + (long long)r * ROWB + ((pchunk ^ (r & 15)) << 4);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(smem + r * ROWB + i * 1024), 16, 0, 0);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                           // the keys are in place; no barrier below
+
+    const int c = lane & 15, g = lane >> 4;
+    const long long tiles = (N + 15) / 16;
+    const uint32_t kbase = (uint32_t)(uintptr_t)LDS_PTR(smem) + c * ROWB;
+    for (long long t = (long long)wi * 8 + wave; t < tiles; t += (long long)per_id * 8) {
+        long long n = t * 16 + c;
+        const bool valid = n < N;
+        n = valid ? n : N - 1;
+        const bf16_t* qrow = qr + n * R_QK + g * 8;
+        f32x4 acc[R_HEADS][2];
+        // q fragments two heads ahead (8 loads = 8 KB in flight per wave; four heads ahead measured the same); the scheduling fences keep hipcc from hoisting all 64
+        // loads and 128 LDS reads of the unrolled tile to its top (1.8 KB of scratch per lane when it is left alone)
+        bf16x8 qb[3][4];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qb[hh][ks] = *reinterpret_cast<const bf16x8*>(qrow + hh * R_HD + ks * 32);
+#pragma unroll
+        for (int h = 0; h < R_HEADS; ++h) {
+            if (h + 2 < R_HEADS) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    qb[(h + 2) % 3][ks] = *reinterpret_cast<const bf16x8*>(qrow + (h + 2) * R_HD + ks * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint32_t a = kbase + (uint32_t)(((16 * h + 4 * ks + g) ^ c) << 4);
+                const bf16x8 k0 = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(a);
+                const bf16x8 k1 = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(a + 16 * ROWB);
+                acc[h][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qb[h % 3][ks], acc[h][0], 0, 0, 0);
+                acc[h][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qb[h % 3][ks], acc[h][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int h = 0; h < R_HEADS; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum += acc[h][j][e];
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / R_FEAT);
+        float sq = 0.f;
+#pragma unroll
+        for (int h = 0; h < R_HEADS; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = acc[h][j][e] - mean; sq += d * d; }
+        sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
+        const float rstd = rsqrtf(sq * (1.0f / R_FEAT) + eps);
+        if (!valid) continue;
+        bf16_t* orow = out + ((long long)id * N + n) * R_FEAT;
+        const bf16_t* prow = pos + n * R_FEAT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tok = 16 * j + 4 * g + e;
+                const int f0 = tok * R_HEADS;
+                float wv[16], bv[16], pv[16], o[16];
+                unpack8(*reinterpret_cast<const u32x4*>(ln_w + f0), wv);
+                unpack8(*reinterpret_cast<const u32x4*>(ln_w + f0 + 8), wv + 8);
+                unpack8(*reinterpret_cast<const u32x4*>(ln_b + f0), bv);
+                unpack8(*reinterpret_cast<const u32x4*>(ln_b + f0 + 8), bv + 8);
+                unpack8(*reinterpret_cast<const u32x4*>(prow + f0), pv);
+                unpack8(*reinterpret_cast<const u32x4*>(prow + f0 + 8), pv + 8);
+#pragma unroll
+                for (int h = 0; h < R_HEADS; ++h)
+                    o[h] = bf2f(f2bf((acc[h][j][e] - mean) * rstd * wv[h] + bv[h])) + pv[h];
+                *reinterpret_cast<u32x4*>(orow + f0) = pack8(o);
+                *reinterpret_cast<u32x4*>(orow + f0 + 8) = pack8(o + 8);
+            }
+    }
 }
 
 // r[n, id] = sigmoid(x[id, n, :] . w + b); D = 512: one wave per row, 8 elements per lane.
@@ -254,6 +365,16 @@ extern "C" int bya_router_scores(const void* qr, const void* kr, const void* ln_
     if (heads != R_HEADS || face_tokens != R_TOK) return BYA_ERR_UNSUPPORTED;
     if (((uintptr_t)qr | (uintptr_t)kr | (uintptr_t)ln_w | (uintptr_t)ln_b | (uintptr_t)pos_emb | (uintptr_t)out) & 15)
         return BYA_ERR_ALIGN;
+    const char* el = getenv("BYA_ROUTER_SCORES_LDS");            // A/B switch, read per call
+    if (N >= 4096 && n_id <= 256 && !(el && el[0] == '0')) {
+        static std::atomic<unsigned long long> big{0};
+        if (bya_allow_big_lds(reinterpret_cast<const void*>(router_scores_lds_kernel), 160 * 1024, big) != BYA_OK) return BYA_ERR_LAUNCH;
+        const int grid = 256 / n_id * n_id;                      // one workgroup per CU, whole identities
+        BYA_LAUNCH(router_scores_lds_kernel, dim3((unsigned)grid), dim3(512), (size_t)R_TOK * R_QK * 2, stream,
+                   (const bf16_t*)qr, (const bf16_t*)kr, (const bf16_t*)ln_w, (const bf16_t*)ln_b,
+                   (const bf16_t*)pos_emb, (bf16_t*)out, n_id, (long long)N, eps);
+        return ok();
+    }
     const long long waves = ((N + 15) / 16) * n_id;
     BYA_LAUNCH(router_scores_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream,
                        (const bf16_t*)qr, (const bf16_t*)kr, (const bf16_t*)ln_w, (const bf16_t*)ln_b,

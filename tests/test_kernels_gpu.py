@@ -796,8 +796,11 @@ def test_linear_small_m_and_timestep(ops, dev):
 
 
 # ----------------------------------------------------------------------------------------------- router pieces
-def test_router_scores(ops, dev):
-    NID, N = 2, 150
+@pytest.mark.parametrize("NID,N", [(2, 150), (2, 17550), (3, 4099), (4, 6001)])
+def test_router_scores(ops, dev, monkeypatch, NID, N):
+    """From 4096 tokens on the identity's 32 keys are resident in LDS (one workgroup per CU, whole identities, every wave on
+    its own 16-token tiles); BYA_ROUTER_SCORES_LDS=0 keeps the kernel that re-reads them per wave.  Same MFMA order:
+    bit-identical, ragged last tile and 2-4 identities included."""
     qr, kr = rnd((N, 2048), dev, 90), rnd((NID, 32, 2048), dev, 91, 0.2)
     w, b = rnd((512,), dev, 92, 0.2) + 1, rnd((512,), dev, 93, 0.2)
     pos = rnd((N, 512), dev, 94)
@@ -808,6 +811,10 @@ def test_router_scores(ops, dev):
     s = (qh @ kh.transpose(-2, -1)).permute(0, 2, 3, 1).reshape(NID, N, 512)
     ref = bf(F.layer_norm(s, (512,), w.float(), b.float(), 1e-5)).float() + pos.float()
     check(out, ref, tol=2e-3, what="router_scores")
+    monkeypatch.setenv("BYA_ROUTER_SCORES_LDS", "0")
+    out0 = torch.empty_like(out)
+    ops.router_scores(qr, kr, w, b, pos, out0, NID, N)
+    assert torch.equal(out, out0)
 
 
 def test_router_head_and_forcing(ops, dev):
