@@ -128,6 +128,9 @@ int bya_timestep_features(const int64_t* timesteps, void* out, int32_t batch, in
  * Replaces CogVideoXLayerNormZero / AdaLayerNorm / nn.LayerNorm call sites
  * (models/transformer.py:233,251,944,948; models/router.py:247-248,380-393,475-491;
  * models/audio_model.py:249).  D in {512, 768, 1024, 2048, 3072}; rows_per_batch rows per z.
+ * Affine + modulation are evaluated as ONE fma, y = fma(LN(x), w (1 + scale), b (1 + scale) + shift), in every kernel
+ * behind this entry point (at D = 3072 with w and b a wave keeps those two vectors in registers and walks several rows),
+ * so a result does not depend on how the rows are cut into launches.
  * --------------------------------------------------------------------------------------------- */
 int bya_layernorm(const void* x, void* y, const void* w, const void* b, const void* shift0, const void* scale0,
                   const void* shift1, const void* scale1, int64_t rows_per_batch, int32_t batch, int32_t D,
@@ -209,7 +212,9 @@ int bya_attn_workspace_status(int32_t* timeouts, hipStream_t stream);
  * masked combine of models/transformer.py:821-832 / 895-936 AFTER the (linear) output projection: the engine mixes first
  * and projects once.  r: routing logits bf16 [n_grp * Sq, n_id]; af: NULL = face weights (w = r), else the audio-to-face
  * matrix bf16 [n_id, n_id] (w as in bya_masked_combine mode 1).  wsum (optional, fp32 [n_grp * Sq]) = sum_id w, the row scale
- * of the projection's bias.  q rows are shared by all identities.  Element strides; head h of a row starts at h * head_dim. */
+ * of the projection's bias.  q rows are shared by all identities.  Element strides; head h of a row starts at h * head_dim.
+ * Up to 32 keys (both callers) with z 16-byte aligned: the K / V of every identity stay in LDS for a (group, head) and z is
+ * stored as whole head segments; otherwise one 128-row tile per workgroup on 64-key tiles -- the same bits either way. */
 typedef struct bya_attn_mix_desc {
     int32_t head_dim, heads, n_id, n_grp, Sq, Skv;
     int64_t q_grp, q_row, k_id, k_grp, k_row, v_id, v_grp, v_row, z_grp, z_row;
@@ -231,6 +236,7 @@ int bya_attn_tiny(const void* q, const void* k, const void* v, void* o, int32_t 
  * router_scores: s[id,n,tok*heads+h] = sum_d qr[n,h*128+d] * kr[id,tok,h*128+d]; LayerNorm(512, w,b);
  *                + pos_emb[n]  ->  out[id,n,512]
  * router_head:   r[n,id] = sigmoid(x[id,n,:].w + b)  ->  [N, n_id]  (the [1,N,n_id] routing logits)
+ * (router_scores keeps an identity's 32 keys in LDS from 4096 tokens on; same bits as the per-wave form below that.)
  * --------------------------------------------------------------------------------------------- */
 int bya_router_scores(const void* qr, const void* kr, const void* ln_w, const void* ln_b, const void* pos_emb,
                       void* out, int32_t n_id, int64_t N, int32_t heads, int32_t face_tokens, float eps,
