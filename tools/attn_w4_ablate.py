@@ -14,7 +14,7 @@ PKG = os.path.join(ROOT, "bind_your_avatar_implementation_amd")
 OUT = os.path.join(PKG, "build", "ablate")
 VARIANTS = {"full": 0, "exp_as_mov": 1, "no_adds": 2, "no_cvt": 4, "no_lds_dma_barrier": 8, "q_in_vgpr": 16, "no_valu": 32,
             "no_valu_no_lds": 40, "no_adds_no_cvt": 6, "exp_only_as_mov": 7, "no_barrier": 128, "no_dma": 256,
-            "no_ds_reads": 512, "no_lgkm_waits": 1024, "no_vmcnt_wait": 2048, "no_barrier_no_vmcnt": 2176, "no_k_reads": 4096, "no_v_reads": 8192, "v_reads_burst": 16384, "v_reads_b128": 32768}
+            "no_ds_reads": 512, "no_lgkm_waits": 1024, "no_vmcnt_wait": 2048, "no_barrier_no_vmcnt": 2176, "no_k_reads": 4096, "no_v_reads": 8192, "v_reads_burst": 16384, "v_reads_b128": 32768, "dma_behind_valu": 65536}
 if "--only" in sys.argv:
     keep = sys.argv[sys.argv.index("--only") + 1].split(",")
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in keep}

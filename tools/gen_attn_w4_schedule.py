@@ -44,7 +44,8 @@ RB = 128                                                   # bytes per K / V row
 # rendezvous inside the loop, 16: Q fragments in VGPRs instead of AGPRs, 32: no VALU at all; finer: 128: no s_barrier,
 # 256: no LDS-DMA, 512: no ds_reads, 1024: no lgkmcnt waits, 2048: no vmcnt wait, 4096: no K reads, 8192: no V reads,
 # 16384: all V reads in one burst behind the first MFMA of QK_1, 32768: V fragments by eight ds_read_b128 instead of sixteen
-# ds_read_b64_tr_b16 (what a V^T layout in memory would allow; addresses meaningless here).
+# ds_read_b64_tr_b16 (what a V^T layout in memory would allow; addresses meaningless here); 65536 (results VALID): the four
+# LDS-DMA pieces issued behind their gap's softmax instructions instead of behind an s_nop.
 ABLATE = 0
 
 
@@ -181,9 +182,15 @@ def group_b(variant, b):
             elif g >= 4 and not ABLATE & 256:
                 q = g - 4                                   # pieces K0 K1 V0 V1 of tile t + 3
                 st.add("s_mov_b32 m0, {0}", st.inp(f"dma_dst{q}", "s"))
-                st.add("s_nop 0")
+                if ABLATE & 65536:
+                    # (experiment, results stay valid) the DMA behind the gap's softmax instructions: they cover the m0 hazard
+                    softmax_half(st, g, sb, 0, b)
+                else:
+                    st.add("s_nop 0")
                 st.add("buffer_load_dwordx4 {0}, {1}, {2} offen lds", st.inp(f"dvo[{q}]"),
                        st.inp("rsK" if q < 2 else "rsV", "s"), st.inp("soffK" if q < 2 else "soffV", "s"))
+                if ABLATE & 65536:
+                    continue
         if variant == "L":
             softmax_half(st, g, sb, 0, b)
     if variant == "L" and b == 3 and not ABLATE & 8:
