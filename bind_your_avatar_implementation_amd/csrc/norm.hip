@@ -257,8 +257,9 @@ struct QkArgs {
 //   1: the cos / sin loads are drained (vmcnt(0)) before any later instruction may touch their address registers
 //   2: 32-bit index arithmetic (no 64-bit division sequences in front of the RoPE branch)
 // (r4, measured and dropped: a row form -- one token row per wave iteration, the four parameter vectors in registers, a row's
-// cos / sin piece loaded once for all heads of q and k -- bit-identical, 86-90 us against 78-86 us for this kernel,
-// the in-place read-modify-write stream binds, not the parameter traffic.)
+// cos / sin piece loaded once for all heads of q and k -- bit-identical, 86-90 us against 78-86 us for this kernel;
+// writing to a second buffer instead of in place -- 92-104 us against 78-90 us: the in-place stores hit lines the loads
+// just brought into L2.)
 template <int DBG>
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
     // one 8-lane group per (row, head) pair, pairs enumerated row-major over all batches: any head count works
