@@ -198,13 +198,21 @@ def main():
             print(json.dumps({"launch_check": world, "rank_sum": t.item()}), flush=True)
         dist.destroy_process_group()
         return
+    # BYA_BENCH_SHARE_GPU=1 (test hook, tests/test_forward_gpu.py): all ranks on GPU 0 with a gloo process group -- how the
+    # builder's one-GPU box exercises the N > 1 code path of this file; never a measurement
+    share = os.environ.get("BYA_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel, ops
     from bind_your_avatar_implementation_amd.synth import synth_inputs
@@ -239,6 +247,34 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
+    transport_note = None
+    if dist is not None:
+        # Every rank returns the SAME full output (the last exchange gathers it): compare a checksum across the ranks before
+        # anything is timed.  The P2P exchange engine has only ever run with all ranks on ONE GPU (no multi-GPU node was
+        # available to the builder): if the ranks disagree, or a bounded wait timed out, every rank switches to the
+        # torch.distributed transport together and the line says so -- a number from a broken exchange is worth nothing.
+        def ranks_agree(o):
+            h = o.contiguous().view(torch.int16).to(torch.int64)
+            sig = torch.stack([h.sum(), (h * (torch.arange(h.numel(), device=h.device) % 8191 + 1).view_as(h)).sum()])
+            p2p = getattr(model, "_seq_p2p", None)
+            mine = (sig.tolist(), 0 if p2p is None else int(p2p.timeouts()))
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)               # (object collective: works on RCCL and on gloo alike)
+            return all(e[0] == everyone[0][0] and e[1] == 0 for e in everyone)
+        agree = ranks_agree(out)
+        if os.environ.get("BYA_BENCH_FAKE_MISMATCH") == "1":     # test hook: walk the fallback once
+            agree = False
+        if not agree:
+            if getattr(model, "_seq_p2p", None) is None:
+                raise SystemExit("the ranks' outputs differ on the torch.distributed transport: no result")
+            from bind_your_avatar_implementation_amd.parallel import shard_sequence as _reshard
+            _reshard(model, model._seq_group, transport="torch")
+            for _ in range(max(1, args.warmup)):
+                out = step()
+            torch.cuda.synchronize()
+            if not ranks_agree(out):
+                raise SystemExit("the ranks' outputs differ on both transports: no result")
+            transport_note = "P2P exchange failed its cross-rank check on this node; torch.distributed collectives used"
     ops.ATTN_VARIANTS.clear()
     assert torch.isfinite(out.float()).all(), "non-finite output"
 
@@ -295,6 +331,8 @@ def main():
                                                  if getattr(model, "_seq_p2p", None) is not None else
                                                  "; exchanges = torch.distributed collectives (RCCL)")},
         }
+        if transport_note:
+            res["config"]["transport_note"] = transport_note
         if ktimes:
             tot = {k: sum(v) for k, v in ktimes.items()}
             per_step = {k: tot[k] / args.steps for k in tot}

@@ -101,3 +101,29 @@ def test_p2p_exchange_between_processes_on_one_gpu(dev, world, mode):
     for r in range(world):
         ok, timeouts, pushes = ret[r]
         assert ok and timeouts == 0 and pushes > 0, (r, ret[r])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_checks_the_exchange_before_timing(tmp_path):
+    """bench.py with N > 1 compares a checksum of the output across the ranks before anything is timed (every rank returns
+    the same full tensor) and, if the P2P engine fails that check or a bounded wait timed out, moves ALL ranks to the
+    torch.distributed transport and says so in the line.  Exercised here with both ranks on the one GPU
+    (BYA_BENCH_SHARE_GPU=1: gloo process group), once as it is and once with the mismatch faked."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "1", "--warmup", "1",
+            "--no-cpu-baseline", "--no-fp8-variant", "--no-kernel-timers"]
+    for fake in ("0", "1"):
+        env = dict(os.environ, BYA_BENCH_SHARE_GPU="1", BYA_BENCH_FAKE_MISMATCH=fake, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+        r = subprocess.run(base, env=env, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=900)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert r.returncode == 0 and len(lines) == 1, (r.stdout[-800:], r.stderr[-1500:])
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["value"] > 0
+        if fake == "0":
+            assert "P2P push kernels" in d["config"]["parallelism"] and "transport_note" not in d["config"]
+        else:
+            assert "torch.distributed collectives" in d["config"]["parallelism"] and "P2P exchange failed" in d["config"]["transport_note"]
