@@ -358,8 +358,16 @@ def main():
             gemm_roof = None
             if gemm:
                 gflop = ops.kernel_timer_flops().get("bya_gemm_bf16", 0.0)
-                gemm_roof = {"kernel": "bya_gemm_bf16 (every Linear of the step: gemm256p_kernel 256x256 tiles, 87 % of the time, + "
-                                       "128x128 tiles; `traffic` is gemm256p_kernel's, per launch of that kernel)",
+                small = ktimes.get("bya_gemm_bf16_small_m", [])
+                sflop = ops.kernel_timer_flops().get("bya_gemm_bf16_small_m", 0.0)
+                gemm_roof = {"kernel": "bya_gemm_bf16 over the token stream (every Linear with >= 1024 rows: gemm256p_kernel 256x256 "
+                                       "tiles + the 128x128 kernel for tail rows; `traffic` is gemm256p_kernel's, per launch of that "
+                                       "kernel).  The step-invariant conditioning's Linears (< 1024 rows against 2048..49152-wide "
+                                       "weights: weight-streaming, HBM-bound) are listed in `small_m_linears` and counted in "
+                                       "`all_linears_frac`",
+                             "small_m_linears": {"launches": len(small), "ms_per_step": sum(small) / args.steps * 1e3,
+                                                 "tflop_per_step": sflop / 1e12 / args.steps},
+                             "all_linears_frac": (gflop + sflop) / 1e12 / (sum(gemm) + sum(small)) / PEAK_BF16_TFLOPS,
                              "bound": "mfma", "achieved": gflop / 1e12 / sum(gemm), "peak": PEAK_BF16_TFLOPS,
                              "unit": "TFLOP/s", "frac": gflop / 1e12 / sum(gemm) / PEAK_BF16_TFLOPS,
                              "traffic": pmc_traffic(world, "gemm256p_kernel<false, false>", "gemm256p_kernel<false>", "gemm256p_kernel", "gemm256_kernel"), "launches": len(gemm),

@@ -253,7 +253,10 @@ def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, g
     d.bias_rowscale, d.alpha = _p(bias_rowscale), float(alpha)
     if bias_rowscale is not None:
         assert bias_rowscale.dtype == torch.float32 and bias_rowscale.is_contiguous() and bias_rowscale.numel() == ab * M
-    name = "bya_gemm_bf16"
+    # per-kernel timers: Linears over fewer than 1024 rows (the step-invariant conditioning: 32 face tokens, 52 audio windows,
+    # 577 ViT tokens against 2048..49152-wide weights) stream their WEIGHTS and are bound by HBM, not by the matrix cores --
+    # they get their own bucket so that the MFMA roofline of bench.py is taken over the launches it applies to
+    name = "bya_gemm_bf16" if M >= 1024 else "bya_gemm_bf16_small_m"
     if _SHAPE_LABELS:
         name += f":{ab}x{M}x{N}x{K}:{act or 'none'}{'+gate' if gate0 is not None else ''}{'+res' if res is not None else ''}"
     tok = _begin(name, 2.0 * ab * M * N * K)
