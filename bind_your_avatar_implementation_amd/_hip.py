@@ -46,6 +46,7 @@ class SchedCoef(_c.Structure):
 SIGNATURES = {
     "bya_abi_version": [],
     "bya_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
+    "bya_gemm_skinny_bf16": [_vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
     "bya_set_gemm_workspace": [_vp, _i64],
     "bya_gemm_workspace_bytes": [_c.POINTER(_i64)],
     "bya_gemm_workspace_status": [_c.POINTER(_i32), _vp],

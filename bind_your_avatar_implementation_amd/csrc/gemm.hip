@@ -429,6 +429,125 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
 }
 
 namespace {
+// ------------------------------------------------------------------------------------------------------------------
+// Skinny Linears (bya_gemm_skinny_bf16): at most 64 rows (batch elements stacked when they fit) against a weight of up to 8192
+// rows -- the step-invariant conditioning (32 face tokens x 2 identities
+// into the perceiver / router keys, 12-49 audio windows through the projector whose conv1 weight alone is 2.4 GB, the
+// LocalFacialExtractor's 37-row latents): ~80 launches per step that stream WEIGHTS.  On the tiled kernels such a launch has
+// N / 128 workgroups (4 for the audio projector's first layer: 47 MB through four CUs, 0.58 ms) and a tile that is mostly
+// padding.  Here: one workgroup per 16 output columns (and batch element), its 16 waves split K, every wave streams its
+// slice of the 16 weight rows as MFMA A operands (v_mfma_f32_16x16x32_bf16; the <= 4 row tiles of X are the B operands, from
+// L2) and leaves a partial [M x 16] in LDS; the partials are added in wave order (deterministic) and the epilogue (bias,
+// activation, alpha, residual) runs on one element per thread.
+template <int MT>
+__global__ __launch_bounds__(1024) void gemm_skinny_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);               // [16 waves][MT * 16 rows][16 columns]
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // rows: the batch elements are stacked when they fit one workgroup together (fold > 0: row r = (z, m) = (r / M, r % M)),
+    // so the weight is streamed once for all of them; otherwise blockIdx.y is the batch element
+    const int n0 = blockIdx.x * 16, zb = blockIdx.y, fold = p.gate_split, rows = fold > 0 ? fold * p.M : p.M;
+    const int ksteps = p.K / 32;
+    const int k_lo = (int)((long long)ksteps * wave / 16), k_hi = (int)((long long)ksteps * (wave + 1) / 16);
+    const bf16_t* wrow = p.W + (long long)(n0 + c) * p.ldw + 8 * g;
+    const bf16_t* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int r = mt * 16 + c;
+        r = r < rows ? r : rows - 1;
+        const int z = fold > 0 ? r / p.M : zb, m = fold > 0 ? r % p.M : r;
+        xrow[mt] = p.A + (long long)z * p.a_bs + (long long)m * p.lda + 8 * g;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int ks = k_lo;
+    for (; ks + 4 <= k_hi; ks += 4) {                           // four weight loads in flight per lane
+        bf16x8 wf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8*>(wrow + (ks + u) * 32);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow[mt] + (ks + u) * 32);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf, acc[mt], 0, 0, 0);
+            }
+    }
+    for (; ks < k_hi; ++ks) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow[mt] + ks * 32);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[mt], 0, 0, 0);
+        }
+    }
+    // lane (c, g) holds row mt * 16 + c, columns n0 + 4 g .. + 3
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<f32x4*>(red + ((wave * MT * 16 + mt * 16 + c) * 16 + 4 * g)) = acc[mt];
+    __syncthreads();
+    for (int t = tid; t < MT * 256; t += 1024) {               // one output element per thread and pass
+        const int r = t >> 4, n = t & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += red[(w * MT * 16 + r) * 16 + n];
+        if (r < rows) {
+            const int z = fold > 0 ? r / p.M : zb, m = fold > 0 ? r % p.M : r;
+            if (p.bias) v += bf2f(p.bias[n0 + n]);
+            switch (p.act) {
+                case 1: v = gelu_tanh(v); break;
+                case 2: v = gelu_erf(v); break;
+                case 3: v = v > 0.f ? v : 0.f; break;
+                case 4: v = silu(v); break;
+                case 5: v = v > 0.f ? v : v * p.leaky; break;
+                case 6: v = gelu_tanh_ieee(v); break;
+                default: break;
+            }
+            v *= p.alpha;
+            if (p.res) v += bf2f(p.res[(long long)z * p.res_bs + (long long)m * p.ldres + n0 + n]);
+            p.C[(long long)z * p.c_bs + (long long)m * p.ldc + n0 + n] = f2bf(v);
+        }
+    }
+}
+
+inline bool skinny_eligible(const GemmArgs& a) {
+    // (wide outputs -- the audio projector's conv1, N = 24576 -- fill the chip on the tiled kernel and stream better there:
+    // 0.75 ms against 0.83-1.2 ms here for its 2.4 GB weight)
+    return a.M <= 64 && a.N <= 8192 && a.K >= 256 && a.K % 32 == 0 && a.N % 16 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.a_bs % 8 == 0 &&
+        !a.gate0 && !a.bias_rowscale && a.n_split == 0 && a.conv_cpg_log2 < 0 && !(((uintptr_t)a.A | (uintptr_t)a.W) & 15);
+}
+
+template <int MT>
+int launch_skinny_mt(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+    const size_t lds = (size_t)16 * MT * 16 * 16 * 4;
+    static std::atomic<unsigned long long> big{0};
+    if (lds > 64 * 1024 && bya_allow_big_lds(reinterpret_cast<const void*>(gemm_skinny_kernel<MT>), 160 * 1024, big) != BYA_OK)
+        return BYA_ERR_LAUNCH;
+    BYA_LAUNCH(gemm_skinny_kernel<MT>, grid, dim3(1024), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+int launch_skinny(const GemmArgs& a0, int nbatch, hipStream_t stream) {
+    GemmArgs a = a0;
+    // stacking pays while the row tiles stay <= 4 (more X fragments per weight fragment cost more than a second weight pass)
+    const bool fold = nbatch > 1 && (long long)nbatch * a.M <= 64;           // (gate_split is free here: no gates on this path)
+    a.gate_split = fold ? nbatch : 0;
+    const int rows = fold ? nbatch * a.M : a.M, mt = (rows + 15) / 16;
+    const dim3 grid((unsigned)(a.N / 16), (unsigned)(fold ? 1 : nbatch));
+    switch (mt) {
+        case 1: return launch_skinny_mt<1>(a, grid, stream);
+        case 2: return launch_skinny_mt<2>(a, grid, stream);
+        case 3: return launch_skinny_mt<3>(a, grid, stream);
+        case 4: return launch_skinny_mt<4>(a, grid, stream);
+        case 5: return launch_skinny_mt<5>(a, grid, stream);
+        case 6: return launch_skinny_mt<6>(a, grid, stream);
+        case 7: return launch_skinny_mt<7>(a, grid, stream);
+        default: return launch_skinny_mt<8>(a, grid, stream);
+    }
+}
+
 int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
     char* const ws = reinterpret_cast<char*>(a.ws_counters);
     struct { int M, N, K, batch, act; } dd{a.M, a.N, a.K, nbatch, a.act};
@@ -478,3 +597,27 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
     return launch256(a, d->batch, stream);
 }
 }  // namespace
+
+
+// The weight-streaming kernel is the CALLER's choice: its summation order differs from the tiled kernels', and which of the
+// two bya_gemm_bf16 would pick must not depend on how many rows a launch happens to have (a rank's shard of the token stream
+// has to round exactly like the whole).  The engine asks for it where the row count is a property of the model -- the
+// step-invariant conditioning.
+extern "C" int bya_gemm_skinny_bf16(const void* A, const void* W, const void* bias, void* C, const void* res,
+                                    const bya_gemm_desc* d, hipStream_t stream) {
+    if (!A || !W || !C || !d) return BYA_ERR_SHAPE;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0) return BYA_ERR_SHAPE;
+    if (d->act < 0 || d->act > 6) return BYA_ERR_UNSUPPORTED;
+    GemmArgs a;
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.C = (bf16_t*)C;
+    a.res = (const bf16_t*)res; a.gate0 = nullptr; a.gate1 = nullptr;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = d->ldres;
+    a.a_bs = d->a_batch_stride; a.c_bs = d->c_batch_stride; a.res_bs = d->res_batch_stride;
+    a.gate_bs = 0; a.gate_split = 0; a.act = d->act; a.leaky = 0.01f;
+    a.n_split = d->n_split; a.c_split_stride = d->c_split_stride;
+    a.bias_rowscale = d->bias_rowscale; a.alpha = d->alpha == 0.0f ? 1.0f : d->alpha;
+    a.ws_counters = nullptr; a.ws_slabs = nullptr;
+    if (!skinny_eligible(a)) return BYA_ERR_UNSUPPORTED;
+    return launch_skinny(a, d->batch, stream);
+}

@@ -295,6 +295,12 @@ class DenoiseEngine:
 
     # ------------------------------------------------------------------------------------------ invariants
     def _face_invariants(self, id_cond, id_vit_hidden, B, n_id):
+        # the row counts in here (face tokens, ViT tokens, latents) are the model's, not a partition's: skinny Linears may
+        # take the weight-streaming kernel (ops.weight_streaming)
+        with ops.weight_streaming():
+            return self._face_invariants_body(id_cond, id_vit_hidden, B, n_id)
+
+    def _face_invariants_body(self, id_cond, id_vit_hidden, B, n_id):
         """LocalFacialExtractor (models/router.py:157-193) + the per-layer face K/V (router.py:247,254) and router
         keys (router.py:377-383).  Returns (kv[l] [B,n_id,32,2*inner], kr[l] [B,n_id,32,qk])."""
         m = self.m
@@ -352,17 +358,23 @@ class DenoiseEngine:
         for l, pc in enumerate(m.perceiver_cross_attention):
             self._ln(face2d, fn, pc.norm1)
             kv_l = E(B * n_id * nq, pc.to_kv.weight.shape[0])
-            ops.gemm(fn, pc.to_kv.weight, kv_l)
+            # one batch element per (sample, identity): the rows of a launch (32 face tokens) must not grow with the batch, or a
+            # batch of two would pick another kernel than two batches of one (ops.weight_streaming takes <= 64 rows)
+            ops.gemm(fn.view(B * n_id, nq, -1), pc.to_kv.weight, kv_l.view(B * n_id, nq, -1))
             inner_p = pc.to_q.weight.shape[0]
             kn = E(B * n_id * nq, inner_p)
             ops.layernorm(kv_l[:, :inner_p], kn, self.r_nk_w, self.r_nk_b, eps=m.router.norm_k.eps)
             kr_l = E(B * n_id * nq, inner_p)
-            ops.gemm(kn, self.r_to_k[l], kr_l)
+            ops.gemm(kn.view(B * n_id, nq, -1), self.r_to_k[l], kr_l.view(B * n_id, nq, -1))
             kvs.append(kv_l.view(B, n_id, nq, -1))
             krs.append(kr_l.view(B, n_id, nq, -1))
         return kvs, krs
 
     def _audio_invariants(self, audio_embeds, T, B, n_id):
+        with ops.weight_streaming():
+            return self._audio_invariants_body(audio_embeds, T, B, n_id)
+
+    def _audio_invariants_body(self, audio_embeds, T, B, n_id):
         """sliding_windows + AudioProjModel (models/audio_model.py:188-193, 78-114) and the per-layer audio K/V
         (diffusers Attention.to_k/to_v on the 32 context tokens of each latent frame)."""
         am = self.m.audio_model

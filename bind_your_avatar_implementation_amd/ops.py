@@ -5,6 +5,7 @@ Tensors are bf16 device tensors unless stated; 2-D ``[rows, cols]`` or 3-D ``[ba
 with unit inner stride are accepted (no copies are made here).
 """
 import ctypes
+import os
 
 import torch
 
@@ -75,6 +76,26 @@ class on_stream:
         if self.done is not None:
             torch.cuda.current_stream().wait_event(self.done)
             self.done = None
+
+
+# ---- which kernel serves a skinny Linear is the caller's decision (include/bya.h: bya_gemm_skinny_bf16) ------------
+_WEIGHT_STREAMING = False
+
+
+class weight_streaming:
+    """``with ops.weight_streaming():`` -- Linears of at most 64 rows inside the block go to the weight-streaming kernel
+    (``bya_gemm_skinny_bf16``) when they qualify.  For code whose row counts are properties of the MODEL (the step-invariant
+    conditioning), never for the token stream: a shard's rows must round like the whole's.  BYA_GEMM_SKINNY=0 switches it off."""
+
+    def __enter__(self):
+        global _WEIGHT_STREAMING
+        self._old, _WEIGHT_STREAMING = _WEIGHT_STREAMING, True
+        return self
+
+    def __exit__(self, *exc):
+        global _WEIGHT_STREAMING
+        _WEIGHT_STREAMING = self._old
+        return False
 
 
 # ---- optional per-entry-point timers (HIP events recorded on the launch stream; used by bench.py) -------------
@@ -260,8 +281,13 @@ def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, g
     if _SHAPE_LABELS:
         name += f":{ab}x{M}x{N}x{K}:{act or 'none'}{'+gate' if gate0 is not None else ''}{'+res' if res is not None else ''}"
     tok = _begin(name, 2.0 * ab * M * N * K)
-    check(lib.bya_gemm_bf16(_p(a), _p(w), _p(bias), _p(out), _p(res), _p(gate0), _p(gate1), ctypes.byref(d),
-                            _stream()), "bya_gemm_bf16")
+    if (_WEIGHT_STREAMING and M <= 64 and N <= 8192 and N % 16 == 0 and K % 32 == 0 and K >= 256 and gate0 is None
+            and bias_rowscale is None and split is None and a_bs % 8 == 0 and os.environ.get("BYA_GEMM_SKINNY") != "0"):
+        check(lib.bya_gemm_skinny_bf16(_p(a), _p(w), _p(bias), _p(out), _p(res), ctypes.byref(d), _stream()),
+              "bya_gemm_skinny_bf16")
+    else:
+        check(lib.bya_gemm_bf16(_p(a), _p(w), _p(bias), _p(out), _p(res), _p(gate0), _p(gate1), ctypes.byref(d),
+                                _stream()), "bya_gemm_bf16")
     _end(tok)
     return out
 

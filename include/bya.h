@@ -63,6 +63,16 @@ typedef struct bya_gemm_desc {
 int bya_gemm_bf16(const void* A, const void* W, const void* bias, void* C, const void* res,
                   const void* gate0, const void* gate1, const bya_gemm_desc* desc, hipStream_t stream);
 
+/* The same product for SKINNY launches -- at most 64 rows, N <= 8192, N % 16 == 0, K % 32 == 0, K >= 256, no gates, no
+ * bias_rowscale, no n_split (anything else: BYA_ERR_UNSUPPORTED) -- on a weight-streaming kernel: one workgroup per 16
+ * output columns (batch elements stacked as rows while they fit 64 together), 16 waves split K, partial sums added in a
+ * fixed order.  For Linears whose few rows meet a wide weight (the step-invariant conditioning: nn.Linear call sites of
+ * models/router.py:216-262 (Perceiver to_kv / LocalFacialExtractor) and models/audio_model.py:78-114 (AudioProjModel)): the
+ * tiled kernels give such a launch N / 128 workgroups.  It is a separate entry point because its fp32 summation order
+ * differs from bya_gemm_bf16's: which kernel runs is the caller's decision, never a function of the row count. */
+int bya_gemm_skinny_bf16(const void* A, const void* W, const void* bias, void* C, const void* res,
+                         const bya_gemm_desc* desc, hipStream_t stream);
+
 /* Optional split-K workspace of the persistent GEMM kernel (device memory owned by the caller, 256-byte aligned, at
  * least the size bya_gemm_workspace_bytes reports, ZERO-FILLED once): with it, the last partial round of 256 x 256 output tiles
  * of a bya_gemm_bf16 launch is cut along K over the idle CUs (partial sums and completion counters live here).  One

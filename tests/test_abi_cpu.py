@@ -23,7 +23,7 @@ def declared_symbols():
 
 def test_header_declares_the_documented_entry_points():
     syms = declared_symbols()
-    for must in ["bya_gemm_bf16", "bya_attn_fwd", "bya_layernorm", "bya_qknorm_rope", "bya_masked_combine",
+    for must in ["bya_gemm_bf16", "bya_gemm_skinny_bf16", "bya_attn_fwd", "bya_layernorm", "bya_qknorm_rope", "bya_masked_combine",
                  "bya_router_scores", "bya_router_head", "bya_forcing_max_over_frames", "bya_patchify",
                  "bya_unpatchify", "bya_linear_small_m", "bya_timestep_features", "bya_attn_tiny", "bya_act_add",
                  "bya_abi_version"]:

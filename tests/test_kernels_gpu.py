@@ -249,6 +249,52 @@ def test_gemm_several_split_launches_in_one_replayed_hip_graph(ops, dev):
     assert dt < 0.5, f"4 replays of 3 split launches took {dt:.2f} s: a finisher sat in its bounded wait"
 
 
+@pytest.mark.parametrize("B,M,N,K,act,res", [(1, 64, 2048, 2048, None, False), (1, 64, 4096, 2048, None, False),
+                                               (2, 37, 1024, 4096, None, True), (2, 49, 512, 46080, "relu", False),
+                                               (2, 37, 4096, 1024, "gelu_erf", False), (2, 12, 1536, 8192, None, False),
+                                               (1, 1, 512, 256, "silu", True), (2, 33, 48, 1088, "gelu_tanh", True),
+                                               (2, 24, 1024, 2048, None, False), (3, 40, 256, 512, None, True), (4, 16, 8192, 512, "relu", False)])
+def test_gemm_skinny_rows_weight_streaming_kernel(ops, dev, monkeypatch, B, M, N, K, act, res):
+    """Linears with at most 64 rows and up to 8192 outputs inside ``ops.weight_streaming()`` (the step-invariant conditioning)
+    run on bya_gemm_skinny_bf16: one workgroup
+    per 16 output columns (batch elements stacked as rows when they fit together, else one workgroup per batch element),
+    16 waves split K, partial sums added in wave order.  Against fp32 at the usual
+    per-kernel bar, against the tiled kernel (BYA_GEMM_SKINNY=0) within the same bar, repeatable bit for bit, strided A /
+    out / res, rows that are no multiple of 16, every epilogue it takes over."""
+    a_w = rnd((B, M, K + 64), dev, 21)
+    a = a_w[..., 32:32 + K]
+    w, b = rnd((N, K), dev, 22, K ** -0.5), rnd((N,), dev, 23, 0.5)
+    r_w = rnd((B, M, N + 16), dev, 24)
+    r = r_w[..., 8:8 + N] if res else None
+    o_w = torch.full((B, M, N + 32), 3.0, dtype=torch.bfloat16, device=dev)
+    out = o_w[..., 16:16 + N]
+    def run():
+        o_w.fill_(3.0)
+        with ops.weight_streaming():
+            ops.gemm(a, w, out, bias=b, act=act, res=r)
+        torch.cuda.synchronize()
+        return o_w.clone()
+    got = run()
+    y = a.float() @ w.float().T + b.float()
+    y = {None: lambda t: t, "relu": torch.relu, "silu": F.silu, "gelu_erf": F.gelu,
+         "gelu_tanh": lambda t: F.gelu(t, approximate="tanh")}[act](y)
+    if res:
+        y = y + r.float()
+    check(got[..., 16:16 + N], y, tol=2e-3, what=f"skinny gemm {B}x{M}x{N}x{K} {act} res={res}")
+    assert bool((got[..., :16] == 3.0).all()) and bool((got[..., 16 + N:] == 3.0).all())
+    assert torch.equal(run(), got)                                        # deterministic: fixed order of the partial sums
+    monkeypatch.setenv("BYA_GEMM_SKINNY", "0")
+    tiled = run()
+    check(tiled[..., 16:16 + N], y, tol=2e-3, what="the tiled kernel on the same launch")
+    assert rel_fro(got[..., 16:16 + N].float(), tiled[..., 16:16 + N].float()) < 4e-3
+    monkeypatch.delenv("BYA_GEMM_SKINNY")
+    # outside ops.weight_streaming() the tiled kernel runs whatever the row count: bya_gemm_bf16 never picks by rows
+    o_w.fill_(3.0)
+    ops.gemm(a, w, out, bias=b, act=act, res=r)
+    torch.cuda.synchronize()
+    assert torch.equal(o_w, tiled)
+
+
 def test_gemm_mfma_layout_asymmetric(ops, dev):
     """A = I against an asymmetric integer-valued W catches swapped row/col maps exactly."""
     K = N = 128
