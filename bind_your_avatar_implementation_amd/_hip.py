@@ -87,6 +87,14 @@ SIGNATURES = {
     "bya_alltoall_router": [_vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "bya_p2p_push": [_vp, _i32, _i64, _vp, _i32, _i32, _vp, _vp],
     "bya_p2p_wait": [_vp, _i32, _vp],
+    "bya_p2p_exchange": [_vp, _i32, _i64, _vp, _i32, _i32, _vp, _vp],
+    "bya_p2p_set_wait_limit_ms": [_i64],
+    "bya_p2p_poison": [_vp, _i32, _vp, _i64, _vp],
+    "bya_p2p_alloc": [_i64, _i32, _c.POINTER(_vp)],
+    "bya_p2p_free": [_vp],
+    "bya_p2p_ipc_export": [_vp, _vp],
+    "bya_p2p_ipc_import": [_vp, _c.POINTER(_vp)],
+    "bya_p2p_ipc_release": [_vp],
     "bya_cfg_scheduler_step": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _c.POINTER(SchedCoef), _vp],
 }
 

@@ -53,7 +53,8 @@ def build_hip_library(force=False, verbose=True):
         form = [] if src in AGPR_SOURCES else ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
         if src in NO_SLP_SOURCES:
             form = form + ["-fno-slp-vectorize"]
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *form, "-c", os.path.join(CSRC, src), "-o", obj]
+        # -fvisibility=hidden: the dynamic symbol table is include/bya.h (which pushes default visibility around its declarations)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", *form, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -11,6 +11,7 @@
 #include "bya_common.h"
 #include "../../include/bya.h"
 #include <dlfcn.h>
+#include <string.h>
 
 namespace {
 
@@ -109,20 +110,27 @@ extern "C" int bya_alltoall_router(const void* send, void* recv, const int64_t* 
 //     push kernel bumps its channel's send counter, the wait kernel its expect counter): a replay advances them itself.
 // Ordering: every workgroup of the push kernel makes its stores visible system-wide (__threadfence_system) before it
 // counts itself done; the last one publishes the new sequence number to every peer's flag (system-scope release store).
-// The receiver runs bya_p2p_wait -- one wave spinning on its LOCAL flags -- as the next kernel on its stream; the
-// consumers are later kernels on that stream, whose dispatch acquires at system scope (stale L2 lines of the receive
-// buffer are dropped).  A peer may only overwrite a receive buffer after this rank has consumed it: the step's own data
-// dependencies guarantee that for every exchange the engine issues (multi-GPU section, lists them).
-// Bounded waits (~1 s) count a time-out in the channel's control words instead of hanging the GPU.
+// The receiver waits on its LOCAL flags (the control block is fine-grained memory when the host module could get it:
+// bya_p2p_alloc) with P2P_WAIT_GROUPS workgroups, which the dispatcher deals over the XCDs: each polls with system-scope
+// loads and ends with a system-scope acquire fence, so every XCD's L2 has dropped what it may hold of the receive buffers
+// before a consumer -- a later kernel on the stream -- reads them (round 4 waited with ONE wave: one XCD).  A peer may only
+// overwrite a receive buffer after this rank has consumed it: the step's own data dependencies guarantee that for every
+// exchange the engine issues (multi-GPU section, lists them).
+// A wait is bounded by WALL time (s_memrealtime, bya_p2p_set_wait_limit_ms, default 30 s): when it gives up it counts the
+// event in the channel's word 35, which is STICKY; bya_p2p_poison -- the last launch of a sharded step -- overwrites the
+// step's output with NaN if any channel of the group carries one, so a result made from a stale buffer cannot be used.
 namespace {
 
 constexpr int P2P_CHUNK = 64 * 1024;                 // bytes per workgroup iteration
 constexpr int P2P_CTRL_WORDS = 64;                   // per channel: [0..31] flags by source rank, [32] sent, [33] expected,
-constexpr int P2P_SENT = 32, P2P_EXPECT = 33, P2P_DONE = 34, P2P_TIMEOUTS = 35;      // [34] workgroups done, [35] time-outs
+constexpr int P2P_SENT = 32, P2P_EXPECT = 33, P2P_DONE = 34, P2P_TIMEOUTS = 35, P2P_WAITED = 36;   // [34] push workgroups done,
+                                                                                                   // [35] time-outs, [36] wait workgroups done
+constexpr int P2P_WAIT_GROUPS = 16;                  // workgroups of a wait: two per XCD under round-robin dispatch
 
-__global__ __launch_bounds__(256) void p2p_push_kernel(const bya_p2p_copy* __restrict__ copies, int n_copies, long long total_chunks,
-                                                        unsigned* const* __restrict__ peer_ctrl, int world, int rank,
-                                                        unsigned* __restrict__ ctrl) {
+std::atomic<long long> g_wait_limit_ticks{30ll * 100000000ll};          // s_memrealtime ticks (100 MHz)
+
+// the copy loop of one workgroup
+__device__ __forceinline__ void p2p_copy_chunks(const bya_p2p_copy* __restrict__ copies, int n_copies, long long total_chunks) {
     const int tid = threadIdx.x;
     for (long long c = blockIdx.x; c < total_chunks; c += gridDim.x) {
         int i = 0;
@@ -143,55 +151,173 @@ __global__ __launch_bounds__(256) void p2p_push_kernel(const bya_p2p_copy* __res
                 *reinterpret_cast<uint16_t*>(dst + b) = *reinterpret_cast<const uint16_t*>(src + b);
         }
     }
+}
+
+// one workgroup's wait: lanes < world poll the local flags until all carry `expect` (signed distance: sequence numbers wrap
+// after 4 G exchanges) or the wall-clock limit passes; then a system-scope acquire; the workgroup that finishes last
+// advances the channel's expect counter.  `groups` = workgroups taking part.
+__device__ __forceinline__ void p2p_wait_flags(unsigned* __restrict__ ctrl, int world, unsigned expect, long long limit_ticks,
+                                               unsigned groups) {
+    const int lane = threadIdx.x;
+    if (lane < world) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int)(__hip_atomic_load(ctrl + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - expect) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > limit_ticks) {
+                __hip_atomic_fetch_add(ctrl + P2P_TIMEOUTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // system scope: this CU's L1 and this XCD's L2 drop stale lines
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (ONE wave calls this: program order is all the ordering it needs)
+    if (lane == 0) {
+        const unsigned done = __hip_atomic_fetch_add(ctrl + P2P_WAITED, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == groups - 1) {
+            __hip_atomic_store(ctrl + P2P_WAITED, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctrl + P2P_EXPECT, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// WAIT: the same workgroups then wait for the peers' pushes of this exchange (push + wait as one launch; every workgroup has
+// finished its own copies before it starts to poll, and publishing never depends on a poller, so nothing can wait in a circle)
+template <bool WAIT>
+__global__ __launch_bounds__(256) void p2p_push_kernel(const bya_p2p_copy* __restrict__ copies, int n_copies, long long total_chunks,
+                                                        unsigned* const* __restrict__ peer_ctrl, int world, int rank,
+                                                        unsigned* __restrict__ ctrl, long long limit_ticks) {
+    const int tid = threadIdx.x;
+    unsigned expect = 0;
+    if (WAIT) expect = __hip_atomic_load(ctrl + P2P_EXPECT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;   // (before anybody can advance it)
+    p2p_copy_chunks(copies, n_copies, total_chunks);
     __threadfence_system();
     __syncthreads();
     if (tid == 0) {
         const unsigned done = __hip_atomic_fetch_add(ctrl + P2P_DONE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == gridDim.x - 1) {
             __hip_atomic_store(ctrl + P2P_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned seq = ctrl[P2P_SENT] + 1u;
-            ctrl[P2P_SENT] = seq;
+            const unsigned seq = __hip_atomic_load(ctrl + P2P_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            __hip_atomic_store(ctrl + P2P_SENT, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence_system();
             for (int p = 0; p < world; ++p)
                 __hip_atomic_store(peer_ctrl[p] + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+    if (WAIT) {
+        __syncthreads();
+        if (tid < 64) p2p_wait_flags(ctrl, world, expect, limit_ticks, gridDim.x);
+    }
 }
 
-__global__ __launch_bounds__(64) void p2p_wait_kernel(unsigned* __restrict__ ctrl, int world) {
-    const int lane = threadIdx.x;
-    const unsigned expect = ctrl[P2P_EXPECT] + 1u;
-    if (lane < world) {
-        int spins = 0;
-        // (sequence numbers wrap after 4 G exchanges: compare by signed distance)
-        while ((int)(__hip_atomic_load(ctrl + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - expect) < 0) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1 << 21)) {
-                __hip_atomic_fetch_add(ctrl + P2P_TIMEOUTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __builtin_amdgcn_s_barrier();
-    if (lane == 0) ctrl[P2P_EXPECT] = expect;
+__global__ __launch_bounds__(64) void p2p_wait_kernel(unsigned* __restrict__ ctrl, int world, long long limit_ticks) {
+    const unsigned expect = __hip_atomic_load(ctrl + P2P_EXPECT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    p2p_wait_flags(ctrl, world, expect, limit_ticks, gridDim.x);
+}
+
+// out[0 .. n) := NaN (bf16) if any of the n_channels control blocks starting at ctrl_base carries a time-out
+__global__ __launch_bounds__(256) void p2p_poison_kernel(const unsigned* __restrict__ ctrl_base, int n_channels, uint16_t* __restrict__ out,
+                                                          long long n) {
+    int bad = 0;
+    for (int c = threadIdx.x; c < n_channels; c += 256)
+        bad |= __hip_atomic_load(ctrl_base + (size_t)c * P2P_CTRL_WORDS + P2P_TIMEOUTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (!__syncthreads_or(bad)) return;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = 0x7fc0u;
+}
+
+int p2p_check(const void* copies_dev, const void* peer_ctrl_dev, const void* ctrl, int32_t n_copies, int64_t total_chunks, int32_t world,
+              int32_t rank) {
+    if (!copies_dev || !peer_ctrl_dev || !ctrl || n_copies <= 0 || total_chunks <= 0) return BYA_ERR_SHAPE;
+    if (world <= 0 || world > 32 || rank < 0 || rank >= world) return BYA_ERR_SHAPE;
+    if (((uintptr_t)copies_dev | (uintptr_t)peer_ctrl_dev) & 7 || ((uintptr_t)ctrl & 3)) return BYA_ERR_ALIGN;
+    return BYA_OK;
 }
 
 }  // namespace
 
 extern "C" int bya_p2p_push(const bya_p2p_copy* copies_dev, int32_t n_copies, int64_t total_chunks, void* const* peer_ctrl_dev,
                             int32_t world, int32_t rank, void* ctrl, hipStream_t stream) {
-    if (!copies_dev || !peer_ctrl_dev || !ctrl || n_copies <= 0 || total_chunks <= 0) return BYA_ERR_SHAPE;
-    if (world <= 0 || world > 32 || rank < 0 || rank >= world) return BYA_ERR_SHAPE;
-    if (((uintptr_t)copies_dev | (uintptr_t)peer_ctrl_dev) & 7 || ((uintptr_t)ctrl & 3)) return BYA_ERR_ALIGN;
+    const int rc = p2p_check(copies_dev, peer_ctrl_dev, ctrl, n_copies, total_chunks, world, rank);
+    if (rc != BYA_OK) return rc;
     // enough workgroups to keep every xGMI link and the local HBM busy, few enough to leave the CUs to the compute stream
     const long long want = total_chunks < 64 ? total_chunks : 64;
-    BYA_LAUNCH(p2p_push_kernel, dim3((unsigned)want), dim3(256), 0, stream, copies_dev, n_copies, (long long)total_chunks,
-               reinterpret_cast<unsigned* const*>(peer_ctrl_dev), world, rank, static_cast<unsigned*>(ctrl));
+    BYA_LAUNCH(p2p_push_kernel<false>, dim3((unsigned)want), dim3(256), 0, stream, copies_dev, n_copies, (long long)total_chunks,
+               reinterpret_cast<unsigned* const*>(peer_ctrl_dev), world, rank, static_cast<unsigned*>(ctrl), 0ll);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
 extern "C" int bya_p2p_wait(void* ctrl, int32_t world, hipStream_t stream) {
     if (!ctrl || world <= 0 || world > 32) return BYA_ERR_SHAPE;
-    BYA_LAUNCH(p2p_wait_kernel, dim3(1), dim3(64), 0, stream, static_cast<unsigned*>(ctrl), world);
+    BYA_LAUNCH(p2p_wait_kernel, dim3(P2P_WAIT_GROUPS), dim3(64), 0, stream, static_cast<unsigned*>(ctrl), world,
+               g_wait_limit_ticks.load(std::memory_order_relaxed));
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+extern "C" int bya_p2p_exchange(const bya_p2p_copy* copies_dev, int32_t n_copies, int64_t total_chunks, void* const* peer_ctrl_dev,
+                                int32_t world, int32_t rank, void* ctrl, hipStream_t stream) {
+    const int rc = p2p_check(copies_dev, peer_ctrl_dev, ctrl, n_copies, total_chunks, world, rank);
+    if (rc != BYA_OK) return rc;
+    // at least P2P_WAIT_GROUPS workgroups, so that the acquire at the end of the wait reaches every XCD
+    long long want = total_chunks < 64 ? total_chunks : 64;
+    if (want < P2P_WAIT_GROUPS) want = P2P_WAIT_GROUPS;
+    BYA_LAUNCH(p2p_push_kernel<true>, dim3((unsigned)want), dim3(256), 0, stream, copies_dev, n_copies, (long long)total_chunks,
+               reinterpret_cast<unsigned* const*>(peer_ctrl_dev), world, rank, static_cast<unsigned*>(ctrl),
+               g_wait_limit_ticks.load(std::memory_order_relaxed));
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+extern "C" int bya_p2p_set_wait_limit_ms(int64_t ms) {
+    if (ms <= 0) return BYA_ERR_SHAPE;
+    g_wait_limit_ticks.store((long long)ms * 100000ll, std::memory_order_relaxed);
+    return BYA_OK;
+}
+
+extern "C" int bya_p2p_poison(const void* ctrl_base, int32_t n_channels, void* out, int64_t n_elems, hipStream_t stream) {
+    if (!ctrl_base || !out || n_channels <= 0 || n_elems <= 0) return BYA_ERR_SHAPE;
+    if (((uintptr_t)ctrl_base & 3) || ((uintptr_t)out & 1)) return BYA_ERR_ALIGN;
+    const long long blocks = (n_elems + 255) / 256;
+    BYA_LAUNCH(p2p_poison_kernel, dim3((unsigned)(blocks < 128 ? blocks : 128)), dim3(256), 0, stream,
+               static_cast<const unsigned*>(ctrl_base), n_channels, static_cast<uint16_t*>(out), (long long)n_elems);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+// ---- memory a peer may store into or that a running kernel polls: the three kinds of device memory, and their hipIpc handles --------
+// kind 0: coarse-grained (hipMalloc: cached in the L2s; coherent at kernel boundaries), 1: fine-grained, 2: uncached.
+// Set-up calls, not part of a step: they are the only entry points of the library that allocate.
+extern "C" int bya_p2p_alloc(int64_t bytes, int32_t kind, void** out) {
+    if (!out || bytes <= 0 || kind < 0 || kind > 2) return BYA_ERR_SHAPE;
+    void* p = nullptr;
+    const unsigned flags = kind == 0 ? hipDeviceMallocDefault : (kind == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);
+    if (hipExtMallocWithFlags(&p, (size_t)bytes, flags) != hipSuccess || !p) { (void)hipGetLastError(); return BYA_ERR_UNSUPPORTED; }
+    if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return BYA_ERR_LAUNCH; }
+    *out = p;
+    return BYA_OK;
+}
+
+extern "C" int bya_p2p_free(void* ptr) {
+    if (!ptr) return BYA_ERR_SHAPE;
+    return hipFree(ptr) == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+extern "C" int bya_p2p_ipc_export(void* ptr, void* handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle travels as 64 bytes");
+    if (!ptr || !handle64) return BYA_ERR_SHAPE;
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, ptr) != hipSuccess) { (void)hipGetLastError(); return BYA_ERR_UNSUPPORTED; }
+    memcpy(handle64, &h, 64);
+    return BYA_OK;
+}
+
+extern "C" int bya_p2p_ipc_import(const void* handle64, void** out) {
+    if (!handle64 || !out) return BYA_ERR_SHAPE;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, 64);
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !p) { (void)hipGetLastError(); return BYA_ERR_UNSUPPORTED; }
+    *out = p;
+    return BYA_OK;
+}
+
+extern "C" int bya_p2p_ipc_release(void* ptr) {
+    if (!ptr) return BYA_ERR_SHAPE;
+    return hipIpcCloseMemHandle(ptr) == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

@@ -491,6 +491,9 @@ class DenoiseEngine:
         key = (B, T, C, Hh, Ww, Tt, sh.rank, sh.world, n_id)
         if self._ws_key != key:
             self._ws_key, self._ws = key, {}
+            if sh.p2p is not None:
+                sh.p2p.drop_tables()       # the copy tables of the old workspace keep its tensors alive (a graph's are pinned)
+        sh.begin_step()
         buf = self._buf
         hs = self._bf(hidden_states)
         enc_in = self._bf(encoder_hidden_states)
@@ -602,8 +605,7 @@ class DenoiseEngine:
                             # 3 x W column blocks to their places in the peers' q / k / v buffers
                             ops.qknorm_rope(qkvb[:W], qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
                                             at.norm_k.bias, cos, sin, **qk_kw)
-                            hx, qh_, kh_, vh_ = sh.rows_to_heads_qkv(qkvb)
-                            hx.wait()
+                            qh_, kh_, vh_ = sh.rows_to_heads_qkv(qkvb)
                             ops.self_attention(qh_[None], kh_[None], vh_[None], oh[None], heads=H // W, tag="joint", prescaled=True,
                                                score_bound=self.score_bound[i])
                             sh.heads_to_rows(oh, xn[0])
@@ -631,8 +633,11 @@ class DenoiseEngine:
                                     heads=H, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
                                         k_scale=self.k_scale)
                     if sh.active:      # exchange A (fallback when heads % world != 0): all-gather K and V
-                        sh.gather_rows(k[0], k_full[0])
-                        sh.gather_rows(v[0], v_full[0])
+                        if sh.p2p is not None:
+                            sh.gather_rows_many([k[0], v[0]], [k_full[0], v_full[0]])       # one exchange, double-buffered
+                        else:
+                            sh.gather_rows(k[0], k_full[0])
+                            sh.gather_rows(v[0], v_full[0])
                         ops.self_attention(q, k_full, v_full, xn, heads=H, tag="joint", prescaled=True,
                                            score_bound=self.score_bound[i])
                     else:
@@ -771,6 +776,8 @@ class DenoiseEngine:
             y = sh.gather_video_rows(y, out=buf("y_full", B, N, co))
         out = torch.empty(B, T, co // 4, Hh, Ww, dtype=torch.bfloat16, device=self.dev)
         ops.unpatchify(y, out)
+        if sh.p2p is not None:
+            sh.p2p.poison(out)             # NaN instead of numbers if any wait of this group ever gave up (sticky)
         return out
 
     def _r_lnlin(self, x, tmp, ln, pk, key, w, b, out, act=None):

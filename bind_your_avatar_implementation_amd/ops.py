@@ -205,6 +205,12 @@ def check_gemm_workspace(device=None):
         n = attn_workspace_status(device)
         if n:
             raise _hip.ByaError(f"{n} stream-K hand-off(s) of the joint attention timed out: results of this run are not to be trusted")
+    # ... and no wait of a P2P exchange gave up (sharded runs; the step's output is NaN-poisoned as well, parallel / p2p.py)
+    import sys
+    p2p = sys.modules.get(__package__ + ".p2p")
+    if p2p is not None:
+        for g in list(p2p.LIVE_GROUPS):
+            g.check()
 
 
 _ATTN_WS = {}          # device index -> stream-K exchange workspace of the joint-attention kernel
@@ -501,7 +507,7 @@ def router_scores(qr, kr, ln_w, ln_b, pos_emb, out, n_id, N, eps=1e-5):
     lib = _hip.load()
     for t in (qr, kr, ln_w, ln_b, pos_emb, out):
         assert t.is_contiguous() and t.dtype == torch.bfloat16
-    tok = _begin("bya_router_scores")
+    tok = _begin("bya_router_scores", 2.0 * n_id * N * 32 * qr.shape[-1])
     check(lib.bya_router_scores(_p(qr), _p(kr), _p(ln_w), _p(ln_b), _p(pos_emb), _p(out), n_id, N, 16, 32,
                                 float(eps), _stream()), "bya_router_scores")
     _end(tok)

@@ -1,36 +1,84 @@
 """P2P exchange engine, host side: the exchanges of the sharded denoise step as PUSH kernels that store straight into
-the peers' HBM over xGMI (``bya_p2p_push`` / ``bya_p2p_wait``, csrc/comm.hip, include/bya.h).
+the peers' HBM over xGMI (``bya_p2p_push`` / ``bya_p2p_wait`` / ``bya_p2p_exchange``, csrc/comm.hip, include/bya.h).
 
 The reference has no inference parallelism; BASELINE.json asks for it.  Round 3 issued every
 exchange through ``torch.distributed`` (RCCL): ~360 collectives per rank-step at ~20 us each, none of which can be
 captured in a hipGraph on this stack.  Here an exchange is ONE ordinary kernel launch whatever its scatter/gather list,
 and the whole sharded step replays as a graph.
 
-``P2PGroup(group, device)``        one per process group; collective (every rank constructs it at the same point)
-``.symmetric(name, shape, dtype)``  a buffer every rank allocates under the same name: returns the local tensor; peers'
-                                    copies are mapped into this process through hipIpc (torch's CUDA storage sharing),
-                                    handles traded ONCE over the process group (any backend: gloo works)
+``P2PGroup(group, device, mem)``    one per process group; collective (every rank constructs it at the same point).
+                                    ``mem`` = kind of the RECEIVE buffers: "coarse" (ordinary device memory, cached in the
+                                    L2s, made coherent by the acquire at the end of every wait) or "fine" (fine-grained:
+                                    coherent by construction, slower to read).  The control block (flags a running kernel
+                                    polls while peers store into them) is fine-grained whenever the platform hands it out.
+``.symmetric(name, shape, dtype)``  a buffer every rank allocates under the same name: returns the local tensor; the peers'
+                                    copies are mapped into this process through hipIpc (torch's CUDA storage sharing for
+                                    coarse memory, ``bya_p2p_ipc_*`` for the other kinds); handles traded ONCE over the
+                                    process group (any backend: gloo works)
 ``.channel(key, pieces)``          the channel (control block, sequence counters) of the logical exchange ``key``, bound to
                                     the copy table of ``pieces`` = [(src, peer, name, offset)], "copy the contiguous local
                                     tensor ``src`` to element ``offset`` of buffer ``name`` on rank ``peer``"; one table per
-                                    set of source addresses (workspaces change, captured graphs own theirs), built once
-``Channel.exchange(side=False)``   push + wait on the current stream (``side``: the push runs on the group's side stream
-                                    behind the work already enqueued; call ``.wait()`` where the data is needed)
+                                    set of source addresses (workspaces change, captured graphs own theirs)
+``Channel.exchange()``             push + wait as ONE launch on the current stream
+``Channel.push(side) / .wait()``   the two halves (``side``: the push runs on the group's side stream behind the work
+                                    already enqueued; call ``.wait()`` where the data is needed)
+``.poison(out)``                   last launch of a sharded step: NaN over ``out`` if any wait of this group ever gave up
 
 All ranks of the group must issue the same sequence of ``symmetric`` calls and, per channel, the same sequence of
 exchanges (sequence numbers live in device memory, one pair per channel).  One process per GPU in production; the tests
 run several processes on ONE GPU -- hipIpc maps a peer's buffer of the same device just the same.
 """
+import collections
 import ctypes
+import os
+import weakref
 
 import torch
 import torch.distributed as dist
 
 from . import _hip
 
-MAX_CHANNELS = 64
+MAX_CHANNELS = 256
 CTRL_WORDS = 64
 CHUNK = 64 * 1024
+KINDS = {"coarse": 0, "fine": 1, "uncached": 2}
+TABLES_PER_CHANNEL = 4           # copy tables kept per channel besides the ones a captured graph owns
+LIVE_GROUPS = weakref.WeakSet()  # every P2PGroup of this process (ops.check_gemm_workspace asks each for timed-out waits)
+
+
+class _FineUnavailable(RuntimeError):
+    """This platform (or one rank of the group) did not hand out fine-grained / uncached device memory."""
+
+
+class _Block:
+    """Device memory from ``bya_p2p_alloc`` (or a peer's, mapped by ``bya_p2p_ipc_import``) as an object torch can wrap."""
+
+    def __init__(self, ptr, nbytes, mine):
+        self.ptr, self.nbytes, self.mine = ptr, nbytes, mine
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    def release(self):
+        lib = _hip.load()
+        if self.ptr:
+            (lib.bya_p2p_free if self.mine else lib.bya_p2p_ipc_release)(self.ptr)
+            self.ptr = 0
+
+
+class _Peer:
+    """What the copy tables need of a peer's buffer: where it is mapped here, how big it is, what it holds."""
+
+    def __init__(self, ptr, shape, dtype, keep=None):
+        self._ptr, self.shape, self.dtype, self._keep = ptr, tuple(shape), dtype, keep
+        n = 1
+        for s in self.shape:
+            n *= s
+        self._n = n
+
+    def data_ptr(self):
+        return self._ptr
+
+    def numel(self):
+        return self._n
 
 
 class Channel:
@@ -38,14 +86,16 @@ class Channel:
     pointers it has been used with, a device-resident copy table.  The engine re-allocates its workspace when the geometry
     changes and gives every captured hipGraph a workspace of its own: the SAME logical exchange then comes with other
     source addresses -- it keeps its channel (and its sequence numbers, which all ranks advance in step) and gets one more
-    table; tables are never freed (a captured graph may hold their address; they are ~32 bytes per piece)."""
+    table.  A table keeps its source tensors alive; tables bound during a stream capture stay for good (the graph holds their
+    address), of the others only the ``TABLES_PER_CHANNEL`` most recently used ones are kept, so a server that moves between
+    geometries does not pin every workspace it ever had."""
 
     def __init__(self, grp, index):
         self.grp, self.index = grp, index
         self.ctrl_ptr = grp.ctrl[index].data_ptr()
-        self.peer_ctrl = torch.tensor([grp.ctrl_peers[j][index].data_ptr() for j in range(grp.world)], dtype=torch.int64,
-                                      device=grp.dev)
-        self.tables = {}                 # source-pointer signature -> (table tensor, n_copies, total_chunks, sources)
+        self.peer_ctrl = torch.tensor([grp.ctrl_peers[j].data_ptr() + index * CTRL_WORDS * 4 for j in range(grp.world)],
+                                      dtype=torch.int64, device=grp.dev)
+        self.tables = collections.OrderedDict()      # source-pointer signature -> [table, n_copies, total_chunks, sources, pinned]
         self.cur = None
         self._join = None
 
@@ -53,14 +103,27 @@ class Channel:
         sig = tuple((p[0].data_ptr(), p[1], p[2], p[3], p[0].numel()) for p in pieces)
         ent = self.tables.get(sig)
         if ent is None:
-            ent = self.tables[sig] = self.grp._build_table(pieces)
+            ent = self.tables[sig] = list(self.grp._build_table(pieces)) + [False]
+        else:
+            self.tables.move_to_end(sig)
+        if torch.cuda.is_current_stream_capturing():
+            ent[4] = True
+        loose = [k for k, e in self.tables.items() if not e[4]]
+        for k in loose[:max(0, len(loose) - TABLES_PER_CHANNEL)]:
+            if k != sig:
+                del self.tables[k]
         self.cur = ent
         return self
 
+    def _launch(self, fn, stream):
+        g = self.grp
+        table, n, total_chunks = self.cur[:3]
+        _hip.check(fn(table.data_ptr(), n, total_chunks, self.peer_ctrl.data_ptr(), g.world, g.rank, self.ctrl_ptr,
+                      stream.cuda_stream), fn.__name__)
+        g.pushes += 1
+
     def push(self, side=False):
         g = self.grp
-        lib = _hip.load()
-        table, n, total_chunks, _ = self.cur
         cur = torch.cuda.current_stream(g.dev)
         stream = cur
         if side and g.world > 1:
@@ -68,13 +131,11 @@ class Channel:
             ev = torch.cuda.Event()
             ev.record(cur)
             stream.wait_event(ev)
-        _hip.check(lib.bya_p2p_push(table.data_ptr(), n, total_chunks, self.peer_ctrl.data_ptr(), g.world, g.rank,
-                                    self.ctrl_ptr, stream.cuda_stream), "bya_p2p_push")
+        self._launch(_hip.load().bya_p2p_push, stream)
         self._join = None
         if stream is not cur:
             self._join = torch.cuda.Event()
             self._join.record(stream)
-        g.pushes += 1
         return self
 
     def wait(self):
@@ -87,15 +148,24 @@ class Channel:
         return self
 
     def exchange(self):
-        return self.push().wait()
+        """push + wait in one launch (``P2PGroup.MERGED = False``: as two, the round-4 form)."""
+        if not self.grp.MERGED:
+            return self.push().wait()
+        self._launch(_hip.load().bya_p2p_exchange, torch.cuda.current_stream(self.grp.dev))
+        return self
 
 
 class P2PGroup:
-    def __init__(self, group=None, device=None):
+    MERGED = True
+
+    def __init__(self, group=None, device=None, mem="coarse"):
         self.group = group if group is not None else dist.group.WORLD
         self.world, self.rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         if self.world > 32:
             raise ValueError("P2P exchange engine: at most 32 ranks (one node)")
+        if mem not in KINDS:
+            raise ValueError(f"P2P memory kind {mem!r}: expected one of {sorted(KINDS)}")
+        self.mem = mem
         self.dev = torch.device(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
         self._named = {}
         self._keep = []
@@ -103,46 +173,110 @@ class P2PGroup:
         self._p2p_enabled = set()
         self.pushes = 0
         self.side_stream = torch.cuda.Stream(self.dev)
-        self.ctrl = self.symmetric("__ctrl__", (MAX_CHANNELS, CTRL_WORDS), torch.int32, zero=True)
+        limit = os.environ.get("BYA_P2P_TIMEOUT")            # seconds a wait may take before it gives up (default 30)
+        if limit:
+            _hip.check(_hip.load().bya_p2p_set_wait_limit_ms(int(float(limit) * 1000)), "bya_p2p_set_wait_limit_ms")
+        # the control block: peers store flags into it while this GPU's wait kernels poll them -> fine-grained memory
+        # where the platform hands it out (RCCL allocates its flags that way for the same reason); coarse otherwise
+        try:
+            self.ctrl = self.symmetric("__ctrl__", (MAX_CHANNELS, CTRL_WORDS), torch.int32, zero=True, kind="fine")
+            self.ctrl_kind = "fine"
+        except _FineUnavailable:
+            self.ctrl = self.symmetric("__ctrl__", (MAX_CHANNELS, CTRL_WORDS), torch.int32, zero=True, kind="coarse")
+            self.ctrl_kind = "coarse"
         self.ctrl_peers = self._named["__ctrl__"][1]
+        LIVE_GROUPS.add(self)
 
     # ---- symmetric buffers -------------------------------------------------------------------------------------------
-    def symmetric(self, name, shape, dtype=torch.bfloat16, zero=False):
+    def symmetric(self, name, shape, dtype=torch.bfloat16, zero=False, kind=None):
         """COLLECTIVE on first use of ``name`` (every rank, same order).  -> local tensor; ``peers(name)[j]`` = rank j's
-        tensor mapped here, in rank j's OWN shape (shapes may differ between ranks: uneven shards)."""
+        buffer mapped here, in rank j's OWN shape (shapes may differ between ranks: uneven shards)."""
         ent = self._named.get(name)
         if ent is not None:
             loc = ent[0]
             if tuple(loc.shape) != tuple(shape) or loc.dtype != dtype:
                 raise ValueError(f"symmetric buffer {name!r} exists with shape {tuple(loc.shape)} {loc.dtype}")
             return loc
+        kind = kind or self.mem
         with torch.cuda.device(self.dev):
-            # the WHOLE allocation is what a peer maps, and it must stay alive for as long as any peer may store into it
-            # (= the life of this object)
-            local = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.dev)
-            torch.cuda.synchronize(self.dev)
-            peers = [None] * self.world
-            peers[self.rank] = local
+            local, peers = (self._symmetric_torch if kind == "coarse" else self._symmetric_ext)(shape, dtype, zero, kind)
             if self.world > 1:
-                info = local.untyped_storage()._share_cuda_()
-                infos = [None] * self.world
-                dist.all_gather_object(infos, (info, local.storage_offset(), tuple(shape)), group=self.group)
-                for j, (inf, off, shp) in enumerate(infos):
-                    if j == self.rank:
-                        continue
-                    st = torch.UntypedStorage._new_shared_cuda(*inf)
-                    self._keep.append(st)
-                    # (the mapped storage carries the OWNER's device index; only its address is used, by kernels of this GPU)
-                    peers[j] = torch.empty(0, dtype=dtype, device=st.device).set_(st, off, shp)
-                    if st.device != self.dev and (self.dev.index, st.device.index) not in self._p2p_enabled:
-                        # one process sees several GPUs (torchrun without per-rank visibility): a kernel of THIS GPU may only
-                        # dereference the peer's memory once peer access is enabled; torch does that on the first P2P copy
-                        probe = torch.empty(1, dtype=dtype, device=self.dev)
-                        probe.copy_(peers[j].reshape(-1)[:1])
-                        self._p2p_enabled.add((self.dev.index, st.device.index))
                 dist.barrier(group=self.group)          # nobody pushes before everybody has mapped
         self._named[name] = (local, peers)
         return local
+
+    def _symmetric_torch(self, shape, dtype, zero, kind):
+        # the WHOLE allocation is what a peer maps, and it must stay alive for as long as any peer may store into it
+        # (= the life of this object)
+        local = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.dev)
+        torch.cuda.synchronize(self.dev)
+        peers = [None] * self.world
+        peers[self.rank] = _Peer(local.data_ptr(), shape, dtype, local)
+        if self.world > 1:
+            info = local.untyped_storage()._share_cuda_()
+            infos = [None] * self.world
+            dist.all_gather_object(infos, (info, local.storage_offset(), tuple(shape)), group=self.group)
+            for j, (inf, off, shp) in enumerate(infos):
+                if j == self.rank:
+                    continue
+                st = torch.UntypedStorage._new_shared_cuda(*inf)
+                # (the mapped storage carries the OWNER's device index; only its address is used, by kernels of this GPU)
+                t = torch.empty(0, dtype=dtype, device=st.device).set_(st, off, shp)
+                if st.device != self.dev and (self.dev.index, st.device.index) not in self._p2p_enabled:
+                    # one process sees several GPUs (torchrun without per-rank visibility): a kernel of THIS GPU may only
+                    # dereference the peer's memory once peer access is enabled; torch does that on the first P2P copy
+                    probe = torch.empty(1, dtype=dtype, device=self.dev)
+                    probe.copy_(t.reshape(-1)[:1])
+                    self._p2p_enabled.add((self.dev.index, st.device.index))
+                peers[j] = _Peer(t.data_ptr(), shp, dtype, (st, t))
+        return local, peers
+
+    def _symmetric_ext(self, shape, dtype, zero, kind):
+        """Fine-grained / uncached memory: ``bya_p2p_alloc`` (zero-filled), handles by ``bya_p2p_ipc_export / import``.  Every
+        rank reports whether it got its memory BEFORE anybody maps anything, so a refusal raises on all ranks together."""
+        lib = _hip.load()
+        n = 1
+        for s in shape:
+            n *= s
+        nbytes = max(n * torch.empty(0, dtype=dtype).element_size(), 16)
+        ptr, handle, err = ctypes.c_void_p(0), (ctypes.c_ubyte * 64)(), None
+        rc = lib.bya_p2p_alloc(nbytes, KINDS[kind], ctypes.byref(ptr))
+        if rc != 0 or not ptr.value:
+            err = f"bya_p2p_alloc({kind}) -> {_hip.ERRORS.get(rc, rc)}"
+        elif self.world > 1:
+            rc = lib.bya_p2p_ipc_export(ptr, handle)
+            if rc != 0:
+                err = f"bya_p2p_ipc_export -> {_hip.ERRORS.get(rc, rc)}"
+        local = None
+        if err is None:
+            try:
+                blk = _Block(ptr.value, nbytes, True)
+                local = torch.as_tensor(blk, device=self.dev)[:n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(*shape)
+                self._keep.append(blk)
+            except Exception as e:                      # noqa: BLE001  (torch without the array interface on this platform)
+                err = f"torch.as_tensor over device memory: {e!r}"
+        infos = [(err, bytes(handle), tuple(shape))]
+        if self.world > 1:
+            infos = [None] * self.world
+            dist.all_gather_object(infos, (err, bytes(handle), tuple(shape)), group=self.group)
+        bad = [(j, i[0]) for j, i in enumerate(infos) if i[0] is not None]
+        if bad:
+            if ptr.value and local is None:
+                lib.bya_p2p_free(ptr)
+            raise _FineUnavailable(f"{kind} device memory unavailable on rank(s) {bad}")
+        peers = [None] * self.world
+        peers[self.rank] = _Peer(local.data_ptr(), shape, dtype, local)
+        for j, (_, h, shp) in enumerate(infos):
+            if j == self.rank:
+                continue
+            p = ctypes.c_void_p(0)
+            rc = lib.bya_p2p_ipc_import((ctypes.c_ubyte * 64).from_buffer_copy(h), ctypes.byref(p))
+            if rc != 0 or not p.value:
+                raise RuntimeError(f"bya_p2p_ipc_import of rank {j}'s buffer -> {_hip.ERRORS.get(rc, rc)}")
+            blk = _Block(p.value, 0, False)
+            self._keep.append(blk)
+            peers[j] = _Peer(p.value, shp, dtype, blk)
+        return local, peers
 
     def peers(self, name):
         return self._named[name][1]
@@ -182,17 +316,43 @@ class P2PGroup:
         table = torch.tensor(rows, dtype=torch.int64, device=self.dev)
         return table, len(rows), chunk0, [p[0] for p in pieces]      # (the sources stay alive with the table)
 
-    def self_test(self):
-        """One tiny all-to-all through the engine, checked: every rank must see every peer's value (raises otherwise).
-        Run once at set-up, so that a platform where peer stores do not arrive is noticed before the first step."""
-        n = 64
-        recv = self.symmetric("__selftest__", (self.world, n), torch.float32, zero=True)
-        send = [torch.full((n,), 1000.0 + self.rank * 32 + j, dtype=torch.float32, device=self.dev) for j in range(self.world)]
-        self.channel("__selftest__", [(send[j], j, "__selftest__", self.rank * n) for j in range(self.world)]).exchange()
-        want = torch.tensor([1000.0 + r * 32 + self.rank for r in range(self.world)], device=self.dev)[:, None].expand(-1, n)
+    def drop_tables(self):
+        """Forget every copy table no captured graph owns (the engine calls this when it lets go of a workspace)."""
+        for ch in self._channels.values():
+            for k in [k for k, e in ch.tables.items() if not e[4]]:
+                del ch.tables[k]
+            ch.cur = None
+
+    # ---- health ----------------------------------------------------------------------------------------------------------
+    def self_test(self, rounds=24, elems=256 * 1024):
+        """``rounds`` all-to-alls of ``elems`` int32 per peer INTO THE SAME receive buffer, payload changing every round, every
+        word checked, with the consumer's reads (which leave the buffer's lines in this GPU's caches) and an acknowledging
+        exchange between two pushes -- the re-use pattern of the step, where a stale line shows if remote stores are not seen.
+        Alternates the one-launch and the two-launch form.  Raises if anything differs or a wait gave up.  Run once at set-up,
+        so that a platform where peer stores do not arrive (or arrive late) is noticed before the first step."""
+        W, n = self.world, elems
+        recv = self.symmetric("__selftest__", (W, n), torch.int32, zero=True)
+        send = torch.zeros(W, n, dtype=torch.int32, device=self.dev)
+        ramp = torch.arange(n, dtype=torch.int32, device=self.dev)
+        data = self.channel("__selftest__", [(send[j], j, "__selftest__", self.rank * n) for j in range(W)])
+        empty = torch.zeros(0, dtype=torch.int32, device=self.dev)
+        ack = self.channel("__selftest_ack__", [(empty, j, "__selftest__", 0) for j in range(W)])
+        src = torch.arange(W, dtype=torch.int32, device=self.dev)[:, None]
+        bad = torch.zeros((), dtype=torch.int64, device=self.dev)
+        for it in range(rounds):
+            for j in range(W):
+                send[j] = ramp * (it + 1) + (self.rank * 64 + j) * 1000003 + it * 7919
+            if it % 2:
+                data.push().wait()
+            else:
+                data.exchange()
+            want = ramp[None, :] * (it + 1) + (src * 64 + self.rank) * 1000003 + it * 7919
+            bad += (recv != want).sum()                  # the consumer: reads every word through the ordinary cache path
+            ack.exchange()                               # "consumed": peers may overwrite the buffer from here on
         torch.cuda.synchronize(self.dev)
-        if self.timeouts() or not torch.equal(recv, want):
-            raise RuntimeError("P2P exchange self-test failed: peer stores did not arrive")
+        if self.timeouts() or int(bad.item()):
+            raise RuntimeError(f"P2P exchange self-test failed: {int(bad.item())} stale or missing words, "
+                               f"{self.timeouts()} timed-out waits ({self.mem} receive buffers, {self.ctrl_kind} flags)")
         if self.world > 1:
             dist.barrier(group=self.group)
 
@@ -201,4 +361,17 @@ class P2PGroup:
         torch.cuda.synchronize(self.dev)
         return int(self.ctrl[:, 35].sum().item())
 
+    def check(self):
+        """Raise if any wait of this group ever gave up (its consumers ran on a stale receive buffer)."""
+        n = self.timeouts()
+        if n:
+            raise _hip.ByaError(f"{n} P2P wait(s) timed out (a peer's push did not arrive within the limit, BYA_P2P_TIMEOUT): "
+                                f"results of this run are not to be trusted")
+
+    def poison(self, out):
+        """Enqueue ``bya_p2p_poison``: ``out`` (bf16) becomes NaN if any channel of this group carries a time-out."""
+        assert out.dtype == torch.bfloat16 and out.is_contiguous()
+        _hip.check(_hip.load().bya_p2p_poison(self.ctrl.data_ptr(), MAX_CHANNELS, out.data_ptr(), out.numel(),
+                                              torch.cuda.current_stream(self.dev).cuda_stream), "bya_p2p_poison")
+        return out
 

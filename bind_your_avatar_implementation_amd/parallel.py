@@ -100,6 +100,12 @@ class SeqShard:
         _count("p2p_exchange")
         return ch.push(side=side)
 
+    def _exchange(self, key, pieces):
+        """push + wait as ONE launch (the exchanges nothing is overlapped with)."""
+        ch = self.p2p.channel(("seq", key, self.S, self.Tt), pieces)
+        _count("p2p_exchange")
+        return ch.exchange()
+
     def staged(self, t):
         """gloo has no device collectives (single-GPU functional tests, CPU tests): stage through host memory."""
         return t.is_cuda and dist.get_backend(self.group) == "gloo"
@@ -139,16 +145,8 @@ class SeqShard:
         if not self.active:
             return local
         if self.p2p is not None:
-            F = local[0].numel()
-            name = f"gr:{(self.S, F)}"
-            full = self.p2p.symmetric(name, (self.S, F), local.dtype)
-            src = local.contiguous().view(self.S_loc, F)
-            self._push("gr", [(src, j, name, self.r0 * F) for j in range(self.world)]).wait()
-            full = full.view(self.S, *local.shape[1:])
-            if out is None:
-                return full.clone()
-            out.copy_(full)
-            return out
+            res = self.gather_rows_many([local], None if out is None else [out])[0]
+            return res
         if self.even:
             if out is None:
                 out = torch.empty(self.S, *local.shape[1:], dtype=local.dtype, device=local.device)
@@ -159,6 +157,36 @@ class SeqShard:
             out.copy_(res)
             return out
         return res.clone()                  # (res lives in a reused staging buffer)
+
+    def begin_step(self):
+        """Called by the engine at the top of a step: the parity of ``gather_rows_many``'s double buffer restarts, so that a
+        replayed hipGraph (parities baked in at capture) and eager steps agree.  Safe across the step boundary: a step ends
+        with the output gather, an exchange every rank joins after it has consumed its last gathered rows."""
+        self._gr_parity = 0
+
+    def gather_rows_many(self, locals_, outs=None):
+        """P2P transport: several [S_loc, F] tensors of this rank (k and v of one layer) -> their [S, F] forms on every rank
+        in ONE exchange.  The receive buffer alternates between two copies by call parity: a peer can only be one exchange
+        ahead of this rank (it passed the wait of exchange n, for which this rank pushed AFTER copying exchange n - 1 out), so
+        exchange n + 1 never lands in rows this rank is still copying out of (round 4 re-used one buffer for k, then v, then
+        the next layer's k with nothing ordering the peer's push behind this rank's copy)."""
+        C = len(locals_)
+        F = locals_[0][0].numel()
+        par = getattr(self, "_gr_parity", 0)
+        self._gr_parity = par ^ 1
+        name = f"gr{par}:{(C, self.S, F)}"
+        full = self.p2p.symmetric(name, (C, self.S, F), locals_[0].dtype)
+        srcs = [t.contiguous().view(self.S_loc, F) for t in locals_]
+        self._exchange(("gr", C, F, par), [(srcs[c], j, name, (c * self.S + self.r0) * F) for j in range(self.world) for c in range(C)])
+        res = []
+        for c, t in enumerate(locals_):
+            fc = full[c].view(self.S, *t.shape[1:])
+            if outs is None:
+                res.append(fc.clone())
+            else:
+                outs[c].copy_(fc)
+                res.append(outs[c])
+        return res
 
     def gather_video_rows(self, local_video, scratch=None, out=None):
         """[..., N_loc, F] per rank (rank 0 owns fewer video rows: its shard starts with the text rows)
@@ -176,7 +204,7 @@ class SeqShard:
             name = f"gv:{(C, self.N, F)}"
             full = self.p2p.symmetric(name, (C, self.N, F), flat.dtype)
             src = flat.contiguous()
-            self._push("gv", [(src[c], j, name, (c * self.N + self.v0) * F) for j in range(self.world) for c in range(C)]).wait()
+            self._exchange("gv", [(src[c], j, name, (c * self.N + self.v0) * F) for j in range(self.world) for c in range(C)])
             if out is None:
                 return full.view(*lead, self.N, F).clone()
             out.view(C, self.N, F).copy_(full)
@@ -218,16 +246,17 @@ class SeqShard:
             h = self._a2a(out.view(-1), blocks.reshape(-1), [n * Dl for n in self.sizes], [S_loc * Dl] * W, async_op=async_op)
         return h if async_op else out
 
-    def rows_to_heads_qkv(self, blocks, side=False):
+    def rows_to_heads_qkv(self, blocks):
         """P2P transport: the packed projection's column blocks [3 * world, S_loc, Dl] (block t * world + j = tensor t of
-        q | k | v, heads of rank j) -> ONE exchange into the symmetric [3, S, Dl] buffer of every destination.  Returns
-        (channel handle, q_heads, k_heads, v_heads); call ``handle.wait()`` before the attention."""
+        q | k | v, heads of rank j) -> ONE exchange (one launch) into the symmetric [3, S, Dl] buffer of every destination.
+        Returns (q_heads, k_heads, v_heads), complete for every kernel enqueued behind the call."""
         W3, S_loc, Dl = blocks.shape
         W = self.world
         name = f"qkvh:{(3, self.S, Dl)}"
         full = self.p2p.symmetric(name, (3, self.S, Dl), blocks.dtype)
         pieces = [(blocks[t * W + j], j, name, (t * self.S + self.r0) * Dl) for j in range(W) for t in range(3)]
-        return self._push("qkvh", pieces, side=side), full[0], full[1], full[2]
+        self._exchange("qkvh", pieces)
+        return full[0], full[1], full[2]
 
     def heads_to_rows(self, o_heads, out=None):
         """o_heads [S, Dl] (all rows, this rank's heads) -> [S_loc, world*Dl] (this rank's rows, all heads).  The
@@ -236,11 +265,13 @@ class SeqShard:
         put underneath it -- what the side stream buys here is that the exchange never queues behind unrelated compute."""
         S, Dl = o_heads.shape
         if self.p2p is not None:
-            name = f"h2r:{Dl}"
+            # (the name carries the geometry like every other symmetric buffer: one P2PGroup serves every resolution and frame
+            # count the model is run at)
+            name = f"h2r:{(self.S, self.world, Dl)}"
             recv = self.p2p.symmetric(name, (self.world, self.S_loc, Dl), o_heads.dtype)       # (rank j: [W, sizes[j], Dl])
             pieces = [(o_heads[self.starts[j]:self.starts[j] + self.sizes[j]], j, name, self.rank * self.sizes[j] * Dl)
                       for j in range(self.world)]
-            self._push("h2r", pieces).wait()
+            self._exchange("h2r", pieces)
             if out is None:
                 out = torch.empty(self.S_loc, self.world * Dl, dtype=o_heads.dtype, device=o_heads.device)
             out.view(self.S_loc, self.world, Dl).copy_(recv.permute(1, 0, 2))
@@ -321,6 +352,11 @@ class RouterPartition:
         _count("p2p_exchange")
         return ch.push(side=side)
 
+    def _exchange(self, key, pieces):
+        ch = self.p2p.channel(("router", key, self.pairs, self.per_frame), pieces)
+        _count("p2p_exchange")
+        return ch.exchange()
+
     def _name(self, base, shape):
         return f"{base}:{(self.pairs, self.per_frame)}:{tuple(shape)}"
 
@@ -355,7 +391,7 @@ class RouterPartition:
                 owner = next(j for j, (a, b) in enumerate(self.PA) if a <= pair < b)
                 pieces.append((src[i, v - v0:end - v0], owner, name, ((pair - self.PA[owner][0]) * pf + (v - f * pf)) * F))
                 v = end
-        self._push("t2a", pieces).wait()
+        self._exchange("t2a", pieces)
         return xa
 
     def a_to_b(self, xa, xb=None, overlap=None):
@@ -376,9 +412,11 @@ class RouterPartition:
             for j, ((a, b), n) in enumerate(zip(self.LB, in_splits)):
                 pieces.append((send[off:off + n], j, name, self.pa0 * (b - a) * F))     # (peer j's copy has ITS shape)
                 off += n
-            h = self._push("a2b", pieces, side=overlap is not None)
-            if overlap is not None:
-                overlap()
+            if overlap is None:
+                self._exchange("a2b", pieces)
+                return xb
+            h = self._push("a2b", pieces, side=True)
+            overlap()
             h.wait()
             return xb
         if xb is None:
@@ -404,7 +442,7 @@ class RouterPartition:
             name = self._name("b2a_recv", (sum(out_splits),))
             before = self.LB[self.rank][0]                          # locations owned by lower ranks
             pieces = [(xb[a:b], j, name, (b - a) * before * F) for j, (a, b) in enumerate(self.PA)]
-            self._push("b2a", pieces).wait()
+            self._exchange("b2a", pieces)
         else:
             recv = self.buf("b2a_recv", (sum(out_splits),), xb)
             h = self._a2a(recv, xb.reshape(-1), out_splits, in_splits)
@@ -426,7 +464,7 @@ class RouterPartition:
         if self.p2p is not None:
             full = self.recv_buf("gb_full", (self.world * lead, nmax, C), yb)
             name = self._name("gb_full", (self.world * lead, nmax, C))
-            self._push("gb", [(pad, j, name, self.rank * lead * nmax * C) for j in range(self.world)]).wait()
+            self._exchange("gb", [(pad, j, name, self.rank * lead * nmax * C) for j in range(self.world)])
             full = full.view(self.world, lead, nmax, C)
             if out is None:
                 out = torch.empty(lead, self.per_frame, C, dtype=yb.dtype, device=yb.device)
@@ -449,35 +487,54 @@ class RouterPartition:
         return out
 
 
+TRANSPORTS = ("p2p", "p2p-fine", "torch")
+
+
 def shard_sequence(model, group=None, transport=None):
     """Switch ``model`` (BindyouravatarTransformer3DModel) to sequence-parallel execution over ``group``.
-    ``transport``: "p2p" (default on GPUs; BYA_SP_TRANSPORT) = push kernels over peer-mapped buffers, "torch" =
-    torch.distributed collectives.  COLLECTIVE: every rank of the group calls it at the same point."""
+    ``transport`` (BYA_SP_TRANSPORT), a ladder the ranks walk TOGETHER from the rung asked for (default: the first on GPUs,
+    the last on CPUs) until one passes its set-up test on every rank:
+      "p2p"       push kernels into the peers' ordinary (coarse-grained, L2-cached) receive buffers -- the fast form;
+      "p2p-fine"  the same into fine-grained receive buffers (BYA_P2P_MEM=fine: coherent by construction, slower to read);
+      "torch"     torch.distributed collectives (RCCL on the nccl backend).
+    ``model._seq_transport`` names the rung that runs.  The set-up test is ``P2PGroup.self_test`` (repeated exchanges into a
+    re-used buffer with consumer reads in between, every word checked); ``bench.py --gpus N`` additionally compares the sharded
+    step with the unsharded one and moves down the ladder on a difference.  COLLECTIVE: every rank of the group calls it at the
+    same point."""
     model._seq_group = group if group is not None else dist.group.WORLD
     model._seq_world = dist.get_world_size(model._seq_group)
     model._seq_rank = dist.get_rank(model._seq_group)
     transport = transport or os.environ.get("BYA_SP_TRANSPORT") or ("p2p" if torch.cuda.is_available() else "torch")
-    if transport not in ("p2p", "torch"):
-        raise ValueError(f"unknown transport {transport!r}")
-    model._seq_p2p = None
-    if transport == "p2p":
+    if transport == "p2p" and os.environ.get("BYA_P2P_MEM") == "fine":
+        transport = "p2p-fine"
+    if transport not in TRANSPORTS:
+        raise ValueError(f"unknown transport {transport!r}: expected one of {TRANSPORTS}")
+    old = getattr(model, "_seq_p2p", None)
+    if old is not None:
+        old.drop_tables()
+    model._seq_p2p, model._seq_transport, notes = None, "torch", []
+    for rung in TRANSPORTS[TRANSPORTS.index(transport):]:
+        if rung == "torch":
+            break
         from .p2p import P2PGroup
         dev = next(model.parameters()).device
         p2p, err = None, None
         try:
-            p2p = P2PGroup(model._seq_group, dev)
+            p2p = P2PGroup(model._seq_group, dev, mem="fine" if rung == "p2p-fine" else "coarse")
             p2p.self_test()
-        except Exception as e:              # no hipIpc on this platform, peer access refused, ...
+        except Exception as e:              # no hipIpc on this platform, peer access refused, stale words, ...
             err = e
         # every rank must agree: one rank on collectives and another on push kernels would deadlock
         ok = [None] * model._seq_world
         dist.all_gather_object(ok, err is None, group=model._seq_group)
         if all(ok):
-            model._seq_p2p = p2p
-        else:
-            import warnings
-            warnings.warn(f"P2P exchange engine unavailable ({err!r} on this rank; ranks ok: {ok}): falling back to "
-                          "torch.distributed collectives")
+            model._seq_p2p, model._seq_transport = p2p, rung
+            break
+        notes.append(f"{rung}: {err!r} on this rank; ranks ok: {ok}")
+    if notes:
+        import warnings
+        warnings.warn("P2P exchange engine: " + "; ".join(notes) + f" -> running on {model._seq_transport!r}")
+    model._seq_transport_notes = notes
     model.invalidate_engine()
     return model
 
@@ -491,6 +548,7 @@ class CfgSplit:
 
     def __init__(self, group=None):
         group = group if group is not None else dist.group.WORLD
+        self.parent = group
         ranks = dist.get_process_group_ranks(group)
         W = len(ranks)
         if W % 2:
@@ -546,12 +604,14 @@ class CfgSplit:
         return out
 
 
-def shard_cfg(model, group=None):
+def shard_cfg(model, group=None, transport=None):
     """Run the two samples of a CFG batch on two halves of ``group``; inside a half the step is sequence-parallel
-    when the half has more than one rank (2 x 2, 2 x 4).  Batch-1 calls fall through to plain execution on the half."""
-    model._cfg = CfgSplit(group)
+    when the half has more than one rank (2 x 2, 2 x 4; ``transport`` as for ``shard_sequence``).  Batch-1 calls fall
+    through to plain execution on the half.  Calling it again (another transport) keeps the process groups."""
+    if getattr(model, "_cfg", None) is None or model._cfg.parent is not (group if group is not None else dist.group.WORLD):
+        model._cfg = CfgSplit(group)
     if model._cfg.half_size > 1:
-        shard_sequence(model, model._cfg.seq_group)
+        shard_sequence(model, model._cfg.seq_group, transport=transport)
     else:
         model.invalidate_engine()
     return model

@@ -5,7 +5,8 @@ zeroed identity / audio-face conditioning), ``transformer.forward``, CFG combine
 
 Out of scope (third-party models that run once outside the loop): T5 prompt encoding, VAE
 encode/decode, key-point drawing.  Consequently ``prompt_embeds`` / ``negative_prompt_embeds`` and the condition
-latents are passed as tensors and ``output_type`` must be ``"latent"``; passing ``prompt`` / ``image`` raises.
+latents are passed as tensors and ``output_type`` must be ``"latent"`` (the default is the reference's ``"pil"``, which
+needs the VAE); passing ``prompt`` / ``image`` raises.
 
 Schedulers: ``DDIMScheduler`` / ``DPMScheduler`` hold the host side (float64 coefficient tables, per-step scalars) of
 diffusers' ``CogVideoXDDIMScheduler`` / ``CogVideoXDPMScheduler`` (v-prediction, scaled-linear betas with SNR shift 3.0,
@@ -198,7 +199,7 @@ class BindyouravatarPipeline:
                  num_frames: int = 49, num_inference_steps: int = 50, timesteps: Optional[List[int]] = None,
                  guidance_scale: float = 6, use_inpaint: bool = False, use_dynamic_cfg: bool = False,
                  num_videos_per_prompt: int = 1, eta: float = 0.0, generator=None, latents=None,
-                 prompt_embeds=None, negative_prompt_embeds=None, output_type: str = "latent",
+                 prompt_embeds=None, negative_prompt_embeds=None, output_type: str = "pil",
                  return_dict: bool = True, callback_on_step_end: Optional[Callable] = None,
                  callback_on_step_end_tensor_inputs: List[str] = ["latents"], max_sequence_length: int = 226,
                  id_vit_hidden=None, id_cond=None, kps_cond=None, audio_embs=None, af_matrix=None,
@@ -310,11 +311,28 @@ class BindyouravatarPipeline:
         if torch.device(dev).type == "cuda":    # end of the clip: no split-K hand-off timed out on the way (one sync, once)
             from . import ops
             ops.check_gemm_workspace(dev)
-        if output_type != "latent":
-            latents = self.decode_latents(latents)             # [B, 3, F, H, W] in the VAE's value range (about [-1, 1])
+        if output_type != "latent":                            # reference :967-971
+            latents = self.postprocess_video(self.decode_latents(latents), output_type)
         if not return_dict:
             return (latents,)
         return SimpleNamespace(frames=latents)
+
+    @staticmethod
+    def postprocess_video(video, output_type="pil"):
+        """diffusers ``VideoProcessor.postprocess_video`` (reference models/pipeline_bindyouravatar.py:969): decoded video
+        [B, 3, F, H, W] in about [-1, 1] -> per sample [F, 3, H, W] denormalised to [0, 1] (x / 2 + 0.5, clamped), returned as
+        ``"pt"``: one tensor [B, F, 3, H, W]; ``"np"``: float32 array [B, F, H, W, 3]; ``"pil"`` (the reference's default):
+        a list per sample of F ``PIL.Image`` frames (uint8 = round(255 x))."""
+        if output_type not in ("pt", "np", "pil"):
+            raise ValueError(f"{output_type} does not exist. Please choose one of ['np', 'pt', 'pil']")
+        vid = (video.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)           # [B, F, 3, H, W]
+        if output_type == "pt":
+            return vid
+        arr = vid.permute(0, 1, 3, 4, 2).cpu().numpy()                                 # [B, F, H, W, 3]
+        if output_type == "np":
+            return arr
+        from PIL import Image
+        return [[Image.fromarray(f) for f in (sample * 255).round().astype("uint8")] for sample in arr]
 
     def encode_image(self, image, generator=None):
         """image [B, 3, H, W] in [-1, 1] -> scaled latents [B, 1, C, H / 8, W / 8]: the posterior SAMPLE of every image on

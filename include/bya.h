@@ -23,6 +23,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the declarations below are its whole dynamic symbol table. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #ifndef __HIP_PLATFORM_AMD__
 typedef struct ihipStream_t* hipStream_t;
@@ -430,10 +434,15 @@ int bya_alltoall_router(const void* send, void* recv, const int64_t* send_counts
  * channel's control block ON PEER p (mapped), p < world, own rank included.
  * bya_p2p_push: copy every table entry, then publish the channel's next sequence number to word `rank` of every peer's
  * control block.  bya_p2p_wait (receiver, same channel, once per push of the peers): returns to the stream when all
- * `world` source ranks have published the receiver's next expected number; kernels enqueued behind it see the data.
- * Sequence numbers live in the control block (words 32 / 33): a hipGraph replay advances them by itself.  Word 35 counts
- * waits that gave up after ~1 s (0 on a healthy run).  The caller guarantees that a receive buffer is not pushed into
- * again before its owner has consumed it (the step's data dependencies do).
+ * `world` source ranks have published the receiver's next expected number; kernels enqueued behind it see the data (the
+ * wait runs as 16 small workgroups, dealt over the XCDs, each ending in a system-scope acquire).  bya_p2p_exchange = push
+ * and wait in ONE launch, for the exchanges nothing is overlapped with.
+ * Sequence numbers live in the control block (words 32 / 33): a hipGraph replay advances them by itself.  A wait is bounded
+ * by wall time (bya_p2p_set_wait_limit_ms; default 30 s); one that gives up counts itself in word 35 of its channel, which
+ * is sticky: bya_p2p_poison(ctrl_base, n_channels, out, n) -- enqueue it behind the last consumer of a step -- overwrites
+ * the bf16 tensor `out` with NaN when any of the n_channels control blocks (64 words apart) carries a time-out, so that a
+ * result made from a buffer that never arrived cannot be consumed.  The caller guarantees that a receive buffer is not
+ * pushed into again before its owner has consumed it (the step's data dependencies do).
  * --------------------------------------------------------------------------------------------- */
 typedef struct bya_p2p_copy {
     const void* src;
@@ -445,7 +454,23 @@ typedef struct bya_p2p_copy {
 int bya_p2p_push(const bya_p2p_copy* copies_dev, int32_t n_copies, int64_t total_chunks, void* const* peer_ctrl_dev,
                  int32_t world, int32_t rank, void* ctrl, hipStream_t stream);
 int bya_p2p_wait(void* ctrl, int32_t world, hipStream_t stream);
+int bya_p2p_exchange(const bya_p2p_copy* copies_dev, int32_t n_copies, int64_t total_chunks, void* const* peer_ctrl_dev,
+                     int32_t world, int32_t rank, void* ctrl, hipStream_t stream);
+int bya_p2p_set_wait_limit_ms(int64_t ms);
+int bya_p2p_poison(const void* ctrl_base, int32_t n_channels, void* out, int64_t n_elems, hipStream_t stream);
+/* Set-up only (the ONLY entry points of this library that allocate; never called inside a step): device memory a peer may
+ * store into or a running kernel polls, by kind -- 0 coarse-grained (hipMalloc), 1 fine-grained, 2 uncached
+ * (hipExtMallocWithFlags) -- zero-filled, and its hipIpc handle (64 bytes) for the peers.  BYA_ERR_UNSUPPORTED: the
+ * platform refused (the host module then falls back, p2p.py). */
+int bya_p2p_alloc(int64_t bytes, int32_t kind, void** out);
+int bya_p2p_free(void* ptr);
+int bya_p2p_ipc_export(void* ptr, void* handle64);
+int bya_p2p_ipc_import(const void* handle64, void** out);
+int bya_p2p_ipc_release(void* ptr);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,11 @@ def _worker(rank, world, port, ret, mode):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from bind_your_avatar_implementation_amd.p2p import P2PGroup
-        g = P2PGroup(dist.group.WORLD, dev)
+        g = P2PGroup(dist.group.WORLD, dev, mem="fine" if mode == "fine" else "coarse")
+        if mode == "fine":
+            assert g.ctrl_kind == "fine"                 # this platform hands out fine-grained memory: the flags live in it
+            g.self_test(rounds=8, elems=64 * 1024)
+            mode = "plain"
         # an uneven all-to-all with TWO pieces per destination (like q|k|v blocks): rank r sends to rank j
         #   piece A: (r + 1) * 1000 + 8 * j elements, piece B: 4096 elements, values encode (iteration, r, j, piece)
         nA = lambda r, j: ((r + 1) * 1000 + 8 * j) // 8 * 8
@@ -92,7 +96,7 @@ def _worker(rank, world, port, ret, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "plain"), (4, "side"), (8, "plain"), (2, "graph"), (4, "graph_side")])
+@pytest.mark.parametrize("world,mode", [(2, "plain"), (4, "side"), (8, "plain"), (2, "graph"), (4, "graph_side"), (4, "fine")])
 def test_p2p_exchange_between_processes_on_one_gpu(dev, world, mode):
     import torch.multiprocessing as mp
     ret = mp.Manager().dict()
@@ -103,19 +107,73 @@ def test_p2p_exchange_between_processes_on_one_gpu(dev, world, mode):
         assert ok and timeouts == 0 and pushes > 0, (r, ret[r])
 
 
+def _timeout_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["BYA_P2P_TIMEOUT"] = "0.3"                # seconds
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bind_your_avatar_implementation_amd import _hip, ops
+        from bind_your_avatar_implementation_amd.p2p import P2PGroup
+        g = P2PGroup(dist.group.WORLD, dev)
+        n = 4096
+        recv = g.symmetric("r", (world, n), torch.bfloat16, zero=True)
+        send = torch.full((world, n), float(rank + 1), dtype=torch.bfloat16, device=dev)
+        ch = g.channel("x", [(send[j], j, "r", rank * n) for j in range(world)])
+        ch.exchange()                                     # a healthy exchange first
+        out = torch.ones(1000, dtype=torch.bfloat16, device=dev)
+        g.poison(out)
+        torch.cuda.synchronize()
+        healthy = (g.timeouts() == 0, bool((out == 1).all()))
+        dist.barrier()
+        # rank 1 "falls behind": it never pushes its second exchange; rank 0's wait gives up after the limit
+        if rank == 0:
+            ch.exchange()
+            g.poison(out)
+            torch.cuda.synchronize()
+            raised = False
+            try:
+                ops.check_gemm_workspace()
+            except _hip.ByaError:
+                raised = True
+            ret[rank] = (healthy, g.timeouts(), bool(torch.isnan(out.float()).all()), raised)
+        else:
+            ret[rank] = (healthy, 0, True, True)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_p2p_wait_that_gives_up_is_loud(dev):
+    """A wait whose peer never pushes gives up after BYA_P2P_TIMEOUT seconds (wall clock) instead of hanging the GPU, and
+    that is not silent: the channel's time-out word is sticky, ``bya_p2p_poison`` turns the step's output into NaN, and
+    ``ops.check_gemm_workspace`` (pipeline end, bench end) raises."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_timeout_worker, args=(2, 32700 + os.getpid() % 200, ret), nprocs=2, join=True)
+    print(dict(ret))
+    for r in (0, 1):
+        assert ret[r][0] == (True, True), ret[r]          # healthy run: no time-out, output untouched
+    assert ret[0][1] > 0 and ret[0][2] and ret[0][3], ret[0]
+
+
 @pytest.mark.gpu
-def test_bench_two_ranks_checks_the_exchange_before_timing(tmp_path):
-    """bench.py with N > 1 compares a checksum of the output across the ranks before anything is timed (every rank returns
-    the same full tensor) and, if the P2P engine fails that check or a bounded wait timed out, moves ALL ranks to the
-    torch.distributed transport and says so in the line.  Exercised here with both ranks on the one GPU
-    (BYA_BENCH_SHARE_GPU=1: gloo process group), once as it is and once with the mismatch faked."""
+def test_bench_two_ranks_validates_against_the_unsharded_step_and_walks_the_ladder(tmp_path):
+    """bench.py with N > 1: every rank runs the UNSHARDED step on its own GPU first; the sharded step must reproduce it bit
+    for bit (strict summation order, after enough steps that every receive buffer has been re-used) before anything is
+    timed, else ALL ranks move one rung down the transport ladder p2p -> p2p-fine -> torch.distributed and the line says so.
+    Exercised with both ranks on the one GPU (BYA_BENCH_SHARE_GPU=1: gloo process group): once as it is, once with the
+    first rung failing, once with both P2P rungs failing (BYA_BENCH_FAKE_MISMATCH)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "1", "--warmup", "1",
             "--no-cpu-baseline", "--no-fp8-variant", "--no-kernel-timers"]
-    for fake in ("0", "1"):
+    for fake, want in (("", "p2p"), ("p2p", "p2p-fine"), ("1", "torch")):
         env = dict(os.environ, BYA_BENCH_SHARE_GPU="1", BYA_BENCH_FAKE_MISMATCH=fake, HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
         r = subprocess.run(base, env=env, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=900)
@@ -123,7 +181,14 @@ def test_bench_two_ranks_checks_the_exchange_before_timing(tmp_path):
         assert r.returncode == 0 and len(lines) == 1, (r.stdout[-800:], r.stderr[-1500:])
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["value"] > 0
-        if fake == "0":
-            assert "P2P push kernels" in d["config"]["parallelism"] and "transport_note" not in d["config"]
+        cfg = d["config"]
+        assert cfg["transport"] == want, cfg
+        val = cfg["validated_against_unsharded_step"]
+        assert [t["transport"] for t in val["rungs"]][-1] == want and val["rungs"][-1]["bit_identical_to_unsharded_step"]
+        assert val["default_mode_rel_fro_vs_reference"] <= val["default_mode_bound"]
+        if want == "p2p":
+            assert "P2P push kernels" in cfg["parallelism"] and "transport_note" not in cfg and len(val["rungs"]) == 1
+        elif want == "p2p-fine":
+            assert "fine-grained receive buffers" in cfg["parallelism"] and "p2p failed" in cfg["transport_note"]
         else:
-            assert "torch.distributed collectives" in d["config"]["parallelism"] and "P2P exchange failed" in d["config"]["transport_note"]
+            assert "torch.distributed collectives" in cfg["parallelism"] and "p2p, p2p-fine failed" in cfg["transport_note"]

@@ -137,7 +137,7 @@ def test_callback_on_step_end_receives_and_replaces_tensors():
     out = pipe(height=32, width=48, num_frames=9, num_inference_steps=2, guidance_scale=1.0, latents=lat,
                prompt_embeds=torch.ones(1, 4, 8), image_latents=torch.zeros(1, 3, 16, 4, 6),
                image_bg_latents=torch.zeros(1, 3, 16, 4, 6),
-               callback_on_step_end=cb, callback_on_step_end_tensor_inputs=["latents", "prompt_embeds"]).frames
+               callback_on_step_end=cb, callback_on_step_end_tensor_inputs=["latents", "prompt_embeds"], output_type="latent").frames
     assert [c[0] for c in calls] == [0, 1] and [c[1] for c in calls] == [1, 0]
     assert torch.allclose(calls[0][2], torch.full_like(lat, -0.5))             # latents AFTER the scheduler step
     assert torch.allclose(calls[1][2], torch.full_like(lat, 9.0))              # the callback's replacement was used
@@ -235,7 +235,8 @@ def test_call_follows_the_reference_channel_rule_and_rejects_what_it_does_not_do
     pipe = BindyouravatarPipeline(Tr(), scheduler=Sch(), vae=StubVAE(DiagonalGaussian))
     g = torch.Generator().manual_seed(3)
     image, kps, bg = (torch.rand(1, 3, 32, 48, generator=g) * 2 - 1 for _ in range(3))
-    kw = dict(height=32, width=48, num_frames=9, num_inference_steps=1, guidance_scale=1.0, prompt_embeds=torch.ones(1, 4, 8))
+    kw = dict(height=32, width=48, num_frames=9, num_inference_steps=1, guidance_scale=1.0, prompt_embeds=torch.ones(1, 4, 8),
+              output_type="latent")
     out = pipe(image=image, image_bg=bg, kps_cond=kps, use_inpaint=True, generator=torch.Generator().manual_seed(5), **kw).frames
     x = seen[-1]
     assert out.shape == (1, 3, 16, 4, 6) and x.shape == (1, 3, 48, 4, 6)
@@ -251,3 +252,25 @@ def test_call_follows_the_reference_channel_rule_and_rejects_what_it_does_not_do
         pipe(image=image, image_bg=bg, eta=0.5, **kw)
     with pytest.raises(NotImplementedError, match="key-point IMAGE"):
         pipe(image=image, image_bg=bg, kps_cond=[[1.0, 2.0]] * 5, **kw)
+
+
+def test_output_type_defaults_to_the_references_pil_and_postprocesses_like_diffusers():
+    """reference models/pipeline_bindyouravatar.py:645 (``output_type: str = "pil"``) and :967-971: anything but "latent" is
+    decoded and passed through diffusers' ``VideoProcessor.postprocess_video``: x / 2 + 0.5 clamped to [0, 1]; "pt" ->
+    [B, F, 3, H, W], "np" -> float32 [B, F, H, W, 3], "pil" -> per sample a list of F uint8 RGB images."""
+    import inspect
+    import numpy as np
+    from bind_your_avatar_implementation_amd.pipeline import BindyouravatarPipeline
+    assert inspect.signature(BindyouravatarPipeline.__call__).parameters["output_type"].default == "pil"
+    g = torch.Generator().manual_seed(0)
+    video = torch.rand(2, 3, 5, 8, 12, generator=g) * 3 - 1.5                  # values outside [-1, 1] get clamped
+    pt = BindyouravatarPipeline.postprocess_video(video, "pt")
+    want = (video / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)
+    assert pt.shape == (2, 5, 3, 8, 12) and torch.equal(pt, want)
+    arr = BindyouravatarPipeline.postprocess_video(video, "np")
+    assert arr.shape == (2, 5, 8, 12, 3) and arr.dtype == np.float32 and np.array_equal(arr, want.permute(0, 1, 3, 4, 2).numpy())
+    pil = BindyouravatarPipeline.postprocess_video(video, "pil")
+    assert len(pil) == 2 and len(pil[0]) == 5 and pil[0][0].size == (12, 8) and pil[0][0].mode == "RGB"
+    assert np.array_equal(np.asarray(pil[1][4]), (arr[1, 4] * 255).round().astype("uint8"))
+    with pytest.raises(ValueError, match="does not exist"):
+        BindyouravatarPipeline.postprocess_video(video, "mp4")
