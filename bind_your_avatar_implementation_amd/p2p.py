@@ -93,7 +93,7 @@ class Channel:
     def __init__(self, grp, index):
         self.grp, self.index = grp, index
         self.ctrl_ptr = grp.ctrl[index].data_ptr()
-        self.peer_ctrl = torch.tensor([grp.ctrl_peers[j].data_ptr() + index * CTRL_WORDS * 4 for j in range(grp.world)],
+        self.peer_ctrl = torch.tensor([grp.ctrl_peers[j].data_ptr() + index * CTRL_WORDS * 4 for j in range(grp.kworld)],
                                       dtype=torch.int64, device=grp.dev)
         self.tables = collections.OrderedDict()      # source-pointer signature -> [table, n_copies, total_chunks, sources, pinned]
         self.cur = None
@@ -118,7 +118,7 @@ class Channel:
     def _launch(self, fn, stream):
         g = self.grp
         table, n, total_chunks = self.cur[:3]
-        _hip.check(fn(table.data_ptr(), n, total_chunks, self.peer_ctrl.data_ptr(), g.world, g.rank, self.ctrl_ptr,
+        _hip.check(fn(table.data_ptr(), n, total_chunks, self.peer_ctrl.data_ptr(), g.kworld, g.krank, self.ctrl_ptr,
                       stream.cuda_stream), fn.__name__)
         g.pushes += 1
 
@@ -126,7 +126,7 @@ class Channel:
         g = self.grp
         cur = torch.cuda.current_stream(g.dev)
         stream = cur
-        if side and g.world > 1:
+        if side and (g.world > 1 or g.solo is not None):
             stream = g.side_stream
             ev = torch.cuda.Event()
             ev.record(cur)
@@ -144,7 +144,7 @@ class Channel:
         if self._join is not None:
             cur.wait_event(self._join)              # (also rejoins the side stream into a graph capture)
             self._join = None
-        _hip.check(_hip.load().bya_p2p_wait(self.ctrl_ptr, g.world, cur.cuda_stream), "bya_p2p_wait")
+        _hip.check(_hip.load().bya_p2p_wait(self.ctrl_ptr, g.kworld, cur.cuda_stream), "bya_p2p_wait")
         return self
 
     def exchange(self):
@@ -158,14 +158,25 @@ class Channel:
 class P2PGroup:
     MERGED = True
 
-    def __init__(self, group=None, device=None, mem="coarse"):
-        self.group = group if group is not None else dist.group.WORLD
-        self.world, self.rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+    def __init__(self, group=None, device=None, mem="coarse", solo=None):
+        """``solo=(rank, world)``: PROBE MODE (tools/solo_rank_step.py) -- this one process plays rank ``rank`` of a
+        ``world``-rank group whose other ranks do not exist: every "peer" buffer is a second local allocation, pushes store
+        into those, and a wait only expects this rank's own flag.  The received data is therefore wrong (the peers' parts
+        never arrive) but every kernel and every exchange launch of ONE rank's step runs with its real shapes: what one GPU
+        can measure of an N-GPU step.  Never used by the product path."""
+        self.solo = solo
+        if solo is not None:
+            self.group, (self.rank, self.world) = None, solo
+        else:
+            self.group = group if group is not None else dist.group.WORLD
+            self.world, self.rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         if self.world > 32:
             raise ValueError("P2P exchange engine: at most 32 ranks (one node)")
         if mem not in KINDS:
             raise ValueError(f"P2P memory kind {mem!r}: expected one of {sorted(KINDS)}")
         self.mem = mem
+        # what the kernels are told: the group's size and this rank -- in solo mode a 1-rank group whose only flag is word 0
+        self.kworld, self.krank = (1, 0) if solo is not None else (self.world, self.rank)
         self.dev = torch.device(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
         self._named = {}
         self._keep = []
@@ -184,6 +195,8 @@ class P2PGroup:
         except _FineUnavailable:
             self.ctrl = self.symmetric("__ctrl__", (MAX_CHANNELS, CTRL_WORDS), torch.int32, zero=True, kind="coarse")
             self.ctrl_kind = "coarse"
+        if solo is not None:
+            self.ctrl_kind = "local (solo probe)"
         self.ctrl_peers = self._named["__ctrl__"][1]
         LIVE_GROUPS.add(self)
 
@@ -199,6 +212,16 @@ class P2PGroup:
             return loc
         kind = kind or self.mem
         with torch.cuda.device(self.dev):
+            if self.solo is not None:
+                local = torch.zeros(*shape, dtype=dtype, device=self.dev)
+                if name == "__ctrl__":
+                    peers = [_Peer(local.data_ptr(), shape, dtype, local)] * self.world     # every flag lands in the own block
+                else:
+                    sinks = [torch.zeros(*shape, dtype=dtype, device=self.dev) for _ in range(self.world - 1)]
+                    peers = [_Peer(t.data_ptr(), shape, dtype, t) for t in sinks]
+                    peers.insert(self.rank, _Peer(local.data_ptr(), shape, dtype, local))
+                self._named[name] = (local, peers)
+                return local
             local, peers = (self._symmetric_torch if kind == "coarse" else self._symmetric_ext)(shape, dtype, zero, kind)
             if self.world > 1:
                 dist.barrier(group=self.group)          # nobody pushes before everybody has mapped
@@ -353,7 +376,7 @@ class P2PGroup:
         if self.timeouts() or int(bad.item()):
             raise RuntimeError(f"P2P exchange self-test failed: {int(bad.item())} stale or missing words, "
                                f"{self.timeouts()} timed-out waits ({self.mem} receive buffers, {self.ctrl_kind} flags)")
-        if self.world > 1:
+        if self.world > 1 and self.solo is None:
             dist.barrier(group=self.group)
 
     def timeouts(self):
