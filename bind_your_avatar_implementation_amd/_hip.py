@@ -28,7 +28,8 @@ class AttnDesc(_c.Structure):
                 ("k_s1", _i64), ("k_s2", _i64), ("k_row", _i64),
                 ("v_s1", _i64), ("v_s2", _i64), ("v_row", _i64),
                 ("o_s1", _i64), ("o_s2", _i64), ("o_row", _i64),
-                ("scale", _f32), ("scores_prescaled", _i32), ("score_bound", _f32)]
+                ("scale", _f32), ("scores_prescaled", _i32), ("score_bound", _f32),
+                ("bound_dev", _vp), ("bound_slots", _i32), ("bound_heads", _i32), ("bound_bh0", _i32), ("fallback_flags", _vp)]
 
 
 class AttnMixDesc(_c.Structure):
@@ -58,7 +59,7 @@ SIGNATURES = {
     "bya_timestep_features": [_vp, _vp, _i32, _i32, _i32, _f32, _vp],
     "bya_layernorm": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64,
                       _f32, _vp],
-    "bya_qknorm_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _f32, _vp],
+    "bya_qknorm_rope": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _f32, _f32, _vp, _i32, _vp],
     "bya_attn_fwd": [_vp, _vp, _vp, _vp, _c.POINTER(AttnDesc), _vp],
     "bya_attn_variant": [_c.POINTER(AttnDesc)],
     "bya_set_attn_workspace": [_vp, _i64],

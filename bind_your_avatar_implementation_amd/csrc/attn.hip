@@ -307,6 +307,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
         qt = (base + j) % p.nqt;
     }
     if (bh >= nbh) return;
+    if (p.only_flagged && !p.only_flagged[bh]) return;       // second pass of the device-bound form: flagged heads only
     const int head = bh % p.heads;
     const int b12 = bh / p.heads;
     const int b1 = b12 / p.nb2, b2 = b12 % p.nb2;
@@ -1023,12 +1024,23 @@ inline bool use_w4() {
     const char* e = getenv("BYA_ATTN_W4");
     return !(e && e[0] == '0');
 }
+inline float static_bound_limit() { return use_w4() ? BYA_ATTN_BOUND_LIMIT : 48.f; }
 
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     const int nbh = a.nb1 * a.nb2 * a.heads;
     dim3 grid((nbh * a.nqt + 7) / 8 * 8);          // whole groups of 8 (one block per XCD); surplus blocks exit at once
     const size_t lds = (size_t)(D == 64 ? BYA_ATTN_RING : 2) * 2 * KV_TILE * D * 2;
+    if (D == 64 && a.prescaled && a.bound_dev) {
+        // data-dependent bound: the static kernel serves every head whose bound is usable and flags the others, the
+        // running-maximum kernel right behind it serves exactly those (its other workgroups exit at once)
+        const int rc = bya_launch_attn_w4(&a, s);
+        if (rc != BYA_OK) return rc;
+        AttnArgs b = a;
+        b.bound_dev = nullptr; b.score_bound = 0.f; b.only_flagged = a.fallback; b.fallback = nullptr;
+        BYA_LAUNCH(attn_fwd_kernel_d64_prescaled, grid, dim3(256), lds, s, b);
+        return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+    }
     if (D == 64 && a.prescaled && a.score_bound > 0.f && use_w4()) return bya_launch_attn_w4(&a, s);
     if (D == 64 && a.prescaled && a.score_bound > 0.f && BYA_ATTN_QB2) {
         AttnArgs b = a;
@@ -1050,8 +1062,10 @@ extern "C" int bya_attn_variant(const bya_attn_desc* d) {
     if (d->head_dim == 128) return d->scores_prescaled ? BYA_ERR_UNSUPPORTED : BYA_ATTN_D128;
     if (d->head_dim != 64) return BYA_ERR_UNSUPPORTED;
     if (!d->scores_prescaled) return BYA_ATTN_D64_RUNNING_MAX;
-    // a usable static bound keeps every P = exp2(s) within [2^-48, 2^48]; otherwise the running-max kernel runs
-    if (!(d->score_bound > 0.f && d->score_bound <= 48.f)) return BYA_ATTN_D64_PRESCALED;
+    if (d->bound_dev && d->fallback_flags && use_w4()) return BYA_ATTN_D64_DEVICE_BOUND_W4;
+    // a usable static bound keeps every P and every row sum a normal number: |s| <= 90 where P = exp2(s) (the hand-placed
+    // kernel), |s| <= 48 where P = exp2(s - bound) (the two-block kernel); otherwise the running-maximum kernel runs
+    if (!(d->score_bound > 0.f && d->score_bound <= static_bound_limit())) return BYA_ATTN_D64_PRESCALED;
     return use_w4() ? BYA_ATTN_D64_STATIC_BOUND_W4 : BYA_ATTN_D64_STATIC_BOUND;
 }
 
@@ -1077,8 +1091,16 @@ extern "C" int bya_attn_fwd(const void* q, const void* k, const void* v, void* o
     a.scale_log2 = d->scale * 1.4426950408889634f;
     a.prescaled = d->scores_prescaled;
     if (a.prescaled && d->head_dim != 64) return BYA_ERR_UNSUPPORTED;
-    // a usable static bound keeps every P = exp2(s - B) >= 2^-96 (a bf16 normal); otherwise the running-max kernel runs
-    a.score_bound = (a.prescaled && d->score_bound > 0.f && d->score_bound <= 48.f) ? d->score_bound : 0.f;
+    a.score_bound = (a.prescaled && d->score_bound > 0.f && d->score_bound <= static_bound_limit()) ? d->score_bound : 0.f;
+    a.bound_dev = nullptr; a.bound_slots = 0; a.bound_heads = 0; a.bound_bh0 = 0; a.bound_limit = BYA_ATTN_BOUND_LIMIT;
+    a.fallback = nullptr; a.only_flagged = nullptr;
+    if (d->bound_dev && a.prescaled && use_w4()) {
+        if (!d->fallback_flags || d->bound_slots < 1 || d->bound_slots > 64 || d->bound_bh0 < 0 ||
+            d->bound_bh0 + d->nb1 * d->nb2 * d->heads > d->bound_heads) return BYA_ERR_SHAPE;
+        if (((uintptr_t)d->bound_dev | (uintptr_t)d->fallback_flags) & 3) return BYA_ERR_ALIGN;
+        a.bound_dev = d->bound_dev; a.bound_slots = d->bound_slots; a.bound_heads = d->bound_heads; a.bound_bh0 = d->bound_bh0;
+        a.fallback = d->fallback_flags;
+    }
     return d->head_dim == 64 ? launch_attn<64>(a, stream) : launch_attn<128>(a, stream);
 }
 

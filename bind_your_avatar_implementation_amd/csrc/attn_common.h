@@ -16,6 +16,12 @@ struct AttnArgs {
     float* sk_part;    // stream-K exchange slots / flags of the joint-attention kernel (attn_w4.hip; set by its launcher)
     unsigned* sk_flags;
     int o_wide;        // o and its strides are 16-byte aligned: the epilogue stores 16 bytes per lane (store_o_tile)
+    // data-dependent score bound (bya_attn_desc.bound_dev; attn_w4.hip): squared norms [slots][2][bound_heads], this launch's
+    // bh at column bound_bh0 + bh; heads whose bound exceeds bound_limit are left to the running-maximum kernel, which
+    // runs with only_flagged = fallback and skips every other head
+    const float* bound_dev; int bound_slots, bound_heads, bound_bh0; float bound_limit;
+    int* fallback;
+    const int* only_flagged;
 };
 
 constexpr int KV_TILE = 64;

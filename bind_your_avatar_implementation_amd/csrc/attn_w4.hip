@@ -245,6 +245,23 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
             if (!first_item) asm volatile("s_barrier" ::: "memory");
             first_item = false;
         }
+        if (p.bound_dev) {
+            // data-dependent bound of this (batch, head): |q . k| <= max ||q|| max ||k|| (squared norms from bya_qknorm_rope,
+            // one partial table per slot).  Every workgroup of the head takes the same decision and writes the same flag.
+            const float* tq = p.bound_dev + (long long)lane * 2 * p.bound_heads + p.bound_bh0 + it.bh;
+            float q2 = lane < p.bound_slots ? tq[0] : 0.f, k2 = lane < p.bound_slots ? tq[p.bound_heads] : 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                q2 = fmaxf(q2, __shfl_xor(q2, o, 64));
+                k2 = fmaxf(k2, __shfl_xor(k2, o, 64));
+            }
+            const bool skip = !(sqrtf(q2) * sqrtf(k2) <= p.bound_limit);         // (NaN statistics: leave the head to the fallback)
+            if (tid == 0) p.fallback[it.bh] = skip ? 1 : 0;
+            if (skip) {
+                if (SK) continue;
+                return;
+            }
+        }
         const int head = it.bh % p.heads, b12 = it.bh / p.heads;
         const int b1 = b12 / p.nb2, b2 = b12 % p.nb2;
         const bf16_t* Qp = p.q + b1 * p.q_s1 + b2 * p.q_s2 + (long long)head * D;

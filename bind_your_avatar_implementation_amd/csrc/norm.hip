@@ -249,18 +249,22 @@ struct QkArgs {
     long long ld, bs;
     float eps;
     float k_scale;     // multiplies the finished k (fp32, before the single rounding to bf16); 1 = off
-    int table_sc1;     // 1: read cos / sin past the vector L1 (sc1 loads) -- see tools/timeslice/repro.py
     int only;          // 0: q and k; 1: q alone; 2: k alone (the sharded step norms q, starts its exchange, then norms k)
+    float* stats;      // STATS instance: [slots][2][batch * heads] squared norms of the finished rows (include/bya.h)
+    int stats_slots;
 };
 
-// DBG (tools/timeslice/repro.py, experiment builds only; 0 = the product kernel):
-//   1: the cos / sin loads are drained (vmcnt(0)) before any later instruction may touch their address registers
-//   2: 32-bit index arithmetic (no 64-bit division sequences in front of the RoPE branch)
 // (r4, measured and dropped: a row form -- one token row per wave iteration, the four parameter vectors in registers, a row's
 // cos / sin piece loaded once for all heads of q and k -- bit-identical, 86-90 us against 78-86 us for this kernel;
 // writing to a second buffer instead of in place -- 92-104 us against 78-90 us: the in-place stores hit lines the loads
-// just brought into L2.)
-template <int DBG>
+// just brought into L2.  r2-r4 experiment arms of tools/timeslice/repro.py -- drained table loads, 32-bit index arithmetic,
+// sc1 table loads -- closed and removed in round 5: the cause was the packed-fp32 arithmetic, see build.py.)
+// STATS: every 8-lane group also raises its (slot, q | k, batch, head) entry of p.stats to the squared norm of the row it
+// stores, taken from the ROUNDED values (what the attention kernel will read): one no-return atomic maximum per (row, head)
+// on the bit pattern of a non-negative float, spread over `slots` copies of the table (blockIdx % slots) so that a table
+// entry sees 1 / slots of the rows.  Only launched when the caller asks for statistics (engine: the worst-case score bound of
+// a layer is too large): the plain instance is untouched.
+template <bool STATS>
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
     // one 8-lane group per (row, head) pair, pairs enumerated row-major over all batches: any head count works
     const int lane = threadIdx.x & 63;
@@ -269,18 +273,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
     if (pair >= (p.only ? 1 : 2) * pairs_per_tensor) return;
     const int which = p.only ? p.only - 1 : (pair >= pairs_per_tensor);      // 0 = q, 1 = k
     long long rest = p.only ? pair : pair - which * pairs_per_tensor;
-    int head, s, z;
-    if constexpr (DBG == 2) {
-        const unsigned r32 = (unsigned)rest, h32 = (unsigned)p.heads, S32 = (unsigned)p.S;
-        head = (int)(r32 % h32);
-        const unsigned r2 = r32 / h32;
-        s = (int)(r2 % S32);
-        z = (int)(r2 / S32);
-    } else {
-        head = (int)(rest % p.heads); rest /= p.heads;
-        s = (int)(rest % p.S);
-        z = (int)(rest / p.S);
-    }
+    const int head = (int)(rest % p.heads); rest /= p.heads;
+    const int s = (int)(rest % p.S);
+    const int z = (int)(rest / p.S);
     const int d0 = (lane & 7) * 8;
     bf16_t* base = (which ? p.k : p.q) + z * p.bs + (long long)s * p.ld + head * 64 + d0;
     const bf16_t* w = (which ? p.kw : p.qw) + d0;
@@ -306,25 +301,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
     if (s >= p.text_rows) {
         const float* c = p.cos + (long long)(s - p.text_rows) * 64 + d0;
         const float* sn = p.sin + (long long)(s - p.text_rows) * 64 + d0;
-        f32x4 c0, c1, s0, s1;
-        if (p.table_sc1) {
-            // the eight head groups of a wave read the SAME eight 32-byte pieces of a table row; served past the L1
-            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.cos, 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsn = __builtin_amdgcn_make_buffer_rsrc((void*)p.sin, 0, 0x7fffffff, 0x00020000);
-            const uint32_t off = (uint32_t)(((long long)(s - p.text_rows) * 64 + d0) * 4);
-            c0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 16));
-            c1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, off + 16, 0, 16));
-            s0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsn, off, 0, 16));
-            s1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsn, off + 16, 0, 16));
-        } else {
-            c0 = *reinterpret_cast<const f32x4*>(c); c1 = *reinterpret_cast<const f32x4*>(c + 4);
-            s0 = *reinterpret_cast<const f32x4*>(sn); s1 = *reinterpret_cast<const f32x4*>(sn + 4);
-        }
-        if constexpr (DBG == 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(s0), "+v"(s1));
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sn), s1 = *reinterpret_cast<const f32x4*>(sn + 4);
         const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
         const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
         float o[8];
@@ -340,7 +318,22 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= p.k_scale;
     }
-    *reinterpret_cast<u32x4*>(base) = pack8(v);
+    const u32x4 out = pack8(v);
+    *reinterpret_cast<u32x4*>(base) = out;
+    if constexpr (STATS) {
+        float r8[8];
+        unpack8(out, r8);
+        float n2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) n2 += r8[e] * r8[e];
+        n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
+        if ((lane & 7) == 0) {
+            const long long nbh = (long long)p.batch * p.heads;
+            unsigned* dst = reinterpret_cast<unsigned*>(p.stats) + ((long long)(blockIdx.x % (unsigned)p.stats_slots) * 2 + which) * nbh +
+                            (long long)z * p.heads + head;
+            (void)__hip_atomic_fetch_max(dst, __float_as_uint(n2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 }  // namespace
@@ -397,27 +390,22 @@ extern "C" int bya_layernorm_fp8(const void* x, void* q, float* q_scale, const v
 extern "C" int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb, const void* kw, const void* kb,
                                const float* cos, const float* sin, int32_t batch, int32_t S, int32_t heads,
                                int64_t ld, int64_t batch_stride, int32_t text_rows, float eps, float k_scale,
-                               hipStream_t stream) {
+                               float* stats, int32_t stats_slots, hipStream_t stream) {
     if ((!q && !k) || !qw || !qb || !kw || !kb || batch <= 0 || S <= 0 || heads <= 0) return BYA_ERR_SHAPE;
     if (text_rows < S && (!cos || !sin)) return BYA_ERR_SHAPE;
+    if (stats && (stats_slots < 1 || stats_slots > 64)) return BYA_ERR_SHAPE;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos | (uintptr_t)sin | (uintptr_t)qw | (uintptr_t)kw |
          (uintptr_t)qb | (uintptr_t)kb) & 15) return BYA_ERR_ALIGN;
-    if ((ld | batch_stride) % 8) return BYA_ERR_ALIGN;
+    if ((ld | batch_stride) % 8 || ((uintptr_t)stats & 3)) return BYA_ERR_ALIGN;
     QkArgs a;
     a.q = (bf16_t*)q; a.k = (bf16_t*)k; a.qw = (const bf16_t*)qw; a.qb = (const bf16_t*)qb;
     a.kw = (const bf16_t*)kw; a.kb = (const bf16_t*)kb; a.cos = cos; a.sin = sin;
     a.batch = batch; a.S = S; a.heads = heads; a.text_rows = text_rows; a.ld = ld; a.bs = batch_stride; a.eps = eps; a.k_scale = k_scale == 0.0f ? 1.0f : k_scale;
-    {   // experiment switch, read per call (tools/timeslice/repro.py); the product default is decided in DESIGN.md section 5
-        const char* e = getenv("BYA_QKNORM_TABLE_SC1");
-        a.table_sc1 = e ? atoi(e) : 0;
-    }
     a.only = !k ? 1 : !q ? 2 : 0;                                             // one tensor alone (the other pointer is NULL)
+    a.stats = stats; a.stats_slots = stats_slots;
     const long long total = ((long long)batch * S * heads * (a.only ? 1 : 2) + 7) / 8;      // waves: 8 (row, head) pairs each
     dim3 grid((unsigned)((total + 3) / 4));
-    const char* dbg = getenv("BYA_QKNORM_DBG");
-    const int d = dbg ? atoi(dbg) : 0;
-    if (d == 1) BYA_LAUNCH(qknorm_rope_kernel<1>, grid, dim3(256), 0, stream, a);
-    else if (d == 2) BYA_LAUNCH(qknorm_rope_kernel<2>, grid, dim3(256), 0, stream, a);
-    else BYA_LAUNCH(qknorm_rope_kernel<0>, grid, dim3(256), 0, stream, a);
+    if (stats) BYA_LAUNCH(qknorm_rope_kernel<true>, grid, dim3(256), 0, stream, a);
+    else BYA_LAUNCH(qknorm_rope_kernel<false>, grid, dim3(256), 0, stream, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }

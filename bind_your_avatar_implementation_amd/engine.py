@@ -131,13 +131,17 @@ class DenoiseEngine:
         self._fp = self._fingerprint()
         # |q.k| * k_scale <= (8 max|gamma_q| + ||beta_q||)(8 max|gamma_k| + ||beta_k||) * k_scale for q, k out of
         # LayerNorm(64) (||x_hat|| <= 8) followed by RoPE (a rotation); 2 % slack for the bf16 roundings of q and k.
-        # bya_attn_fwd uses the bound as a static softmax offset when it is small enough (include/bya.h).
+        # bya_attn_fwd runs its softmax without a running maximum when that is <= ops.ATTN_BOUND_LIMIT (include/bya.h).  A
+        # layer whose WORST CASE is larger (learned gains: a few large elements of gamma are enough) does not lose the fast
+        # kernel: its q/k-norm launch then records the norms the rows actually have, and the attention takes
+        # max||q|| max||k|| per (batch, head) from device memory (``_attn_bound``), heads above the limit alone fall back.
         self.score_bound = []
         for blk in m.transformer_blocks:
             nq, nk = blk.attn1.norm_q, blk.attn1.norm_k
             bq = 8.0 * nq.weight.float().abs().max().item() + nq.bias.float().norm().item()
             bk = 8.0 * nk.weight.float().abs().max().item() + nk.bias.float().norm().item()
             self.score_bound.append(1.02 * bq * bk * self.k_scale if os.environ.get("BYA_ATTN_BOUNDED", "1") != "0" else 0.0)
+        self.device_bound = os.environ.get("BYA_ATTN_DEVICE_BOUND", "1") != "0"
         mods_w, mods_b = [], []
         for blk in m.transformer_blocks:
             for nz in (blk.norm1, blk.norm2):
@@ -248,6 +252,21 @@ class DenoiseEngine:
             t = torch.empty(*shape, dtype=torch.bfloat16, device=self.dev)
             self._ws[name] = t
         return t
+
+    def _attn_bound(self, i, n_bh, slots=64):
+        """How the joint attention of layer ``i`` bounds its scores: ``(static bound, None)`` when the worst case over the
+        layer's q/k-LayerNorm parameters is usable (or nothing is: 0 -> running maximum), else ``(0, stats)`` with a zeroed fp32
+        table [slots, 2, n_bh] for this layer's q/k-norm launch to fill (``ops.qknorm_rope(stats=...)``)."""
+        wc = self.score_bound[i]
+        if wc <= ops.ATTN_BOUND_LIMIT or not self.device_bound or wc == 0.0:
+            return wc, None
+        key = ("qk_stats", slots, n_bh)
+        st = self._ws.get(key)
+        if st is None:
+            st = self._ws[key] = torch.empty(slots, 2, n_bh, dtype=torch.float32, device=self.dev)
+            self._ws["qk_flags"] = torch.zeros(max(n_bh, 64), dtype=torch.int32, device=self.dev)
+        st.zero_()
+        return 0.0, st
 
     def _dit_linear(self, which, i, a, w, out, quantised=None, **kw):
         """One of the four big Linears of DiT block ``i`` (models/transformer.py:241-260): the bf16 GEMM, or -- when the
@@ -603,11 +622,14 @@ class DenoiseEngine:
                         if sh.p2p is not None:
                             # P2P transport: q/k-norm + RoPE on the local rows of both, then ONE push kernel carries all
                             # 3 x W column blocks to their places in the peers' q / k / v buffers
+                            # (device bound: this rank's rows give its partial maxima for ALL heads; the tables travel with
+                            # the q|k|v exchange and the attention takes the maximum over the ranks' tables for its heads)
+                            sb, st = self._attn_bound(i, H, slots=max(1, 64 // W))
                             ops.qknorm_rope(qkvb[:W], qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
-                                            at.norm_k.bias, cos, sin, **qk_kw)
-                            qh_, kh_, vh_ = sh.rows_to_heads_qkv(qkvb)
+                                            at.norm_k.bias, cos, sin, stats=st, **qk_kw)
+                            qh_, kh_, vh_, st_all = sh.rows_to_heads_qkv(qkvb, st)
                             ops.self_attention(qh_[None], kh_[None], vh_[None], oh[None], heads=H // W, tag="joint", prescaled=True,
-                                               score_bound=self.score_bound[i])
+                                               score_bound=sb, bound=None if st is None else (st_all, sh.rank * (H // W), self._ws["qk_flags"]))
                             sh.heads_to_rows(oh, xn[0])
                             self._dit_linear("out", i, xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x,
                                              gate0=mo[:, 5 * D:], gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
@@ -629,9 +651,11 @@ class DenoiseEngine:
                                  gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                         continue
                     self._dit_linear("qkv", i, xn, self.qkv_w[i], q, bias=self.qkv_b[i], split=(D, B * S_loc * D), quantised=xq)
+                    # (rows of K from other ranks are not in this rank's statistics: the all-gather form keeps the worst case)
+                    sb, st = self._attn_bound(i, B * H) if not sh.active else (self.score_bound[i], None)
                     ops.qknorm_rope(q, k, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
                                     heads=H, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
-                                        k_scale=self.k_scale)
+                                        k_scale=self.k_scale, stats=st)
                     if sh.active:      # exchange A (fallback when heads % world != 0): all-gather K and V
                         if sh.p2p is not None:
                             sh.gather_rows_many([k[0], v[0]], [k_full[0], v_full[0]])       # one exchange, double-buffered
@@ -641,8 +665,8 @@ class DenoiseEngine:
                         ops.self_attention(q, k_full, v_full, xn, heads=H, tag="joint", prescaled=True,
                                            score_bound=self.score_bound[i])
                     else:
-                        ops.self_attention(q, k, v, xn, heads=H, tag="joint", prescaled=True,
-                                           score_bound=self.score_bound[i])
+                        ops.self_attention(q, k, v, xn, heads=H, tag="joint", prescaled=True, score_bound=sb,
+                                           bound=None if st is None else (st, 0, self._ws["qk_flags"]))
                     self._dit_linear("out", i, xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
                              gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                 else:

@@ -409,30 +409,38 @@ def layernorm_fp8(x, q, q_scale, weight=None, bias=None, eps=1e-5, shift0=None, 
     return q, q_scale
 
 
-def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6, k_scale=1.0):
-    """In place on q, k [B, S, heads*64]; q or k may be None (only the other one is processed)."""
+def qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads, text_rows, eps=1e-6, k_scale=1.0, stats=None):
+    """In place on q, k [B, S, heads*64]; q or k may be None (only the other one is processed).  ``stats``: fp32
+    [slots, 2, B * heads], ZEROED by the caller: the kernel raises its entries to the squared norms of the rows it writes
+    (max over the slots = max ||q||^2, max ||k||^2 per (batch, head): the data-dependent score bound of ``attention``)."""
     lib = _hip.load()
     b, S, _, bs, ld = _mat(q if q is not None else k, "q")
     assert q is None or k is None or _mat(k, "k") == _mat(q, "q")
+    if stats is not None:
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 3 and stats.shape[1:] == (2, b * heads)
     if cos is not None:
         assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
         assert cos.shape == (S - text_rows, 64)
     tok = _begin("bya_qknorm_rope")
     check(lib.bya_qknorm_rope(_p(q), _p(k), _p(qw), _p(qb), _p(kw), _p(kb), _p(cos), _p(sin), b, S, heads, ld,
-                              bs if b > 1 else 0, text_rows, float(eps), float(k_scale), _stream()),
-          "bya_qknorm_rope")
+                              bs if b > 1 else 0, text_rows, float(eps), float(k_scale), _p(stats),
+                              0 if stats is None else stats.shape[0], _stream()), "bya_qknorm_rope")
     _end(tok)
 
 
 # (call tag, softmax variant) -> launches since the last reset; the variant is reported by the library itself
 ATTN_VARIANT_NAMES = {0: "d64_running_max", 1: "d64_prescaled_running_max", 2: "d64_static_bound", 3: "d128_running_max",
-                      4: "d64_static_bound_w4"}
+                      4: "d64_static_bound_w4", 5: "d64_device_bound_w4"}
+ATTN_BOUND_LIMIT = 90.0          # BYA_ATTN_BOUND_LIMIT (include/bya.h): |score| <= 90 keeps P = exp2(s) and its row sums normal
 ATTN_VARIANTS = {}
 
 
 def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_strides, v_strides, o_strides,
-              scale, tag="other", prescaled=False, score_bound=0.0):
-    """Flash attention with explicit (level-1, level-2, row) element strides for q, k, v, out."""
+              scale, tag="other", prescaled=False, score_bound=0.0, bound=None):
+    """Flash attention with explicit (level-1, level-2, row) element strides for q, k, v, out.
+    ``bound`` = (stats, bh0, flags): the data-dependent score bound -- ``stats`` fp32 [slots, 2, n] as written by
+    ``qknorm_rope(stats=...)``, this launch's (batch, head) index bh at column bh0 + bh, ``flags`` int32 [nb1 * nb2 * heads]
+    (scratch: which heads went to the running-maximum kernel)."""
     lib = _hip.load()
     d = AttnDesc()
     d.head_dim, d.heads, d.nb1, d.nb2, d.Sq, d.Skv = head_dim, heads, nb1, nb2, Sq, Skv
@@ -445,7 +453,13 @@ def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_
     d.score_bound = float(score_bound)
     for t in (q, k, v, out):
         assert t.dtype == torch.bfloat16 and t.is_cuda
-    if prescaled and score_bound > 0 and q.device.index not in _ATTN_WS:
+    if bound is not None:
+        stats, bh0, flags = bound
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 3 and stats.shape[1] == 2
+        assert flags.dtype == torch.int32 and flags.is_contiguous() and flags.numel() >= nb1 * nb2 * heads
+        d.bound_dev, d.bound_slots, d.bound_heads, d.bound_bh0 = stats.data_ptr(), stats.shape[0], stats.shape[2], int(bh0)
+        d.fallback_flags = flags.data_ptr()
+    if prescaled and (score_bound > 0 or bound is not None) and q.device.index not in _ATTN_WS:
         ensure_attn_workspace(q.device)
     var = ATTN_VARIANT_NAMES.get(lib.bya_attn_variant(ctypes.byref(d)), "rejected")
     ATTN_VARIANTS[tag, var] = ATTN_VARIANTS.get((tag, var), 0) + 1
@@ -458,7 +472,7 @@ def attention(q, k, v, out, *, head_dim, heads, nb1, nb2, Sq, Skv, q_strides, k_
     return out
 
 
-def self_attention(q, k, v, out, heads, head_dim=64, scale=None, tag="other", prescaled=False, score_bound=0.0):
+def self_attention(q, k, v, out, heads, head_dim=64, scale=None, tag="other", prescaled=False, score_bound=0.0, bound=None):
     """q,k,v,out: [B, S, heads*head_dim] views (row-strided ok)."""
     b, S, _, q_bs, q_ld = _mat(q, "q")
     _, Skv, _, k_bs, k_ld = _mat(k, "k")
@@ -467,7 +481,7 @@ def self_attention(q, k, v, out, heads, head_dim=64, scale=None, tag="other", pr
     scale = head_dim ** -0.5 if scale is None else scale
     return attention(q, k, v, out, head_dim=head_dim, heads=heads, nb1=b, nb2=1, Sq=S, Skv=Skv,
                      q_strides=(q_bs, 0, q_ld), k_strides=(k_bs, 0, k_ld), v_strides=(v_bs, 0, v_ld),
-                     o_strides=(o_bs, 0, o_ld), scale=scale, tag=tag, prescaled=prescaled, score_bound=score_bound)
+                     o_strides=(o_bs, 0, o_ld), scale=scale, tag=tag, prescaled=prescaled, score_bound=score_bound, bound=bound)
 
 
 def attn_kv_mix(q, k, v, r, af, z, wsum=None, *, head_dim, heads, n_id, n_grp, Sq, Skv, q_strides, k_strides, v_strides,

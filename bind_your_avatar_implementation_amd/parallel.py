@@ -246,17 +246,25 @@ class SeqShard:
             h = self._a2a(out.view(-1), blocks.reshape(-1), [n * Dl for n in self.sizes], [S_loc * Dl] * W, async_op=async_op)
         return h if async_op else out
 
-    def rows_to_heads_qkv(self, blocks):
+    def rows_to_heads_qkv(self, blocks, stats=None):
         """P2P transport: the packed projection's column blocks [3 * world, S_loc, Dl] (block t * world + j = tensor t of
         q | k | v, heads of rank j) -> ONE exchange (one launch) into the symmetric [3, S, Dl] buffer of every destination.
-        Returns (q_heads, k_heads, v_heads), complete for every kernel enqueued behind the call."""
+        ``stats`` (fp32 [slots, 2, heads], this rank's partial q/k squared-norm maxima): travels in the same exchange, into
+        row block ``rank`` of every peer's [world * slots, 2, heads] table.
+        Returns (q_heads, k_heads, v_heads, stats of all ranks or None), complete for every kernel enqueued behind the call."""
         W3, S_loc, Dl = blocks.shape
         W = self.world
         name = f"qkvh:{(3, self.S, Dl)}"
         full = self.p2p.symmetric(name, (3, self.S, Dl), blocks.dtype)
         pieces = [(blocks[t * W + j], j, name, (t * self.S + self.r0) * Dl) for j in range(W) for t in range(3)]
-        self._exchange("qkvh", pieces)
-        return full[0], full[1], full[2]
+        st_all = None
+        if stats is not None:
+            slots, _, nh = stats.shape
+            sname = f"qkstats:{(W * slots, 2, nh)}"
+            st_all = self.p2p.symmetric(sname, (W * slots, 2, nh), stats.dtype)
+            pieces += [(stats, j, sname, self.rank * stats.numel()) for j in range(W)]
+        self._exchange(("qkvh", stats is not None), pieces)
+        return full[0], full[1], full[2], st_all
 
     def heads_to_rows(self, o_heads, out=None):
         """o_heads [S, Dl] (all rows, this rank's heads) -> [S_loc, world*Dl] (this rank's rows, all heads).  The

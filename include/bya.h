@@ -157,10 +157,16 @@ int bya_layernorm(const void* x, void* y, const void* w, const void* b, const vo
  * k_scale (0 or 1 = off): the finished k is multiplied by it in fp32 before its single rounding to bf16 -- the engine
  * folds softmax_scale*log2(e) into k here so that bya_attn_fwd can run with scores_prescaled = 1.
  * q or k (not both) may be NULL: only the other tensor is processed (the sharded step norms q, starts q's exchange on
- * the RCCL stream and norms k underneath it). */
+ * the RCCL stream and norms k underneath it).
+ * stats (may be NULL): fp32 [stats_slots][2][batch * heads], zero-filled by the caller before the launch.  The kernel
+ * raises (atomic maximum on the bit pattern) entry [blockIdx % stats_slots][0 = q, 1 = k][z * heads + head] to the squared
+ * Euclidean norm of every finished, bf16-rounded head row it writes: max over the slots = max ||q||^2 / max ||k||^2 per
+ * (batch, head) -- the data-dependent score bound  |q . k| <= max||q|| max||k||  that bya_attn_fwd reads from device
+ * memory (bya_attn_desc.bound_dev) when the worst case over the LayerNorm's parameters is too large to be useful. */
 int bya_qknorm_rope(void* q, void* k, const void* qw, const void* qb, const void* kw, const void* kb,
                     const float* cos, const float* sin, int32_t batch, int32_t S, int32_t heads, int64_t ld,
-                    int64_t batch_stride, int32_t text_rows, float eps, float k_scale, hipStream_t stream);
+                    int64_t batch_stride, int32_t text_rows, float eps, float k_scale, float* stats, int32_t stats_slots,
+                    hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Flash attention forward, head_dim 64 or 128, no mask, fp32 online softmax, bf16 P.V on MFMA.
@@ -186,21 +192,32 @@ typedef struct bya_attn_desc {
     float score_bound;          /* > 0 (with scores_prescaled): the caller GUARANTEES |score| <= score_bound in exp2
                                    units for every (q, k) pair, e.g. because q and k come out of a LayerNorm with known
                                    weights (||q|| <= 8 max|gamma| + ||beta|| at head_dim 64; RoPE is a rotation).  The
-                                   softmax then uses the constant bound instead of a running maximum (mathematically
-                                   identical, shift invariance) -- bounds above 48 are ignored.  0 = unknown. */
+                                   softmax then uses no running maximum at all (P = exp2(s): mathematically identical,
+                                   shift invariance; every P and every row sum stays a normal fp32 / bf16 number while
+                                   |s| <= 90) -- bounds above BYA_ATTN_BOUND_LIMIT are ignored.  0 = unknown. */
+    /* Data-dependent bound (head_dim 64, scores_prescaled; NULL = off): squared norms written by bya_qknorm_rope's `stats`,
+       fp32 [bound_slots][2][bound_heads]; this launch's (batch, head) index bh reads column bound_bh0 + bh.  Per (batch,
+       head) the kernel takes B = sqrt(max_slots q2 * max_slots k2); where B <= BYA_ATTN_BOUND_LIMIT the static kernel runs,
+       elsewhere it leaves the head alone, sets fallback_flags[bh] (int32 [nb1 * nb2 * heads], written for EVERY bh, no reset
+       needed) and the running-maximum kernel, launched right behind it, computes exactly the flagged heads. */
+    const float* bound_dev;
+    int32_t bound_slots, bound_heads, bound_bh0;
+    int32_t* fallback_flags;
 } bya_attn_desc;
+#define BYA_ATTN_BOUND_LIMIT 90.0f
 
 int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya_attn_desc* desc,
                  hipStream_t stream);
 
 /* Which softmax variant bya_attn_fwd runs for a descriptor (host-side query, launches nothing): the joint attention
- * silently falls back from the static-bound kernel to the running-maximum kernel when score_bound > 48, and callers
+ * silently falls back from the static-bound kernel to the running-maximum kernel when score_bound is above the limit, and callers
  * (tests, bench.py) need to say which one they measured.  Negative = the descriptor is rejected. */
 #define BYA_ATTN_D64_RUNNING_MAX 0   /* online softmax, scores scaled in the kernel */
 #define BYA_ATTN_D64_PRESCALED 1     /* online softmax, scores already in exp2 units */
-#define BYA_ATTN_D64_STATIC_BOUND 2  /* no running maximum: P = exp2(s), |s| <= score_bound <= 48 */
+#define BYA_ATTN_D64_STATIC_BOUND 2  /* no running maximum: P = exp2(s - bound), |s| <= score_bound <= 48 (two-block kernel) */
 #define BYA_ATTN_D128 3
-#define BYA_ATTN_D64_STATIC_BOUND_W4 4  /* the same arithmetic on the one-wave-per-SIMD hand-placed kernel (csrc/attn_w4.hip) */
+#define BYA_ATTN_D64_STATIC_BOUND_W4 4  /* P = exp2(s), |s| <= score_bound <= 90, on the one-wave-per-SIMD hand-placed kernel (csrc/attn_w4.hip) */
+#define BYA_ATTN_D64_DEVICE_BOUND_W4 5  /* the same kernel under the data-dependent bound (bound_dev), per-head running-maximum fallback */
 int bya_attn_variant(const bya_attn_desc* desc);
 
 /* Optional stream-K workspace of the static-bound joint-attention kernel (BYA_ATTN_D64_STATIC_BOUND_W4): device memory

@@ -54,8 +54,19 @@ def test_python_binding_table_matches_header(lib_path):
         assert lib.bya_attn_variant(ctypes.byref(a)) == 2      # ... on the two-block kernel
     finally:
         del os.environ["BYA_ATTN_W4"]
-    a.score_bound = 60.0
+    a.score_bound = 60.0                                        # P = exp2(s) without an offset: usable up to 90 on that kernel,
+    assert lib.bya_attn_variant(ctypes.byref(a)) == 4          # up to 48 on the two-block kernel (P = exp2(s - bound))
+    os.environ["BYA_ATTN_W4"] = "0"
+    try:
+        assert lib.bya_attn_variant(ctypes.byref(a)) == 1
+    finally:
+        del os.environ["BYA_ATTN_W4"]
+    a.score_bound = 100.0
     assert lib.bya_attn_variant(ctypes.byref(a)) == 1
+    dummy = (ctypes.c_float * 4)()
+    a.bound_dev, a.fallback_flags = ctypes.addressof(dummy), ctypes.addressof(dummy)      # data-dependent bound: static kernel +
+    assert lib.bya_attn_variant(ctypes.byref(a)) == 5                                      # per-head running-maximum fallback
+    a.bound_dev, a.fallback_flags = None, None
     a.scores_prescaled = 0
     assert lib.bya_attn_variant(ctypes.byref(a)) == 0
     a.head_dim = 128
@@ -82,7 +93,7 @@ def test_struct_layout_matches_header():
             typ, name = re.match(r"(.*?)(\w+)$", first.strip(), flags=re.S).groups()
             fields += [(name, typ.strip())] + [(n.strip(), typ.strip()) for n in more]
         assert [f[0] for f in fields] == [f[0] for f in cls._fields_], cname
-        size = {"int32_t": 4, "int64_t": 8, "float": 4, "const float*": 8}
+        size = {"int32_t": 4, "int64_t": 8, "float": 4, "const float*": 8, "int32_t*": 8}
         for (n, typ), (_, ct) in zip(fields, cls._fields_):
             assert ctypes.sizeof(ct) == size[typ], (cname, n)
 

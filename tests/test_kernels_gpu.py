@@ -797,27 +797,76 @@ def test_qknorm_rope(ops, dev):
     check(k, 0.18 * ref(k0, kw, kb), what="qknorm_rope k * k_scale (single rounding)")
 
 
-@pytest.mark.parametrize("env", [{"BYA_QKNORM_DBG": "1"}, {"BYA_QKNORM_DBG": "2"}, {"BYA_QKNORM_TABLE_SC1": "1"}])
-def test_qknorm_rope_diagnostic_variants_are_bit_identical(ops, dev, monkeypatch, env):
-    """The experiment instances of bya_qknorm_rope that tools/timeslice/repro.py switches between (the cos / sin loads
-    drained before anything else touches their address registers; 32-bit index arithmetic; table rows read past the
-    vector L1) differ in scheduling and cache policy only: same bits as the product kernel."""
+def test_qknorm_rope_statistics_bound_every_row(ops, dev):
+    """``stats``: the q/k-norm launch records, per (batch, head), the largest squared norm of the rows it WRITES (bf16-rounded,
+    after RoPE and k_scale) in `slots` partial tables; their maximum is the data-dependent score bound the joint attention
+    reads from device memory.  It must bound every row (it is a maximum of exactly these numbers), be attained, leave the
+    kernel's output bits unchanged, and work for q alone / k alone (the sharded step's call forms)."""
     from bind_your_avatar_implementation_amd.synth import rope_table
-    B, T, H, grid = 1, 226, 48, (2, 6, 10)
+    B, T, H, grid = 2, 26, 48, (3, 4, 5)
     S = T + grid[0] * grid[1] * grid[2]
     q0, k0 = rnd((B, S, H * 64), dev, 70), rnd((B, S, H * 64), dev, 71)
     qw, qb, kw, kb = (rnd((64,), dev, 72 + i, 0.3) + (1 if i % 2 == 0 else 0) for i in range(4))
+    qw = qw * torch.linspace(0.5, 3.0, 64, device=dev).to(torch.bfloat16)           # uneven gains: the case the bound is for
     cos, sin = (t.to(dev) for t in rope_table(grid))
-    def run():
-        q, k = q0.clone(), k0.clone()
-        ops.qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads=H, text_rows=T, eps=1e-6, k_scale=0.18)
-        torch.cuda.synchronize()
-        return q, k
-    qa, ka = run()
-    for k_, v_ in env.items():
-        monkeypatch.setenv(k_, v_)
-    qb_, kb_ = run()
-    assert torch.equal(qa, qb_) and torch.equal(ka, kb_)
+    q, k = q0.clone(), k0.clone()
+    ops.qknorm_rope(q, k, qw, qb, kw, kb, cos, sin, heads=H, text_rows=T, eps=1e-6, k_scale=0.18)
+    for slots in (1, 8, 64):
+        st = torch.zeros(slots, 2, B * H, dtype=torch.float32, device=dev)
+        q2, k2 = q0.clone(), k0.clone()
+        ops.qknorm_rope(q2, k2, qw, qb, kw, kb, cos, sin, heads=H, text_rows=T, eps=1e-6, k_scale=0.18, stats=st)
+        assert torch.equal(q2, q) and torch.equal(k2, k)
+        got = st.amax(0)                                                           # [2, B * H]
+        for which, t in enumerate((q, k)):
+            n2 = t.float().view(B, S, H, 64).pow(2).sum(-1)                         # [B, S, H]
+            want = n2.amax(1).reshape(B * H)
+            assert torch.allclose(got[which], want, rtol=1e-5, atol=0), (slots, which)
+            assert bool((n2.permute(0, 2, 1).reshape(B * H, S) <= got[which][:, None] * (1 + 1e-5)).all())
+    st = torch.zeros(4, 2, B * H, dtype=torch.float32, device=dev)
+    q3, k3 = q0.clone(), k0.clone()
+    ops.qknorm_rope(q3, None, qw, qb, kw, kb, cos, sin, heads=H, text_rows=T, eps=1e-6, k_scale=0.18, stats=st)
+    ops.qknorm_rope(None, k3, qw, qb, kw, kb, cos, sin, heads=H, text_rows=T, eps=1e-6, k_scale=0.18, stats=st)
+    assert torch.equal(q3, q) and torch.equal(k3, k)
+    assert torch.allclose(st.amax(0)[0], q.float().view(B, S, H, 64).pow(2).sum(-1).amax(1).reshape(-1), rtol=1e-5)
+    assert torch.allclose(st.amax(0)[1], k.float().view(B, S, H, 64).pow(2).sum(-1).amax(1).reshape(-1), rtol=1e-5)
+
+
+@pytest.mark.parametrize("S,H", [(777, 8), (1500, 6)])
+def test_joint_attention_device_bound_with_per_head_fallback(ops, dev, S, H):
+    """The data-dependent bound: heads whose max||q|| max||k|| is within the limit (90, exp2 units) run on the static-bound
+    one-wave-per-SIMD kernel, the others -- flagged by that kernel -- on the running-maximum kernel launched right behind it.
+    Half the heads here have large q (bound ~ 300): flags must say exactly which, and EVERY head must match the fp32
+    softmax at the attention bar (3e-3)."""
+    torch.manual_seed(5)
+    q = torch.randn(1, S, H, 64, device=dev) * 1.2
+    k = torch.randn(1, S, H, 64, device=dev) * 0.6
+    v = torch.randn(1, S, H, 64, device=dev)
+    big = torch.arange(H, device=dev) % 2 == 1
+    q[:, :, big] *= 6.0                                                            # |q| ~ 58, |k| ~ 4.8 -> bound ~ 280 > 90
+    qb, kb_, vb = (t.to(torch.bfloat16).reshape(1, S, H * 64).contiguous() for t in (q, k, v))
+    st = torch.zeros(8, 2, H, dtype=torch.float32, device=dev)
+    n2q = qb.float().view(S, H, 64).pow(2).sum(-1).amax(0)
+    n2k = kb_.float().view(S, H, 64).pow(2).sum(-1).amax(0)
+    st[3, 0], st[5, 1] = n2q, n2k                                                  # (any slot: the kernel takes the maximum)
+    flags = torch.full((64,), -7, dtype=torch.int32, device=dev)
+    out = torch.empty_like(qb)
+    ops.ATTN_VARIANTS.clear()
+    ops.self_attention(qb, kb_, vb, out, heads=H, tag="t", prescaled=True, bound=(st, 0, flags))
+    torch.cuda.synchronize()
+    assert ops.ATTN_VARIANTS == {("t", "d64_device_bound_w4"): 1}
+    bound = n2q.sqrt() * n2k.sqrt()
+    assert torch.equal(flags[:H].bool(), bound > 90.0) and bool(flags[:H].bool().any()) and not bool(flags[:H].bool().all())
+    sc = torch.einsum("bqhd,bkhd->bhqk", qb.float().view(1, S, H, 64), kb_.float().view(1, S, H, 64)) * math.log(2.0)
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, -1), vb.float().view(1, S, H, 64))
+    for h in range(H):
+        e = rel_fro(out.view(1, S, H, 64)[:, :, h], ref[:, :, h])
+        assert e <= 3e-3, (h, bool(flags[h]), e)
+    # the table of another launch geometry: this launch's heads at a column offset (the sharded step's form)
+    st2 = torch.zeros(2, 2, H + 5, dtype=torch.float32, device=dev)
+    st2[1, 0, 5:], st2[0, 1, 5:] = n2q, n2k
+    out2 = torch.empty_like(qb)
+    ops.self_attention(qb, kb_, vb, out2, heads=H, tag="t", prescaled=True, bound=(st2, 5, flags))
+    assert torch.equal(out2, out)
 
 
 # ----------------------------------------------------------------------------------------------- small linears
