@@ -129,26 +129,51 @@ constexpr int P2P_WAIT_GROUPS = 16;                  // workgroups of a wait: tw
 
 std::atomic<long long> g_wait_limit_ticks{30ll * 100000000ll};          // s_memrealtime ticks (100 MHz)
 
-// the copy loop of one workgroup
+// the copy loop of one workgroup.  A table entry is a 2-D piece: `rows` rows of `row_bytes` bytes, `src_pitch` / `dst_pitch`
+// bytes apart (a contiguous piece is one row).  Its chunks: a row longer than P2P_CHUNK is cut into P2P_CHUNK-byte chunks
+// (chunks_per_row > 1, one row per chunk); shorter rows are grouped, rows_per_chunk = P2P_CHUNK / row_bytes of them per chunk.
 __device__ __forceinline__ void p2p_copy_chunks(const bya_p2p_copy* __restrict__ copies, int n_copies, long long total_chunks) {
     const int tid = threadIdx.x;
     for (long long c = blockIdx.x; c < total_chunks; c += gridDim.x) {
         int i = 0;
-        while (i + 1 < n_copies && copies[i + 1].chunk0 <= c) ++i;               // <= 100 entries: a linear scan
-        const long long off = (c - copies[i].chunk0) * (long long)P2P_CHUNK;
-        const long long left = copies[i].bytes - off;
-        const int n = (int)(left < P2P_CHUNK ? left : P2P_CHUNK);
-        const char* src = static_cast<const char*>(copies[i].src) + off;
-        char* dst = static_cast<char*>(copies[i].dst) + off;
-        if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
-            const int n16 = n & ~15;
-            for (int b = tid * 16; b < n16; b += 256 * 16)
-                *reinterpret_cast<u32x4*>(dst + b) = *reinterpret_cast<const u32x4*>(src + b);
-            for (int b = n16 + tid * 2; b < n; b += 256 * 2)            // (a piece ends on a bf16 element, not on 16 bytes)
+        while (i + 1 < n_copies && copies[i + 1].chunk0 <= c) ++i;               // <= ~100 entries: a linear scan
+        const bya_p2p_copy e = copies[i];
+        if (e.row_bytes <= 0 || e.rows <= 0) continue;                           // (the place-holder entry of a rank with nothing to send)
+        const long long ci = c - e.chunk0;
+        long long row0, col0;
+        int nrows, n;                                                            // rows in this chunk, bytes per row of it
+        if (e.row_bytes > P2P_CHUNK) {
+            const long long cpr = (e.row_bytes + P2P_CHUNK - 1) / P2P_CHUNK;
+            row0 = ci / cpr;
+            col0 = (ci - row0 * cpr) * (long long)P2P_CHUNK;
+            nrows = 1;
+            const long long left = e.row_bytes - col0;
+            n = (int)(left < P2P_CHUNK ? left : P2P_CHUNK);
+        } else {
+            const long long rpc = P2P_CHUNK / e.row_bytes;
+            row0 = ci * rpc;
+            col0 = 0;
+            const long long left = e.rows - row0;
+            nrows = (int)(left < rpc ? left : rpc);
+            n = (int)e.row_bytes;
+        }
+        const char* src = static_cast<const char*>(e.src) + row0 * e.src_pitch + col0;
+        char* dst = static_cast<char*>(e.dst) + row0 * e.dst_pitch + col0;
+        const bool wide = ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) && (nrows == 1 || ((e.src_pitch | e.dst_pitch | n) & 15) == 0);
+        if (wide) {
+            const int n16 = n & ~15, per_row = n16 >> 4, total = per_row * nrows;
+            for (int t = tid; t < total; t += 256) {
+                const int r = nrows == 1 ? 0 : t / per_row, b = (t - r * per_row) << 4;
+                *reinterpret_cast<u32x4*>(dst + (long long)r * e.dst_pitch + b) = *reinterpret_cast<const u32x4*>(src + (long long)r * e.src_pitch + b);
+            }
+            for (int b = n16 + tid * 2; b < n; b += 256 * 2)            // (nrows == 1 here: a piece ends on a bf16 element, not on 16 bytes)
                 *reinterpret_cast<uint16_t*>(dst + b) = *reinterpret_cast<const uint16_t*>(src + b);
         } else {                                                        // small odd-sized pieces (the router's logits)
-            for (int b = tid * 2; b < n; b += 256 * 2)
-                *reinterpret_cast<uint16_t*>(dst + b) = *reinterpret_cast<const uint16_t*>(src + b);
+            const int per_row = n >> 1, total = per_row * nrows;
+            for (int t = tid; t < total; t += 256) {
+                const int r = nrows == 1 ? 0 : t / per_row, b = (t - r * per_row) << 1;
+                *reinterpret_cast<uint16_t*>(dst + (long long)r * e.dst_pitch + b) = *reinterpret_cast<const uint16_t*>(src + (long long)r * e.src_pitch + b);
+            }
         }
     }
 }

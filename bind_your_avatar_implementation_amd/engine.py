@@ -630,8 +630,8 @@ class DenoiseEngine:
                             qh_, kh_, vh_, st_all = sh.rows_to_heads_qkv(qkvb, st)
                             ops.self_attention(qh_[None], kh_[None], vh_[None], oh[None], heads=H // W, tag="joint", prescaled=True,
                                                score_bound=sb, bound=None if st is None else (st_all, sh.rank * (H // W), self._ws["qk_flags"]))
-                            sh.heads_to_rows(oh, xn[0])
-                            self._dit_linear("out", i, xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x,
+                            xo = sh.heads_to_rows(oh)              # (the symmetric receive buffer, already in [rows, heads] order)
+                            self._dit_linear("out", i, xo[None], at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x,
                                              gate0=mo[:, 5 * D:], gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                             continue
                         pending = [sh.rows_to_heads(qkvb[2 * W:], vh, async_op=True)]
@@ -797,7 +797,7 @@ class DenoiseEngine:
         co = m.proj_out.weight.shape[0]
         y = ops.gemm(xo, m.proj_out.weight, buf("y", B, N_loc, co), bias=m.proj_out.bias)
         if sh.active:                                        # every rank returns the full latent prediction
-            y = sh.gather_video_rows(y, out=buf("y_full", B, N, co))
+            y = sh.gather_video_rows(y, out=buf("y_full", B, N, co), in_place=True)
         out = torch.empty(B, T, co // 4, Hh, Ww, dtype=torch.bfloat16, device=self.dev)
         ops.unpatchify(y, out)
         if sh.p2p is not None:
@@ -938,7 +938,7 @@ class DenoiseEngine:
             self._r_lnlin(xb2, rn_b, st.norm4, pk, "rg_mlp", st.mlp[0].weight, st.mlp[0].bias, rh_b, act="gelu_erf")
             self._r_linres(rh_b, pk, "rg_mlp", st.mlp[2], xb2)
             if bi + 1 < nblk:
-                rp.b_to_a(xb, xa)
+                xa = rp.b_to_a(xb, xa)
         fp = r.final_proj[0]
         lb = buf("rp_logits_b", T * rp.nLB, n_id)
         ops.router_head(xb.view(n_id, T * rp.nLB, F), fp.weight, fp.bias, lb, n_id, T * rp.nLB)

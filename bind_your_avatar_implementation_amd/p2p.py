@@ -100,7 +100,7 @@ class Channel:
         self._join = None
 
     def bind(self, pieces):
-        sig = tuple((p[0].data_ptr(), p[1], p[2], p[3], p[0].numel()) for p in pieces)
+        sig = tuple((p[0].data_ptr(), p[1], p[2], p[3], tuple(p[0].shape), p[0].stride(), p[4] if len(p) > 4 else None) for p in pieces)
         ent = self.tables.get(sig)
         if ent is None:
             ent = self.tables[sig] = list(self.grp._build_table(pieces)) + [False]
@@ -213,7 +213,10 @@ class P2PGroup:
         kind = kind or self.mem
         with torch.cuda.device(self.dev):
             if self.solo is not None:
-                local = torch.zeros(*shape, dtype=dtype, device=self.dev)
+                # (bf16 receive buffers start as gaussian noise, not zeros: the peers' parts never arrive, and kernels that
+                # multiply zeros draw less power and clock higher than they would on a node)
+                local = (torch.randn(*shape, device=self.dev) * 0.5).to(dtype) if dtype == torch.bfloat16 else \
+                    torch.zeros(*shape, dtype=dtype, device=self.dev)
                 if name == "__ctrl__":
                     peers = [_Peer(local.data_ptr(), shape, dtype, local)] * self.world     # every flag lands in the own block
                 else:
@@ -318,24 +321,49 @@ class P2PGroup:
             ch = self._channels[key] = Channel(self, len(self._channels))
         return ch.bind(pieces)
 
+    @staticmethod
+    def _rows_of(src):
+        """A piece's source as (rows, row elements, row pitch in elements): any contiguous tensor is one row; otherwise a view
+        whose trailing dimensions are dense behind ONE strided leading dimension (e.g. ``x[:, a:b]`` of a [P, L, F] tensor)."""
+        if src.is_contiguous():
+            return 1, src.numel(), src.numel()
+        inner = src[0]
+        if not inner.is_contiguous():
+            raise ValueError("P2P piece sources must be contiguous, or dense rows behind one strided leading dimension")
+        return src.shape[0], inner.numel(), src.stride(0)
+
     def _build_table(self, pieces):
+        """pieces: (src, peer, name, offset) or (src, peer, name, offset, dst_pitch): ``src`` lands at element ``offset`` of
+        rank ``peer``'s buffer ``name``; a strided source (see ``_rows_of``) and / or ``dst_pitch`` (elements between the
+        starts of consecutive rows at the destination; default: dense) make it a 2-D piece."""
         rows, chunk0 = [], 0
-        for src, peer, name, offset in pieces:
-            nbytes = src.numel() * src.element_size()
-            if nbytes == 0:
+        for piece in pieces:
+            src, peer, name, offset = piece[:4]
+            if src.numel() == 0:
                 continue
+            es = src.element_size()
+            nrows, ncols, spitch = self._rows_of(src)
+            dpitch = piece[4] if len(piece) > 4 and piece[4] is not None else ncols
+            if len(piece) > 4 and piece[4] is not None and nrows == 1 and src.dim() >= 2 and src.shape[0] > 1:
+                # a contiguous source scattered to pitched destination rows: its leading dimension is the row index
+                nrows, ncols = src.shape[0], src[0].numel()
+                spitch = ncols
             dst_t = self.peers(name)[peer]
-            if not src.is_contiguous():
-                raise ValueError("P2P piece sources must be contiguous")
-            if dst_t.dtype != src.dtype or offset < 0 or offset + src.numel() > dst_t.numel():
+            last = offset + (nrows - 1) * dpitch + ncols
+            if dst_t.dtype != src.dtype or offset < 0 or last > dst_t.numel() or dpitch < ncols:
                 raise ValueError(f"P2P piece does not fit buffer {name!r} on rank {peer}")
-            dst = dst_t.data_ptr() + offset * src.element_size()
-            if (src.data_ptr() | dst | nbytes) & 1:
+            dst = dst_t.data_ptr() + offset * es
+            if (src.data_ptr() | dst | (ncols * es) | (spitch * es) | (dpitch * es)) & 1:
                 raise ValueError("P2P pieces must be 2-byte aligned in address and size")
-            rows.append((src.data_ptr(), dst, nbytes, chunk0))
-            chunk0 += (nbytes + CHUNK - 1) // CHUNK
+            row_bytes = ncols * es
+            rows.append((src.data_ptr(), dst, row_bytes, nrows, spitch * es, dpitch * es, chunk0))
+            if row_bytes > CHUNK:
+                chunk0 += nrows * ((row_bytes + CHUNK - 1) // CHUNK)
+            else:
+                rpc = CHUNK // row_bytes
+                chunk0 += (nrows + rpc - 1) // rpc
         if not rows:                                     # nothing to send: still takes part in the flag protocol
-            rows, chunk0 = [(self.ctrl.data_ptr(), self.ctrl.data_ptr(), 0, 0)], 1
+            rows, chunk0 = [(self.ctrl.data_ptr(), self.ctrl.data_ptr(), 0, 0, 0, 0, 0)], 1
         table = torch.tensor(rows, dtype=torch.int64, device=self.dev)
         return table, len(rows), chunk0, [p[0] for p in pieces]      # (the sources stay alive with the table)
 

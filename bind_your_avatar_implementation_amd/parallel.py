@@ -188,7 +188,7 @@ class SeqShard:
                 res.append(outs[c])
         return res
 
-    def gather_video_rows(self, local_video, scratch=None, out=None):
+    def gather_video_rows(self, local_video, scratch=None, out=None, in_place=False):
         """[..., N_loc, F] per rank (rank 0 owns fewer video rows: its shard starts with the text rows)
         -> [..., N, F].  Implemented as a row all-gather of Tt_loc junk rows + the video rows.  ``out``: where the result
         goes (the engine passes a workspace tensor; without it a fresh tensor is returned); the staging buffers of the
@@ -205,6 +205,8 @@ class SeqShard:
             full = self.p2p.symmetric(name, (C, self.N, F), flat.dtype)
             src = flat.contiguous()
             self._exchange("gv", [(src[c], j, name, (c * self.N + self.v0) * F) for j in range(self.world) for c in range(C)])
+            if in_place:                      # the caller only READS the result before the next gather of this shape: no copy
+                return full.view(*lead, self.N, F)
             if out is None:
                 return full.view(*lead, self.N, F).clone()
             out.view(C, self.N, F).copy_(full)
@@ -275,15 +277,15 @@ class SeqShard:
         if self.p2p is not None:
             # (the name carries the geometry like every other symmetric buffer: one P2PGroup serves every resolution and frame
             # count the model is run at)
+            # 2-D pieces: this rank's heads of destination j's rows go straight to column block `rank` of j's [S_loc_j, W * Dl]
+            # buffer -- the layout the out-projection reads (round 4 received [W, S_loc, Dl] and permuted it with a copy kernel).
+            # The RETURNED tensor is the symmetric buffer itself: the caller reads it in place (``out`` is not written).
             name = f"h2r:{(self.S, self.world, Dl)}"
-            recv = self.p2p.symmetric(name, (self.world, self.S_loc, Dl), o_heads.dtype)       # (rank j: [W, sizes[j], Dl])
-            pieces = [(o_heads[self.starts[j]:self.starts[j] + self.sizes[j]], j, name, self.rank * self.sizes[j] * Dl)
+            recv = self.p2p.symmetric(name, (self.S_loc, self.world * Dl), o_heads.dtype)     # (rank j: [sizes[j], W * Dl])
+            pieces = [(o_heads[self.starts[j]:self.starts[j] + self.sizes[j]], j, name, self.rank * Dl, self.world * Dl)
                       for j in range(self.world)]
             self._exchange("h2r", pieces)
-            if out is None:
-                out = torch.empty(self.S_loc, self.world * Dl, dtype=o_heads.dtype, device=o_heads.device)
-            out.view(self.S_loc, self.world, Dl).copy_(recv.permute(1, 0, 2))
-            return out
+            return recv
         recv = self.buf("h2r_recv", (self.world, self.S_loc, Dl), o_heads)
         if self.even:
             h = self._a2a(recv.view(-1), o_heads.reshape(-1), async_op=True)
@@ -407,19 +409,12 @@ class RouterPartition:
         compute stream; it runs while the exchange is in flight on the communicator's stream."""
         F = xa.shape[-1]
         in_splits = [self.nPA * (b - a) * F for a, b in self.LB]
-        send = self.buf("a2b_send", (sum(in_splits),), xa)
-        off = 0
-        for (a, b), n in zip(self.LB, in_splits):                  # pack per destination: W slice copies, no temporaries
-            send[off:off + n].view(self.nPA, b - a, F).copy_(xa[:, a:b])
-            off += n
         if self.p2p is not None:
-            # my pairs of destination j's locations go to rows [pa0, pa1) of j's xb [pairs, nLB_j, F]
+            # my pairs of destination j's locations go to rows [pa0, pa1) of j's xb [pairs, nLB_j, F]: one 2-D piece per
+            # destination straight out of xa (rows = my pairs; a pair's locations [a, b) are dense) -- no pack copies
             xb = self.recv_buf("rp_xb", (self.pairs, self.nLB, F), xa)
             name = self._name("rp_xb", (self.pairs, self.nLB, F))
-            pieces, off = [], 0
-            for j, ((a, b), n) in enumerate(zip(self.LB, in_splits)):
-                pieces.append((send[off:off + n], j, name, self.pa0 * (b - a) * F))     # (peer j's copy has ITS shape)
-                off += n
+            pieces = [(xa[:, a:b], j, name, self.pa0 * (b - a) * F) for j, (a, b) in enumerate(self.LB)]     # (peer j's copy has ITS shape)
             if overlap is None:
                 self._exchange("a2b", pieces)
                 return xb
@@ -427,6 +422,11 @@ class RouterPartition:
             overlap()
             h.wait()
             return xb
+        send = self.buf("a2b_send", (sum(in_splits),), xa)
+        off = 0
+        for (a, b), n in zip(self.LB, in_splits):                  # pack per destination: W slice copies, no temporaries
+            send[off:off + n].view(self.nPA, b - a, F).copy_(xa[:, a:b])
+            off += n
         if xb is None:
             xb = torch.empty(self.pairs, self.nLB, F, dtype=xa.dtype, device=xa.device)
         out_splits = [(b - a) * self.nLB * F for a, b in self.PA]
@@ -440,22 +440,24 @@ class RouterPartition:
     def b_to_a(self, xb, xa=None):
         """xb [pairs, nLB, F] -> xa [nPA, per_frame, F]."""
         F = xb.shape[-1]
+        if self.p2p is not None:
+            # destination j's pairs [a, b) of my locations go to columns [lb0, lb1) of j's xa [nPA_j, per_frame, F] -- which is
+            # the symmetric "rp_xa" buffer (what ``tokens_to_a`` returned): one 2-D piece per destination, no unpack copies
+            name = self._name("rp_xa", (self.nPA, self.per_frame, F))
+            mine = self.recv_buf("rp_xa", (self.nPA, self.per_frame, F), xb)
+            if xa is not None and xa.data_ptr() != mine.data_ptr():
+                raise ValueError("b_to_a on the P2P transport writes into the symmetric rp_xa buffer: pass the tensor tokens_to_a returned")
+            pieces = [(xb[a:b], j, name, self.lb0 * F, self.per_frame * F) for j, (a, b) in enumerate(self.PA)]
+            self._exchange("b2a", pieces)
+            return mine
         if xa is None:
             xa = torch.empty(self.nPA, self.per_frame, F, dtype=xb.dtype, device=xb.device)
         in_splits = [(b - a) * self.nLB * F for a, b in self.PA]
         out_splits = [self.nPA * (b - a) * F for a, b in self.LB]
-        if self.p2p is not None:
-            # destination j receives, source after source, [nPA_j, nLB_source, F]: mine starts after the lower ranks' locations
-            recv = self.recv_buf("b2a_recv", (sum(out_splits),), xb)
-            name = self._name("b2a_recv", (sum(out_splits),))
-            before = self.LB[self.rank][0]                          # locations owned by lower ranks
-            pieces = [(xb[a:b], j, name, (b - a) * before * F) for j, (a, b) in enumerate(self.PA)]
-            self._exchange("b2a", pieces)
-        else:
-            recv = self.buf("b2a_recv", (sum(out_splits),), xb)
-            h = self._a2a(recv, xb.reshape(-1), out_splits, in_splits)
-            if h is not None:
-                h.wait()
+        recv = self.buf("b2a_recv", (sum(out_splits),), xb)
+        h = self._a2a(recv, xb.reshape(-1), out_splits, in_splits)
+        if h is not None:
+            h.wait()
         off = 0
         for a, b in self.LB:
             n = self.nPA * (b - a) * F
@@ -466,19 +468,17 @@ class RouterPartition:
     def gather_b_rows(self, yb, out=None):
         """yb [T_or_pairs, nLB, C] per rank (location-major) -> [T_or_pairs, per_frame, C] on every rank."""
         lead, C = yb.shape[0], yb.shape[-1]
+        if self.p2p is not None:
+            # every rank's locations straight into place on every peer: one 2-D piece per destination (rows = lead).  The
+            # result is the symmetric buffer itself (read it before the next gather of this shape; ``out`` is not written).
+            full = self.recv_buf("gb_out", (lead, self.per_frame, C), yb)
+            name = self._name("gb_out", (lead, self.per_frame, C))
+            src = yb.contiguous()
+            self._exchange("gb", [(src, j, name, self.lb0 * C, self.per_frame * C) for j in range(self.world)])
+            return full
         nmax = max(b - a for a, b in self.LB)
         pad = self.buf("gb_pad", (lead, nmax, C), yb, zero=True)
         pad[:, :self.nLB] = yb
-        if self.p2p is not None:
-            full = self.recv_buf("gb_full", (self.world * lead, nmax, C), yb)
-            name = self._name("gb_full", (self.world * lead, nmax, C))
-            self._exchange("gb", [(pad, j, name, self.rank * lead * nmax * C) for j in range(self.world)])
-            full = full.view(self.world, lead, nmax, C)
-            if out is None:
-                out = torch.empty(lead, self.per_frame, C, dtype=yb.dtype, device=yb.device)
-            for j, (a, b) in enumerate(self.LB):
-                out[:, a:b] = full[j, :, :b - a]
-            return out
         full = self.buf("gb_full", (self.world * lead, nmax, C), yb)
         if pad.is_cuda and dist.get_backend(self.group) == "gloo":
             host = torch.empty(full.shape, dtype=full.dtype)

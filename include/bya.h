@@ -446,8 +446,8 @@ int bya_alltoall_router(const void* send, void* recv, const int64_t* send_counts
  * hipGraph (RCCL collectives are neither).  No reference counterpart (the reference has no inference parallelism).
  * Set-up is the host's (bind_your_avatar_implementation_amd/p2p.py): every rank allocates its receive buffers and one
  * control block of 64 uint32 words per channel (zero-filled), trades hipIpc handles once, and builds per channel, in DEVICE
- * memory, (a) the copy table: `src` local, `dst` an address inside a peer's (or its own) receive buffer mapped into this
- * process, `bytes` % 2 == 0 (16-byte aligned pieces take the fast path), `chunk0` = number of 64 KiB chunks of the entries before it; (b) `peer_ctrl[p]` = the
+ * memory, (a) the copy table (bya_p2p_copy below): `src` local, `dst` an address inside a peer's (or its own) receive buffer
+ * mapped into this process; 16-byte aligned pieces and pitches take the fast path; (b) `peer_ctrl[p]` = the
  * channel's control block ON PEER p (mapped), p < world, own rank included.
  * bya_p2p_push: copy every table entry, then publish the channel's next sequence number to word `rank` of every peer's
  * control block.  bya_p2p_wait (receiver, same channel, once per push of the peers): returns to the stream when all
@@ -461,11 +461,14 @@ int bya_alltoall_router(const void* send, void* recv, const int64_t* send_counts
  * result made from a buffer that never arrived cannot be consumed.  The caller guarantees that a receive buffer is not
  * pushed into again before its owner has consumed it (the step's data dependencies do).
  * --------------------------------------------------------------------------------------------- */
-typedef struct bya_p2p_copy {
+typedef struct bya_p2p_copy {      /* a 2-D piece: `rows` rows of `row_bytes` bytes (a contiguous piece is ONE row) */
     const void* src;
     void* dst;
-    int64_t bytes;
-    int64_t chunk0;
+    int64_t row_bytes;             /* % 2 == 0 */
+    int64_t rows;
+    int64_t src_pitch, dst_pitch;  /* bytes from one row to the next on either side (% 2 == 0; ignored when rows == 1) */
+    int64_t chunk0;                /* chunks of the entries before this one; an entry has rows * ceil(row_bytes / 64 KiB) chunks
+                                      when row_bytes > 64 KiB, else ceil(rows / floor(64 KiB / row_bytes)) */
 } bya_p2p_copy;
 
 int bya_p2p_push(const bya_p2p_copy* copies_dev, int32_t n_copies, int64_t total_chunks, void* const* peer_ctrl_dev,
