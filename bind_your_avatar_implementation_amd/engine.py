@@ -313,13 +313,13 @@ class DenoiseEngine:
         return t.to(device=self.dev, dtype=torch.bfloat16).contiguous()
 
     # ------------------------------------------------------------------------------------------ invariants
-    def _face_invariants(self, id_cond, id_vit_hidden, B, n_id):
+    def _face_invariants(self, id_cond, id_vit_hidden, B, n_id, after_layer=None):
         # the row counts in here (face tokens, ViT tokens, latents) are the model's, not a partition's: skinny Linears may
         # take the weight-streaming kernel (ops.weight_streaming)
         with ops.weight_streaming():
-            return self._face_invariants_body(id_cond, id_vit_hidden, B, n_id)
+            return self._face_invariants_body(id_cond, id_vit_hidden, B, n_id, after_layer)
 
-    def _face_invariants_body(self, id_cond, id_vit_hidden, B, n_id):
+    def _face_invariants_body(self, id_cond, id_vit_hidden, B, n_id, after_layer=None):
         """LocalFacialExtractor (models/router.py:157-193) + the per-layer face K/V (router.py:247,254) and router
         keys (router.py:377-383).  Returns (kv[l] [B,n_id,32,2*inner], kr[l] [B,n_id,32,qk])."""
         m = self.m
@@ -387,6 +387,8 @@ class DenoiseEngine:
             ops.gemm(kn.view(B * n_id, nq, -1), self.r_to_k[l], kr_l.view(B * n_id, nq, -1))
             kvs.append(kv_l.view(B, n_id, nq, -1))
             krs.append(kr_l.view(B, n_id, nq, -1))
+            if after_layer is not None:
+                after_layer(l)           # (the step marks its side stream here: routing layer l waits for exactly this much)
         return kvs, krs
 
     def _audio_invariants(self, audio_embeds, T, B, n_id):
@@ -536,17 +538,36 @@ class DenoiseEngine:
         # (recomputed every step like the reference unless cached.  Their ~250 small launches -- 5 ms when they run alone --
         # go to a side stream: nothing needs them before the first routing layer, ~8 ms into the step, so they fill the CUs
         # the big kernels of patch embed and block 0 leave idle; the main stream joins right before block 0's face branch.)
-        inv_side = None
+        # (round 5: the main stream no longer joins the WHOLE conditioning before block 0's face branch.  Routing layer l waits
+        # for the side stream's mark behind face layer l's K/V and keys, the first audio layer for the mark behind the audio
+        # K/V launch, which is enqueued right behind face layer 0: at 8 ranks the conditioning -- replicated on every rank -- is
+        # 7 ms of launches against a 1.9 ms DiT layer, and nothing needs face layer 20's keys before layer 40.)
+        inv_side, face_marks, audio_mark = None, {}, [None]
         if (use_face or use_audio) and ops._TIMERS is None and os.environ.get("BYA_INVARIANTS_SIDE_STREAM", "1") != "0":
             if self._side is None:
                 self._side = torch.cuda.Stream(self.dev)
             inv_side = ops.on_stream(self._side)
         with (inv_side if inv_side is not None else contextlib.nullcontext()):
+            audio_res = []
+
+            def audio_now():
+                if use_audio and not audio_res:
+                    audio_res.append(self._cached("audio", [audio_embeds], lambda: self._audio_invariants(audio_embeds, T, B, n_id)))
+                    if inv_side is not None:
+                        audio_mark[0] = inv_side.mark()
+
+            def after_face_layer(l):
+                if inv_side is not None:
+                    face_marks[l] = inv_side.mark()
+                if l == 0:
+                    audio_now()
             if use_face:
                 flat_face = list(id_cond[:n_id]) + [t for i in range(n_id) for t in id_vit_hidden[i]]
-                face_kv, router_k = self._cached("face", flat_face, lambda: self._face_invariants(id_cond, id_vit_hidden, B, n_id))
+                face_kv, router_k = self._cached("face", flat_face,
+                                                 lambda: self._face_invariants(id_cond, id_vit_hidden, B, n_id, after_face_layer))
+            audio_now()
             if use_audio:
-                audio_k, audio_v = self._cached("audio", [audio_embeds], lambda: self._audio_invariants(audio_embeds, T, B, n_id))
+                audio_k, audio_v = audio_res[0]
         if use_audio:
             af = self._bf(af_matrix)
         forced = None
@@ -677,12 +698,10 @@ class DenoiseEngine:
             if taps is not None:
                 taps[f"block{i}"] = x.clone()
 
-            if inv_side is not None:                 # the conditioning is needed from here on
-                inv_side.join()
-                inv_side = None
             # ---- P1 + R1..R4 + G1: face routing (models/transformer.py:737-833)
             if use_face and i % m.cross_attn_interval == 0:
                 ca = i // m.cross_attn_interval
+                ops.on_stream.need(face_marks.pop(ca, None))     # the side stream has produced this layer's face K/V and keys
                 pc = m.perceiver_cross_attention[ca]
                 inner_p = pc.to_q.weight.shape[0]
                 hd_p = inner_p // 16
@@ -733,6 +752,8 @@ class DenoiseEngine:
 
             # ---- A1 + G2: audio injection (models/transformer.py:858-936)
             if use_audio and i % m.audio_attn_interval == 0:
+                ops.on_stream.need(audio_mark[0])
+                audio_mark[0] = None
                 al = m.audio_model.layers[i // m.audio_attn_interval]
                 at = al["attn"]
                 an = buf("lat", B, N_loc, D)
@@ -787,6 +808,8 @@ class DenoiseEngine:
                 if taps is not None:
                     taps[f"audio{i}"] = xv.clone()
 
+        if inv_side is not None:
+            inv_side.join()                  # (whatever of the conditioning no layer waited for: the step ends behind all of it)
         # ---- F1: final norm, AdaLN head, projection, unpatchify (models/transformer.py:938-957)
         xf = buf("lat", B, N_loc, D)
         ops.layernorm(xv, xf, m.norm_final.weight, m.norm_final.bias, eps=m.norm_final.eps)

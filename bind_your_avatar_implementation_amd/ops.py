@@ -72,6 +72,18 @@ class on_stream:
         self.ctx.__exit__(*exc)
         return False
 
+    def mark(self):
+        """Inside the block: an event at this point of the side stream (``need(event)`` later makes the main stream wait for
+        everything enqueued up to here, and no more)."""
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    @staticmethod
+    def need(ev):
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def join(self):
         if self.done is not None:
             torch.cuda.current_stream().wait_event(self.done)
