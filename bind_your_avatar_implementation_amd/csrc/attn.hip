@@ -32,16 +32,6 @@ namespace {
 #ifndef BYA_ATTN_OCC
 #define BYA_ATTN_OCC 4
 #endif
-#ifndef BYA_ATTN_QB2
-#define BYA_ATTN_QB2 1           // two query blocks per wave for the static-bound kernel (0 = the one-block kernel of round 1)
-#endif
-#ifndef BYA_ATTN_QB2_RING3
-#define BYA_ATTN_QB2_RING3 3     // with BYA_ATTN_QB2: 3 or 4 K/V stages and the rendezvous in the middle of the tile (0 = 2 stages)
-#endif
-#ifndef BYA_ATTN_QB2_KPF
-#define BYA_ATTN_QB2_KPF 0       // 1 = two-block kernel requests the next tile's K fragments right behind the rendezvous
-                                 // (no measurable change once the kernel sits at the power limit: off)
-#endif
 #ifndef BYA_ATTN_RING
 #define BYA_ATTN_RING 2          // K/V stages in LDS for head_dim 64 (3 = staging two tiles ahead; experiment switch)
 #endif
@@ -736,269 +726,9 @@ __global__ __launch_bounds__(256) void attn_kv_mix_kernel_d128(MixArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Two query blocks per wave (static-bound softmax, head_dim 64 only): a wave owns 64 query rows, a workgroup 256, and
-// every K and V fragment read from LDS feeds BOTH 32-row blocks -- half the LDS reads, half the K/V staging and half the
-// workgroup rendezvous per FLOP of the one-block form, at two waves per SIMD (256 registers) instead of four.
-// One softmax chunk = the eight scores (keys 16 c .. 16 c + 15 of the tile, this lane's half) of one query block: 8 v_exp,
-// 8 adds, 4 converts -> the P fragment of key step c.
-template <bool TAIL>
-__device__ __forceinline__ void softmax_chunk(const f32x16 (&sacc)[2], int c, bf16x8& pf, float& psum, int kv_valid, int hf) {
-    const int u = c >> 1, tt = c & 1;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float sv = sacc[u][tt * 8 + e];
-        if (TAIL) {
-            const int i = tt * 8 + e;
-            const int kv = u * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
-            if (kv >= kv_valid) sv = -INFINITY;
-        }
-        const float pv = __builtin_amdgcn_exp2f(sv);
-        psum += pv;
-        pf[e] = (__bf16)pv;
-    }
-}
-
-// The tile is software-pipelined INSIDE the wave: the softmax of block A runs between the QK^T MFMAs of block B, the
-// softmax of block B between the PV MFMAs of block A (sched_barrier pins the interleaving; a wave of the one-block kernel
-// leaves the matrix pipe idle during its softmax and relies on the other waves of the SIMD).
-// K fragments of a tile: lane (r, hf) holds keys r and r + 32, dims 16 s + 8 hf .. + 7 (A operand of S^T = K.Q^T)
-__device__ __forceinline__ void k_frag_reads(const char* kt, bf16x8 (&kf)[2][4], int r, int hf) {
-    constexpr int D = 64, ROW_BYTES = D * 2;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int krow = u * 32 + r;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            kf[u][s] = *reinterpret_cast<const bf16x8*>(kt + krow * ROW_BYTES + (((2 * s + hf) ^ kswz<D>(krow)) << 4));
-    }
-}
-
-// kf: this tile's K fragments on entry; when PREFETCH, the NEXT tile's on exit (requested right behind the rendezvous,
-// in flight under the whole PV phase: the fragment registers are dead once the QK^T MFMAs have been issued).
-template <bool TAIL, bool PREFETCH, typename Mid>
-__device__ __forceinline__ void attn_tile2(const char* kt, const uint32_t (&vbase)[2], const bf16x8 (&qf)[2][4],
-                                           f32x16 (&oacc)[2][2], float (&l_run)[2], int kv_valid, int r, int hf, Mid&& mid,
-                                           bf16x8 (&kf)[2][4], const char* next_kt) {
-    constexpr int D = 64, ROW_BYTES = D * 2;
-    if (!PREFETCH) k_frag_reads(kt, kf, r, hf);
-    f32x16 sacc[2][2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[qb][u][i] = 0.f;
-    // QK^T of block A
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        sacc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][s], qf[0][s], sacc[0][0], 0, 0, 0);
-        sacc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][s], qf[0][s], sacc[0][1], 0, 0, 0);
-    }
-    VFrag<D> fa, fb;
-    v_issue<D, 0>(fa, vbase);
-    __builtin_amdgcn_sched_barrier(0);
-    // QK^T of block B || softmax of block A
-    bf16x8 pf[2][4];
-    float psum0 = 0.f, psum1 = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        sacc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][s], qf[1][s], sacc[1][0], 0, 0, 0);
-        sacc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][s], qf[1][s], sacc[1][1], 0, 0, 0);
-        softmax_chunk<TAIL>(sacc[0], s, pf[0][s], psum0, kv_valid, hf);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    l_run[0] += psum0;
-    mid();                                             // (three-stage ring: the tile's rendezvous + next staging sit here)
-    if (PREFETCH && next_kt) {
-        k_frag_reads(next_kt, kf, r, hf);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // PV of block A || softmax of block B, then PV of block B, key step by key step (V fragments shared)
-    v_issue<D, 1>(fb, vbase);
-    lgkm_wait<4>();
-    pv_mfma<D>(fa, pf[0][0], oacc[0]);
-    softmax_chunk<TAIL>(sacc[1], 0, pf[1][0], psum1, kv_valid, hf);
-    __builtin_amdgcn_sched_barrier(0);
-    pv_mfma<D>(fa, pf[1][0], oacc[1]);
-    v_issue<D, 2>(fa, vbase);
-    lgkm_wait<4>();
-    pv_mfma<D>(fb, pf[0][1], oacc[0]);
-    softmax_chunk<TAIL>(sacc[1], 1, pf[1][1], psum1, kv_valid, hf);
-    __builtin_amdgcn_sched_barrier(0);
-    pv_mfma<D>(fb, pf[1][1], oacc[1]);
-    v_issue<D, 3>(fb, vbase);
-    lgkm_wait<4>();
-    pv_mfma<D>(fa, pf[0][2], oacc[0]);
-    softmax_chunk<TAIL>(sacc[1], 2, pf[1][2], psum1, kv_valid, hf);
-    __builtin_amdgcn_sched_barrier(0);
-    pv_mfma<D>(fa, pf[1][2], oacc[1]);
-    lgkm_wait<0>();
-    pv_mfma<D>(fb, pf[0][3], oacc[0]);
-    softmax_chunk<TAIL>(sacc[1], 3, pf[1][3], psum1, kv_valid, hf);
-    __builtin_amdgcn_sched_barrier(0);
-    pv_mfma<D>(fb, pf[1][3], oacc[1]);
-    l_run[1] += psum1;
-}
-
-__device__ __forceinline__ void attn_fwd_body2(const AttnArgs& p, char* smem) {
-    constexpr int D = 64, ROW_BYTES = D * 2, TILE_BYTES = KV_TILE * ROW_BYTES, QPW = 64, QPB = 256;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hf = lane >> 5;
-    const int nbh = p.nb1 * p.nb2 * p.heads;
-    int bh, qt;
-    if (nbh % 8 == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        bh = (j / p.nqt) * 8 + xcd;
-        qt = j % p.nqt;
-    } else {
-        const int total = nbh * p.nqt, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int cq = total >> 3, cr = total & 7;
-        const int base = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
-        if (j >= cq + (xcd < cr ? 1 : 0)) return;
-        bh = (base + j) / p.nqt;
-        qt = (base + j) % p.nqt;
-    }
-    if (bh >= nbh) return;
-    const int head = bh % p.heads, b12 = bh / p.heads;
-    const int b1 = b12 / p.nb2, b2 = b12 % p.nb2;
-    const bf16_t* Q = p.q + b1 * p.q_s1 + b2 * p.q_s2 + (long long)head * D;
-    const bf16_t* K = p.k + b1 * p.k_s1 + b2 * p.k_s2 + (long long)head * D;
-    const bf16_t* V = p.v + b1 * p.v_s1 + b2 * p.v_s2 + (long long)head * D;
-    bf16_t* O = p.o + b1 * p.o_s1 + b2 * p.o_s2 + (long long)head * D;
-
-    const int q0 = qt * QPB + wave * QPW;
-    bf16x8 qf[2][4];
-    bool q_valid[2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        int qrow = q0 + qb * 32 + r;
-        q_valid[qb] = qrow < p.Sq;
-        qrow = q_valid[qb] ? qrow : p.Sq - 1;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            qf[qb][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Q + (long long)qrow * p.q_row + s * 16 + hf * 8));
-    }
-    f32x16 oacc[2][2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[qb][d][i] = 0.f;
-    float l_run[2] = {0.f, 0.f};
-
-    const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-    uint32_t voff[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        const int row = 4 * hf + tq;
-        const int chunk = 4 * d + 2 * (g & 1) + (tp >> 1);
-        voff[d] = row * ROW_BYTES + ((chunk ^ vswz<D>(row)) << 4) + (tp & 1) * 8;
-    }
-    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)K, 0, (int)(((long long)(p.Skv - 1) * p.k_row + D) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)V, 0, (int)(((long long)(p.Skv - 1) * p.v_row + D) * 2), 0x00020000);
-    uint32_t kvo[2], vvo[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = wave * 16 + q * 8 + lane / 8, slot = lane % 8;
-        kvo[q] = (uint32_t)row * (uint32_t)(p.k_row * 2) + ((slot ^ kswz<D>(row)) << 4);
-        vvo[q] = (uint32_t)row * (uint32_t)(p.v_row * 2) + ((slot ^ vswz<D>(row)) << 4);
-    }
-    const int k_tile_stride = KV_TILE * (int)p.k_row * 2, v_tile_stride = KV_TILE * (int)p.v_row * 2;
-    auto stage = [&](int t) {
-        char* st = smem + (BYA_ATTN_QB2_RING3 ? (t % BYA_ATTN_QB2_RING3) : (t & 1)) * 2 * TILE_BYTES + wave * 16 * ROW_BYTES;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, LDS_PTR(st + q * 1024), 16, kvo[q], t * k_tile_stride, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, LDS_PTR(st + TILE_BYTES + q * 1024), 16, vvo[q], t * v_tile_stride, 0, 0);
-        }
-    };
-    const int ntiles = (p.Skv + KV_TILE - 1) / KV_TILE, nfull = p.Skv / KV_TILE;
-#if BYA_ATTN_QB2_RING3
-    // Three K/V stages, staging TWO tiles ahead, and the per-tile rendezvous in the MIDDLE of the tile (behind the QK^T
-    // MFMAs, in front of the PV phase): a wave runs from the last PV MFMA of one tile straight into the K fragment reads
-    // of the next -- tile t + 1 landed, for everybody, at tile t's rendezvous.  Tile t + 2 goes into the stage of tile
-    // t - 1, which every wave has left when it reaches tile t's rendezvous.  (Rotating the loop further, so that the K
-    // reads of tile t + 1 are issued in front of the PV phase of tile t, needs more than 256 registers: measured -11 %.)
-    constexpr int NST = BYA_ATTN_QB2_RING3;               // 3 or 4 stages: staging NST - 1 tiles ahead
-    stage(0);
-    if (ntiles > 1) stage(1);
-    if (NST == 4 && ntiles > 2) stage(2);
-    // tile 0 has landed once all but the younger requests (4 per tile) are done
-    if (NST == 4 && ntiles > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    int slot = 0;
-    bf16x8 kf[2][4];
-    k_frag_reads(smem, kf, r, hf);                        // tile 0
-    for (int t = 0; t < nfull; ++t) {
-        const char* kt = smem + slot * 2 * TILE_BYTES;
-        uint32_t vbase[2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) vbase[d] = lds0 + slot * 2 * TILE_BYTES + TILE_BYTES + voff[d];
-        auto mid = [&]() {
-            // tile t + 1 has landed (with four stages tile t + 2 may still be in flight)
-            if (NST == 4 && t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_barrier" ::: "memory");
-            if (t + NST - 1 < ntiles) stage(t + NST - 1);
-        };
-        const int nslot = slot == NST - 1 ? 0 : slot + 1;
-        attn_tile2<false, BYA_ATTN_QB2_KPF != 0>(kt, vbase, qf, oacc, l_run, KV_TILE, r, hf, mid, kf,
-                                                 t + 1 < ntiles ? smem + nslot * 2 * TILE_BYTES : nullptr);
-        slot = nslot;
-    }
-    if (nfull < ntiles) {                                  // ragged last tile: landed at the previous tile's rendezvous
-        const char* kt = smem + slot * 2 * TILE_BYTES;
-        uint32_t vbase[2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) vbase[d] = lds0 + slot * 2 * TILE_BYTES + TILE_BYTES + voff[d];
-        auto no_mid = []() {};
-        attn_tile2<true, BYA_ATTN_QB2_KPF != 0>(kt, vbase, qf, oacc, l_run, p.Skv - nfull * KV_TILE, r, hf, no_mid, kf, nullptr);
-    }
-#else
-    stage(0);
-    auto no_mid = []() {};
-    bf16x8 kf2[2][4];
-    for (int t = 0; t < nfull; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < ntiles) stage(t + 1);
-        const char* kt = smem + (t & 1) * 2 * TILE_BYTES;
-        uint32_t vbase[2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) vbase[d] = lds0 + (t & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
-        attn_tile2<false, false>(kt, vbase, qf, oacc, l_run, KV_TILE, r, hf, no_mid, kf2, nullptr);
-    }
-    if (nfull < ntiles) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const char* kt = smem + (nfull & 1) * 2 * TILE_BYTES;
-        uint32_t vbase[2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) vbase[d] = lds0 + (nfull & 1) * 2 * TILE_BYTES + TILE_BYTES + voff[d];
-        attn_tile2<true, false>(kt, vbase, qf, oacc, l_run, p.Skv - nfull * KV_TILE, r, hf, no_mid, kf2, nullptr);
-    }
-#endif
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[qb]), __float_as_uint(l_run[qb]), false, false);
-        const float inv = 1.0f / (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1]));
-        bf16_t* orow = O + (long long)(q_valid[qb] ? q0 + qb * 32 + r : 0) * p.o_row;
-#pragma unroll
-        for (int d = 0; d < 2; ++d) store_o_tile(orow + d * 32, oacc[qb][d], inv, hf, q_valid[qb], p.o_wide != 0);
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel_d64_bounded2(AttnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_fwd_body2(p, smem);
-}
+// (rounds 2-4 had a two-query-blocks-per-wave static-bound kernel here, attn_fwd_kernel_d64_bounded2 -- the joint attention
+// until the hand-placed one-wave-per-SIMD kernel of attn_w4.hip replaced it, then its BYA_ATTN_W4=0 A/B arm; retired in round 5
+// together with the one-block bounded instance: every bounded launch now runs attn_w4.hip.  git history has the code.)
 
 // (plain __global__ wrappers: hipcc's host pass did not emit the launch stub of the templated kernel once its body
 // used the buffer-resource builtins)
@@ -1010,21 +740,12 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel_d64_prescaled(AttnArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_fwd_body<64, true>(p, smem);
 }
-__global__ __launch_bounds__(256, BYA_ATTN_OCC) void attn_fwd_kernel_d64_bounded(AttnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_fwd_body<64, true, true>(p, smem);
-}
 __global__ __launch_bounds__(256) void attn_fwd_kernel_d128(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_fwd_body<128, false>(p, smem);
 }
 
-// BYA_ATTN_W4=0 (read per call: A/B runs) keeps the joint attention on the two-block kernel of this file
-inline bool use_w4() {
-    const char* e = getenv("BYA_ATTN_W4");
-    return !(e && e[0] == '0');
-}
-inline float static_bound_limit() { return use_w4() ? BYA_ATTN_BOUND_LIMIT : 48.f; }
+inline float static_bound_limit() { return BYA_ATTN_BOUND_LIMIT; }
 
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
@@ -1041,14 +762,8 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
         BYA_LAUNCH(attn_fwd_kernel_d64_prescaled, grid, dim3(256), lds, s, b);
         return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
     }
-    if (D == 64 && a.prescaled && a.score_bound > 0.f && use_w4()) return bya_launch_attn_w4(&a, s);
-    if (D == 64 && a.prescaled && a.score_bound > 0.f && BYA_ATTN_QB2) {
-        AttnArgs b = a;
-        b.nqt = (a.Sq + 255) / 256;                  // 256 query rows per workgroup
-        dim3 grid2((nbh * b.nqt + 7) / 8 * 8);
-        BYA_LAUNCH(attn_fwd_kernel_d64_bounded2, grid2, dim3(256), (size_t)(BYA_ATTN_QB2_RING3 ? 2 * BYA_ATTN_QB2_RING3 : 4) * KV_TILE * D * 2, s, b);
-    } else if (D == 64 && a.prescaled && a.score_bound > 0.f) BYA_LAUNCH(attn_fwd_kernel_d64_bounded, grid, dim3(256), lds, s, a);
-    else if (D == 64 && a.prescaled) BYA_LAUNCH(attn_fwd_kernel_d64_prescaled, grid, dim3(256), lds, s, a);
+    if (D == 64 && a.prescaled && a.score_bound > 0.f) return bya_launch_attn_w4(&a, s);
+    if (D == 64 && a.prescaled) BYA_LAUNCH(attn_fwd_kernel_d64_prescaled, grid, dim3(256), lds, s, a);
     else if (D == 64) BYA_LAUNCH(attn_fwd_kernel_d64, grid, dim3(256), lds, s, a);
     else BYA_LAUNCH(attn_fwd_kernel_d128, grid, dim3(256), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
@@ -1062,11 +777,11 @@ extern "C" int bya_attn_variant(const bya_attn_desc* d) {
     if (d->head_dim == 128) return d->scores_prescaled ? BYA_ERR_UNSUPPORTED : BYA_ATTN_D128;
     if (d->head_dim != 64) return BYA_ERR_UNSUPPORTED;
     if (!d->scores_prescaled) return BYA_ATTN_D64_RUNNING_MAX;
-    if (d->bound_dev && d->fallback_flags && use_w4()) return BYA_ATTN_D64_DEVICE_BOUND_W4;
-    // a usable static bound keeps every P and every row sum a normal number: |s| <= 90 where P = exp2(s) (the hand-placed
-    // kernel), |s| <= 48 where P = exp2(s - bound) (the two-block kernel); otherwise the running-maximum kernel runs
+    if (d->bound_dev && d->fallback_flags) return BYA_ATTN_D64_DEVICE_BOUND_W4;
+    // a usable static bound keeps every P = exp2(s) and every row sum a normal number: |s| <= 90; otherwise the
+    // running-maximum kernel runs
     if (!(d->score_bound > 0.f && d->score_bound <= static_bound_limit())) return BYA_ATTN_D64_PRESCALED;
-    return use_w4() ? BYA_ATTN_D64_STATIC_BOUND_W4 : BYA_ATTN_D64_STATIC_BOUND;
+    return BYA_ATTN_D64_STATIC_BOUND_W4;
 }
 
 extern "C" int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya_attn_desc* d,
@@ -1094,7 +809,7 @@ extern "C" int bya_attn_fwd(const void* q, const void* k, const void* v, void* o
     a.score_bound = (a.prescaled && d->score_bound > 0.f && d->score_bound <= static_bound_limit()) ? d->score_bound : 0.f;
     a.bound_dev = nullptr; a.bound_slots = 0; a.bound_heads = 0; a.bound_bh0 = 0; a.bound_limit = BYA_ATTN_BOUND_LIMIT;
     a.fallback = nullptr; a.only_flagged = nullptr;
-    if (d->bound_dev && a.prescaled && use_w4()) {
+    if (d->bound_dev && a.prescaled) {
         if (!d->fallback_flags || d->bound_slots < 1 || d->bound_slots > 64 || d->bound_bh0 < 0 ||
             d->bound_bh0 + d->nb1 * d->nb2 * d->heads > d->bound_heads) return BYA_ERR_SHAPE;
         if (((uintptr_t)d->bound_dev | (uintptr_t)d->fallback_flags) & 3) return BYA_ERR_ALIGN;

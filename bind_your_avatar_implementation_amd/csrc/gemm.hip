@@ -577,7 +577,10 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
         const int m0 = main_tm * 256;
         if (m0 > 0 && m0 < a.M) {
             const long long tail_blocks = (long long)((a.M - m0 + 127) / 128) * ((a.N + 127) / 128);
-            const double tail_cost = 0.6 * (double)((tail_blocks + 511) / 512);      // in pipelined-kernel rounds
+            // in pipelined-kernel rounds.  0.9 since round 5 (0.6 before): same-process sweeps (profiles/r5_d_gemm_sweep_*.json)
+            // have the unsplit persistent kernel ahead of the row split wherever 0.6 chose it -- 2222 x 9216 x 3072: 1078 vs 960
+            // TFLOP/s, 4444 x 9216: 1334 vs 1217, 17776 x 3072 x 3072: 1248 vs 1230 -- so the split now needs a clear win
+            const double tail_cost = 0.9 * (double)((tail_blocks + 511) / 512);
             const double main_cost = (double)(((long long)main_tm * tn + 255) / 256);
             if (main_cost + tail_cost < (double)((tiles + 255) / 256) - 0.15) {
                 GemmArgs lo = a, hi = a;

@@ -79,7 +79,6 @@ __device__ __forceinline__ void dma_piece(uint32_t lds_base, uint32_t voff, cons
 struct TileCoord { int z, m0, n0; bool valid; int k0, nkk, role, parts, slab, slab_step, ctr; };
 // K-tiles per K-range below which a split does not pay (the slab exchange costs ~20 us: measured break-even ~30 K-tiles)
 constexpr int DEFAULT_MIN_SPLIT_KTILES = 40;
-constexpr int MAX_SPLIT_PARTS = 4;                 // K-ranges per tile: the finisher adds at most three slabs (straight-line code)
 
 // Wide epilogue of one wave.  The lane (fr = lane & 15, fq = lane >> 4) holds, for row block j and accumulator register e,
 // the EIGHT consecutive columns  n8 = n_wave + (4 e + fq) * 8 + i,  i = 0..7  in acc[i][j][e]  (W rows are staged in the
@@ -225,7 +224,6 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
     if (split && R > 0) {
         parts = slots / R;
         if (parts > nk / min_seg) parts = nk / min_seg;
-        if (parts > MAX_SPLIT_PARTS) parts = MAX_SPLIT_PARTS;
         if (parts < 1) parts = 1;
     }
     auto coord = [&](int seq) {
@@ -949,57 +947,56 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
-            // add the slabs into the accumulators (back into the AGPRs: the epilogue below is the ordinary one).  A slab read is an
-            // agent-scope (sc1) load, a memory round trip past the L2s -- other workgroups, maybe on another XCD, wrote it -- so
-            // what counts is how much of it is in flight at once.  Round 4 read it through registers, 8 KiB per wave at a time:
-            // eight exposed round trips per slab, ~24 us per finisher, which is why only K = 12288 ever split.  Now it travels
-            // by LDS-DMA: a finisher is the LAST unit of its workgroup, so the 128-KiB ring is free (the drain's prefetch of the
-            // "next tile" -- empty descriptors, zeros -- has landed: the vmcnt(0) + barrier above); a wave moves its quarter of the
-            // slab (64 KiB, slab order = (wave, row block, register, half): nobody else's) through its quarter of the ring in
-            // two halves of 32 one-KiB pieces, ALL in flight together and in no register, then adds them from LDS.
+            // add the slabs into the accumulators (back into the AGPRs: the epilogue below is the ordinary one).  (row block,
+            // slab) pairs in order, the loads of pair it + 1 in flight while pair it is summed: a slab read is an
+            // agent-scope (sc1) load, a memory round trip past the L2s -- other workgroups, maybe on another XCD, wrote it.
+            // (r5, measured and NOT adopted: more of the slab in flight.  Two 64-register buffers, two 32-register buffers,
+            // a straight-line one-slab form: every variant made hipcc spill 0.3-1 KB per lane around the asm-owned
+            // accumulators; the slab by LDS-DMA through the ring -- no registers at all -- built with 700 B of scratch, ran
+            // 13-30 % SLOWER on every split shape and failed the split-K parity test.  profiles/r5_d_gemm_finisher_*.json)
             {
+                const float* const part0 = p.ws_slabs + (size_t)cur.slab * (GEMM_WS_SLAB_BYTES / 4);
                 const int nparts = cur.parts - 1, part_step = cur.slab_step;
-                const uint32_t lds_w = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 32768u);
-                const uint32_t rd = lds0 + (uint32_t)wave * 32768u + (uint32_t)lane * 16u;
-                const uint32_t vlane = (uint32_t)lane * 16u;
-                // (straight-line per slab: with the accumulators modified inside a RUNTIME loop hipcc carries all 256 of them
-                // around the back edge through scratch; a tile is cut into at most MAX_SPLIT_PARTS K-ranges)
-                auto add_slab = [&](int s2) {
-                    const i32x4 rsP = raw_rsrc(p.ws_slabs + (size_t)(cur.slab + s2 * part_step) * (GEMM_WS_SLAB_BYTES / 4), (uint32_t)GEMM_WS_SLAB_BYTES);
+                u32x4 pf[4][2];
+                auto issue = [&](int it) {
+                    const int jn = it / nparts, s2 = it - jn * nparts;
+                    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(part0 + (size_t)s2 * part_step * (GEMM_WS_SLAB_BYTES / 4)), 0, (int)GEMM_WS_SLAB_BYTES, 0x00020000);
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads of the previous half are done with the ring
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int u = 0; u < 32; ++u)
-                            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds"
-                                         :
-                                         : "s"(lds_w + (uint32_t)u * 1024u), "v"(vlane), "s"(rsP), "s"((uint32_t)((wave * 64 + hh * 32 + u) * 1024))
-                                         : "memory");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                        for (int jl = 0; jl < 4; ++jl) {
-                            const int jn = hh * 4 + jl;
-                            f32x4 c[4][2];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                                for (int hlf = 0; hlf < 2; ++hlf)
-                                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c[e][hlf]) : "v"(rd), "i"(((jl * 4 + e) * 2 + hlf) * 1024));
-                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[1][0]), "+v"(c[1][1]),
-                                                                      "+v"(c[2][0]), "+v"(c[2][1]), "+v"(c[3][0]), "+v"(c[3][1]));
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                f32x4 t = acc[i][jn];
-                                t[0] += c[0][i >> 2][i & 3]; t[1] += c[1][i >> 2][i & 3]; t[2] += c[2][i >> 2][i & 3]; t[3] += c[3][i >> 2][i & 3];
-                                asm volatile("" : "+a"(t));          // back into accumulator registers, 4 at a time
-                                acc[i][jn] = t;
-                            }
-                        }
-                    }
+                        for (int hlf = 0; hlf < 2; ++hlf)
+                            pf[e][hlf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                rsP, (uint32_t)(((wave * 64 + (jn * 4 + e) * 2 + hlf) * 64 + lane) * 16), 0, 16 /* sc1 */));
                 };
-                add_slab(0);
-                if (nparts > 1) add_slab(1);
-                if (nparts > 2) add_slab(2);
+                issue(0);
+#pragma unroll
+                for (int jn = 0; jn < 8; ++jn) {
+                    float ps[4][8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) ps[e][i] = 0.f;
+                    for (int s2 = 0; s2 < nparts; ++s2) {
+                        f32x4 c[4][2];
+                        // whole-vector casts: bit_cast of ONE element of an ext_vector miscompiles (hipcc 7.2 returns element 0)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { c[e][0] = __builtin_bit_cast(f32x4, pf[e][0]); c[e][1] = __builtin_bit_cast(f32x4, pf[e][1]); }
+                        const int it = jn * nparts + s2 + 1;
+                        if (it < 8 * nparts) issue(it);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) ps[e][i] += c[e][i >> 2][i & 3];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        f32x4 t = acc[i][jn];
+                        t[0] += ps[0][i]; t[1] += ps[1][i]; t[2] += ps[2][i]; t[3] += ps[3][i];
+                        asm volatile("" : "+a"(t));          // back into accumulator registers, 4 at a time
+                        acc[i][jn] = t;
+                    }
+                }
             }
             auto run = [&](auto act_tag) {
                 epilogue_wide<decltype(act_tag)::value, 2, SPLIT, CONV>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc, wave, lane);

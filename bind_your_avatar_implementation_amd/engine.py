@@ -91,6 +91,11 @@ class DenoiseEngine:
         # pack time, per-row activation scales on the fly; fp32 accumulation, bf16 everywhere else)
         self.fp8_weights = bool(getattr(model, "_fp8_weights", False)) or os.environ.get("BYA_FP8_WEIGHTS") == "1"
         self.fuse_ln_quant = os.environ.get("BYA_FP8_FUSED_LN", "1") != "0"     # AdaLN LayerNorm writes e4m3 directly
+        # the remaining A/B switches of the step, read ONCE here (round 4 looked them up in os.environ on every step / call)
+        self.side_stream_conditioning = os.environ.get("BYA_INVARIANTS_SIDE_STREAM", "1") != "0"
+        self.sp_allgather = os.environ.get("BYA_SP_ALLGATHER", "0") == "1"       # exchange A as a K/V all-gather (A/B)
+        self.router_fused_attn = os.environ.get("BYA_ROUTER_FUSED_ATTN", "1") != "0"
+        self.router_replicated = os.environ.get("BYA_ROUTER_REPLICATED", "0") == "1"
         self._inv_cache = {}
         self._side = None              # side stream of the step-invariant conditioning
         self._ws_key, self._ws = None, None
@@ -543,7 +548,7 @@ class DenoiseEngine:
         # K/V launch, which is enqueued right behind face layer 0: at 8 ranks the conditioning -- replicated on every rank -- is
         # 7 ms of launches against a 1.9 ms DiT layer, and nothing needs face layer 20's keys before layer 40.)
         inv_side, face_marks, audio_mark = None, {}, [None]
-        if (use_face or use_audio) and ops._TIMERS is None and os.environ.get("BYA_INVARIANTS_SIDE_STREAM", "1") != "0":
+        if (use_face or use_audio) and ops._TIMERS is None and self.side_stream_conditioning:
             if self._side is None:
                 self._side = torch.cuda.Stream(self.dev)
             inv_side = ops.on_stream(self._side)
@@ -605,7 +610,7 @@ class DenoiseEngine:
         qkv = buf("qkv", 3, B, S_loc, D)
         q, k, v = qkv[0], qkv[1], qkv[2]
         ff = buf("ff", B, S_loc, 4 * D)
-        head_parallel = sh.active and H % sh.world == 0 and os.environ.get("BYA_SP_ALLGATHER", "0") != "1"
+        head_parallel = sh.active and H % sh.world == 0 and not self.sp_allgather
         if head_parallel:
             W = sh.world
             Dl = D // W
@@ -841,7 +846,7 @@ class DenoiseEngine:
         the group fits the two 16-row MFMA tiles of a wave (32 rows) and the folded weights exist, else LN -> q|k|v GEMM -> attn_tiny."""
         rg = pk.get("rg_" + name)
         hd = 64
-        if rg is not None and L <= 32 and heads == 8 and os.environ.get("BYA_ROUTER_FUSED_ATTN", "1") != "0":
+        if rg is not None and L <= 32 and heads == 8 and self.router_fused_attn:
             return ops.router_group_attn(x, rg[0], out, L, n_outer, n_inner, outer_stride, seq_stride, eps=rg[1],
                                          scale=hd ** -0.5)
         F = x.shape[1]
@@ -864,8 +869,7 @@ class DenoiseEngine:
         N, N_loc = T * per_frame, sh.N_loc
         F = r.feat_dim
         qk = qp.shape[-1]
-        if sh.active and n_id * T >= sh.world and per_frame >= sh.world and \
-                os.environ.get("BYA_ROUTER_REPLICATED", "0") != "1":
+        if sh.active and n_id * T >= sh.world and per_frame >= sh.world and not self.router_replicated:
             return self._router_sharded(qp, kr, ca, T, per_frame, n_id, sh, taps, overlap)
         overlap()
         qn = buf("r_qn", B, N_loc, qk)

@@ -101,7 +101,7 @@ class weight_streaming:
 
     def __enter__(self):
         global _WEIGHT_STREAMING
-        self._old, _WEIGHT_STREAMING = _WEIGHT_STREAMING, True
+        self._old, _WEIGHT_STREAMING = _WEIGHT_STREAMING, os.environ.get("BYA_GEMM_SKINNY") != "0"      # (read per block, not per GEMM)
         return self
 
     def __exit__(self, *exc):
@@ -300,7 +300,7 @@ def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, g
         name += f":{ab}x{M}x{N}x{K}:{act or 'none'}{'+gate' if gate0 is not None else ''}{'+res' if res is not None else ''}"
     tok = _begin(name, 2.0 * ab * M * N * K)
     if (_WEIGHT_STREAMING and M <= 64 and N <= 8192 and N % 16 == 0 and K % 32 == 0 and K >= 256 and gate0 is None
-            and bias_rowscale is None and split is None and a_bs % 8 == 0 and os.environ.get("BYA_GEMM_SKINNY") != "0"):
+            and bias_rowscale is None and split is None and a_bs % 8 == 0):
         check(lib.bya_gemm_skinny_bf16(_p(a), _p(w), _p(bias), _p(out), _p(res), ctypes.byref(d), _stream()),
               "bya_gemm_skinny_bf16")
     else:

@@ -214,7 +214,7 @@ int bya_attn_fwd(const void* q, const void* k, const void* v, void* o, const bya
  * (tests, bench.py) need to say which one they measured.  Negative = the descriptor is rejected. */
 #define BYA_ATTN_D64_RUNNING_MAX 0   /* online softmax, scores scaled in the kernel */
 #define BYA_ATTN_D64_PRESCALED 1     /* online softmax, scores already in exp2 units */
-#define BYA_ATTN_D64_STATIC_BOUND 2  /* no running maximum: P = exp2(s - bound), |s| <= score_bound <= 48 (two-block kernel) */
+#define BYA_ATTN_D64_STATIC_BOUND 2  /* (retired in round 5: the two-block static-bound kernel; never returned) */
 #define BYA_ATTN_D128 3
 #define BYA_ATTN_D64_STATIC_BOUND_W4 4  /* P = exp2(s), |s| <= score_bound <= 90, on the one-wave-per-SIMD hand-placed kernel (csrc/attn_w4.hip) */
 #define BYA_ATTN_D64_DEVICE_BOUND_W4 5  /* the same kernel under the data-dependent bound (bound_dev), per-head running-maximum fallback */

@@ -48,19 +48,9 @@ def test_python_binding_table_matches_header(lib_path):
     assert lib.bya_attn_fwd(None, None, None, None, ctypes.byref(a), None) == -1
     # the softmax-variant query mirrors bya_attn_fwd's kernel choice (host-side, launches nothing)
     a.head_dim, a.scores_prescaled, a.score_bound = 64, 1, 11.8
-    assert lib.bya_attn_variant(ctypes.byref(a)) == 4          # static bound on the one-wave-per-SIMD kernel (default)
-    os.environ["BYA_ATTN_W4"] = "0"
-    try:
-        assert lib.bya_attn_variant(ctypes.byref(a)) == 2      # ... on the two-block kernel
-    finally:
-        del os.environ["BYA_ATTN_W4"]
-    a.score_bound = 60.0                                        # P = exp2(s) without an offset: usable up to 90 on that kernel,
-    assert lib.bya_attn_variant(ctypes.byref(a)) == 4          # up to 48 on the two-block kernel (P = exp2(s - bound))
-    os.environ["BYA_ATTN_W4"] = "0"
-    try:
-        assert lib.bya_attn_variant(ctypes.byref(a)) == 1
-    finally:
-        del os.environ["BYA_ATTN_W4"]
+    assert lib.bya_attn_variant(ctypes.byref(a)) == 4          # static bound on the one-wave-per-SIMD kernel
+    a.score_bound = 60.0                                        # P = exp2(s) without an offset: usable up to 90
+    assert lib.bya_attn_variant(ctypes.byref(a)) == 4
     a.score_bound = 100.0
     assert lib.bya_attn_variant(ctypes.byref(a)) == 1
     dummy = (ctypes.c_float * 4)()

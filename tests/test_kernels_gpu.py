@@ -1068,16 +1068,14 @@ def test_act_add(ops, dev):
     check(out, bf(F.gelu(x.float())).float() + r.float(), what="gelu+res")
 
 
-@pytest.mark.parametrize("kernel", ["w4", "qb2"])
 @pytest.mark.parametrize("S", [40, 200, 1350, 4133])
-def test_attn_static_bound_softmax(ops, dev, S, kernel, monkeypatch):
+def test_attn_static_bound_softmax(ops, dev, S):
     """score_bound: q and k with ||q|| <= 8, ||k|| <= 8 * k_scale (what LayerNorm(64) + RoPE guarantee), so every score is
-    within +-11.6 in exp2 units and the kernel may replace the running maximum by that constant.  Must agree with the
-    fp32 softmax like the running-max kernel does, including rows whose scores sit far below the bound.  Both static-bound
-    kernels: "w4" = the hand-placed one-wave-per-SIMD kernel (csrc/attn_w4.hip, 512 query rows per workgroup, the default),
-    "qb2" = the two-block kernel (BYA_ATTN_W4=0).  Sizes: fewer keys than one tile (40: the padded keys of the only tile
-    are subtracted from the row sums), ragged tails (200 = 3 x 64 + 8, 4133), fewer rows than a workgroup holds."""
-    monkeypatch.setenv("BYA_ATTN_W4", "1" if kernel == "w4" else "0")
+    within +-11.6 in exp2 units and the kernel may drop the running maximum (P = exp2(s)).  Must agree with the fp32 softmax
+    like the running-max kernel does, including rows whose scores sit far below the bound.  The hand-placed
+    one-wave-per-SIMD kernel (csrc/attn_w4.hip, 512 query rows per workgroup) is the only static-bound kernel since round 5.
+    Sizes: fewer keys than one tile (40: the padded keys of the only tile are subtracted from the row sums), ragged tails
+    (200 = 3 x 64 + 8, 4133), fewer rows than a workgroup holds."""
     H, D = 4, 64
     g = torch.Generator().manual_seed(S)
     def unit_rows(scale_rows):

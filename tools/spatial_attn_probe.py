@@ -47,7 +47,6 @@ for name, env, kw in [("running_max (today)", {}, {}),
                       ("prescaled running_max, 8-byte epilogue stores", {"BYA_ATTN_WIDE_STORE": "0"}, dict(prescaled=True)),
                       ("prescaled running_max (again)", {}, dict(prescaled=True)),
                       ("prescaled running_max, 8-byte epilogue stores (again)", {"BYA_ATTN_WIDE_STORE": "0"}, dict(prescaled=True)),
-                      ("static bound, two-block", {"BYA_ATTN_W4": "0"}, dict(prescaled=True, score_bound=20.0)),
                       ("static bound, w4 per item", {"BYA_ATTN_STREAMK": "0"}, dict(prescaled=True, score_bound=20.0)),
                       ("static bound, w4 stream-K", {}, dict(prescaled=True, score_bound=20.0))]:
     for k_, v_ in env.items():
