@@ -511,13 +511,14 @@ def main():
             finally:
                 model.enable_fp8_weights(False)
         if world == 1 and headline and not args.no_qk_gain_variant:
-            # Beside the headline, never in it: the same step with every q/k-LayerNorm gain multiplied by 3 (a stand-in for a
-            # trained checkpoint's learned gains, reference models/transformer.py:200-209): the worst-case score bound of every
-            # layer is then 106 > 90, so each q/k-norm launch records the norms of its rows and the joint attention takes its
-            # bound from device memory (static kernel + per-head running-maximum fallback) -- round 4 lost 9 % of the attention
-            # time to the running-maximum kernel at that point
+            # Beside the headline, never in it: the same step with every q/k-LayerNorm gain doubled (a stand-in for a trained
+            # checkpoint's learned gains, reference models/transformer.py:200-209; the synthetic gains are N(1, 0.1)): the
+            # worst-case score bound of a layer goes from ~20 to ~78.  Round 4's limit of 48 sent such a checkpoint to the
+            # running-maximum kernel (-9 % on 36 % of the step) without saying so; the hand-placed kernel computes P = exp2(s)
+            # with no offset, so it is safe to 90.  Above that (non-uniform gains: tests/test_forward_gpu.py) the bound comes
+            # from the data, per head.
             try:
-                scale_qk_gains(3.0)
+                scale_qk_gains(2.0)
                 ops.ATTN_VARIANTS.clear()
                 step()
                 torch.cuda.synchronize()
@@ -527,7 +528,7 @@ def main():
                 torch.cuda.synchronize()
                 sec3 = (time.perf_counter() - t1) / 3
                 res["large_qk_gain_variant"] = {
-                    "value": 1.0 / sec3, "unit": "steps/s", "ms_per_step": sec3 * 1e3, "steps": 3, "qk_gain": 3.0,
+                    "value": 1.0 / sec3, "unit": "steps/s", "ms_per_step": sec3 * 1e3, "steps": 3, "qk_gain": 2.0,
                     "worst_case_score_bound": max(model._engine.score_bound),
                     "attention_variants": {f"{tag}:{var}": n for (tag, var), n in sorted(ops.ATTN_VARIANTS.items()) if tag == "joint"},
                     "heads_on_the_running_maximum_kernel_last_layer": int(model._engine._ws["qk_flags"][:48].sum().item())
@@ -537,7 +538,7 @@ def main():
             except Exception as e:                        # noqa: BLE001  (an extra, never a reason to lose the headline line)
                 res["large_qk_gain_variant"] = {"error": str(e)[:200]}
             finally:
-                scale_qk_gains(1.0 / 3.0)
+                scale_qk_gains(0.5)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1, config0=args.cpu_baseline_config0)
             ref0 = committed_config0_baseline()

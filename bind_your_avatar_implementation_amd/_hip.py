@@ -22,6 +22,11 @@ class GemmDesc(_c.Structure):
                 ("n_split", _i32), ("c_split_stride", _i64), ("bias_rowscale", _vp), ("alpha", _f32)]
 
 
+class QkNormDesc(_c.Structure):
+    _fields_ = [("qw", _vp), ("qb", _vp), ("kw", _vp), ("kb", _vp), ("cos", _vp), ("sin", _vp),
+                ("text_rows", _i32), ("width", _i32), ("eps", _f32), ("k_scale", _f32)]
+
+
 class AttnDesc(_c.Structure):
     _fields_ = [("head_dim", _i32), ("heads", _i32), ("nb1", _i32), ("nb2", _i32), ("Sq", _i32), ("Skv", _i32),
                 ("q_s1", _i64), ("q_s2", _i64), ("q_row", _i64),
@@ -48,6 +53,7 @@ SIGNATURES = {
     "bya_abi_version": [],
     "bya_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
     "bya_gemm_skinny_bf16": [_vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
+    "bya_gemm_qkv_norm_rope": [_vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _c.POINTER(QkNormDesc), _vp],
     "bya_set_gemm_workspace": [_vp, _i64],
     "bya_gemm_workspace_bytes": [_c.POINTER(_i64)],
     "bya_gemm_workspace_status": [_c.POINTER(_i32), _vp],

@@ -428,6 +428,36 @@ extern "C" int bya_gemm_bf16(const void* A, const void* W, const void* bias, voi
     });
 }
 
+// The packed q|k|v projection with the q/k LayerNorm(64) + RoPE (+ the k pre-scale) in its epilogue: one launch, q and k
+// written once (include/bya.h).  Only the persistent one-wave-per-SIMD kernel has that epilogue: anything it does not take
+// is BYA_ERR_UNSUPPORTED and the caller keeps bya_gemm_bf16 + bya_qknorm_rope.
+extern "C" int bya_gemm_qkv_norm_rope(const void* A, const void* W, const void* bias, void* C, const bya_gemm_desc* d,
+                                      const bya_qknorm_desc* n, hipStream_t stream) {
+    if (!A || !W || !C || !d || !n) return BYA_ERR_SHAPE;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->K % BK != 0) return BYA_ERR_SHAPE;
+    if (!n->qw || !n->qb || !n->kw || !n->kb || n->width <= 0 || n->text_rows < 0) return BYA_ERR_SHAPE;
+    if (n->text_rows < d->M && (!n->cos || !n->sin)) return BYA_ERR_SHAPE;
+    if (d->N != 3 * n->width || n->width % 128 != 0 || d->n_split <= 0 || d->act != 0 || d->bias_rowscale || (d->alpha != 0.0f && d->alpha != 1.0f))
+        return BYA_ERR_UNSUPPORTED;
+    if (d->lda % 8 || d->ldw % 8) return BYA_ERR_ALIGN;
+    if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)n->qw | (uintptr_t)n->qb | (uintptr_t)n->kw |
+         (uintptr_t)n->kb | (uintptr_t)n->cos | (uintptr_t)n->sin) & 15) return BYA_ERR_ALIGN;
+    GemmArgs a;
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.C = (bf16_t*)C;
+    a.res = nullptr; a.gate0 = nullptr; a.gate1 = nullptr;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = 0;
+    a.a_bs = d->a_batch_stride; a.c_bs = d->c_batch_stride; a.res_bs = 0; a.gate_bs = 0; a.gate_split = 0; a.act = 0; a.leaky = 0.01f;
+    a.n_split = d->n_split; a.c_split_stride = d->c_split_stride;
+    a.bias_rowscale = nullptr; a.alpha = 1.0f;
+    a.ws_counters = nullptr; a.ws_slabs = nullptr;                 // (the QKN instance never splits a tile)
+    a.qkn_w[0] = (const bf16_t*)n->qw; a.qkn_b[0] = (const bf16_t*)n->qb; a.qkn_w[1] = (const bf16_t*)n->kw; a.qkn_b[1] = (const bf16_t*)n->kb;
+    a.qkn_cos = n->cos; a.qkn_sin = n->sin; a.qkn_text_rows = n->text_rows; a.qkn_width = n->width;
+    a.qkn_eps = n->eps; a.qkn_kscale = n->k_scale == 0.0f ? 1.0f : n->k_scale;
+    if (!v4_eligible(a) || !gemm_rows_reachable(a, a.M)) return BYA_ERR_UNSUPPORTED;
+    return bya_launch_gemm256p_qkn(&a, d->batch, stream);
+}
+
 namespace {
 // ------------------------------------------------------------------------------------------------------------------
 // Skinny Linears (bya_gemm_skinny_bf16): at most 64 rows (batch elements stacked when they fit) against a weight of up to 8192

@@ -26,6 +26,14 @@ struct GemmArgs {
     // zero-padded channels-last input [To + 2, Hp, Wp, C] seen as a matrix of pixels x C (lda = C), row m of the product is
     // the padded pixel m of the OUTPUT grid [To, Hp, Wp] (rows with h >= H or w >= W are computed and dropped), K-tile t is
     // the 64-channel group t % cpg of tap t / cpg = (dt, dh, dw): the same rows, ((dt Hp + dh) Wp + dw) pixels further on.
+    // q/k LayerNorm(64) + RoPE in the packed q|k|v projection's epilogue (bya_gemm_qkv_norm_rope; gemm_v4.hip, QKN instance):
+    // columns [0, qkn_width) are q, [qkn_width, 2 qkn_width) k, the rest v (untouched); per 64-column head row the arithmetic
+    // of qknorm_math.h on the bf16-ROUNDED projection (what the two-launch path reads back), rows >= qkn_text_rows rotated
+    const bf16_t* qkn_w[2] = {nullptr, nullptr};
+    const bf16_t* qkn_b[2] = {nullptr, nullptr};
+    const float* qkn_cos = nullptr; const float* qkn_sin = nullptr;
+    int qkn_text_rows = 0, qkn_width = 0;
+    float qkn_eps = 0.f, qkn_kscale = 1.f;
     int conv_cpg_log2 = -1;            // log2(C / 64); < 0: plain GEMM
     int conv_Hp = 0, conv_Wp = 0, conv_H = 0, conv_W = 0, conv_To = 0;
     long long conv_a_bytes = 0;        // bytes of the padded input from A on (reads past it return zeros)
@@ -219,4 +227,5 @@ int gemm_row_chunks(const GemmArgs& a, int batch, int a_elem_bytes, F&& run) {
 // defined in gemm_v4.hip (compiled with its own register-allocation flags: accumulators in AGPRs), called from
 // bya_gemm_bf16: persistent one-wave-per-SIMD kernel with cross-tile prefetch and 16-byte epilogue accesses
 int bya_launch_gemm256p(const void* args, int batch, hipStream_t stream);
+int bya_launch_gemm256p_qkn(const void* args, int batch, hipStream_t stream);    // ... its QKN instance (bya_gemm_qkv_norm_rope)
 int bya_gemm_split_min_ktiles();     // K-tiles per K-range below which the persistent kernel does not split a tile

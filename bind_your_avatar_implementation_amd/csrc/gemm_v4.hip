@@ -35,6 +35,7 @@
 // drain tile of gemm_v3 computed wrong sums); (2) it pads no MFMA -> accvgpr_read hazard, so the epilogue starts behind
 // explicit s_nops.  This translation unit is compiled WITHOUT -amdgpu-mfma-vgpr-form (accumulators in AGPRs).
 #include "gemm_common.h"
+#include "qknorm_math.h"
 
 #ifndef BYA_GEMM_ABLATE
 #define BYA_GEMM_ABLATE 0
@@ -191,13 +192,104 @@ __device__ __forceinline__ void epilogue_wide(const GemmArgs& p, int z, int m_wa
     }
 }
 
+// The packed q|k|v projection's epilogue with the per-head q/k LayerNorm(64) + RoPE inside (QKN instance; reference
+// models/transformer.py:204-208 = diffusers CogVideoXAttnProcessor2_0: norm_q / norm_k, apply_rotary_emb on the video rows).
+// Round 4 wrote q, k and launched bya_qknorm_rope on them: 473 MB of traffic per layer against 218 MB if q and k are written
+// once.  In the wide epilogue's layout a lane (fr, fq) holds, for row block j, the eight consecutive columns
+// n_wave + (4 e + fq) * 8 + i: the wave's 128 columns are two heads, head hh = registers e = 2 hh, 2 hh + 1, and a head row is
+// spread over the FOUR lanes fq = 0 .. 3 of one fr -- group g = 4 (e & 1) + fq of qknorm_math.h's eight.  The tree (g ^ 1),
+// (g ^ 2), (g ^ 4) is therefore lane ^ 16, lane ^ 32, then the lane's own two registers: same operands, same order, same bits
+// as the stand-alone kernel.  The projection is rounded to bf16 first (the value the two-launch path stored and read back).
+// v tiles (n_wave >= 2 width) take the plain bias epilogue.
+__device__ __forceinline__ void epilogue_qkn(const GemmArgs& p, int z, int m_wave, int n_wave, int fr, int fq, const f32x4 (&acc)[8][8]) {
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (long long)z * p.c_bs), 0, 0x7fffffff, 0x00020000);
+    const int tsel = n_wave / p.qkn_width;                       // 0 = q, 1 = k, 2 = v (a tile never straddles: width % 128 == 0)
+    const bool has_bias = p.bias != nullptr;
+    u32x4 bv[4];
+    uint32_t colb[4];
+    bool nok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n8 = n_wave + (4 * e + fq) * 8;
+        nok[e] = n8 < p.N;
+        const uint32_t ncb = nok[e] ? (uint32_t)n8 * 2u : 0u;
+        colb[e] = ((uint32_t)(n8 / p.n_split) * (uint32_t)p.c_split_stride + (uint32_t)(n8 % p.n_split)) * 2u;
+        bv[e] = has_bias ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.bias) + ncb) : u32x4{0u, 0u, 0u, 0u};
+    }
+    // LayerNorm parameters of this lane's columns: e and e + 2 sit at the same place of their heads
+    float wv[2][8], bb[2][8];
+    const int tn = tsel < 2 ? tsel : 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int hc = (4 * e + fq) * 8;
+        unpack8(*reinterpret_cast<const u32x4*>(p.qkn_w[tn] + hc), wv[e]);
+        unpack8(*reinterpret_cast<const u32x4*>(p.qkn_b[tn] + hc), bb[e]);
+    }
+    const float ks = tsel == 1 ? p.qkn_kscale : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = m_wave + 16 * j + fr;
+        const bool mok = m < p.M;
+        const uint32_t coff = (mok ? (uint32_t)m : 0u) * (uint32_t)(p.ldc * 2);
+        const bool rope = tsel < 2 && m >= p.qkn_text_rows && mok;
+        float cc[2][8] = {}, ss[2][8] = {};
+        if (rope) {
+            const long long t0 = (long long)(m - p.qkn_text_rows) * 64;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int hc = (4 * e + fq) * 8;
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.qkn_cos + t0 + hc), c1 = *reinterpret_cast<const f32x4*>(p.qkn_cos + t0 + hc + 4);
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.qkn_sin + t0 + hc), s1 = *reinterpret_cast<const f32x4*>(p.qkn_sin + t0 + hc + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { cc[e][i] = c0[i]; cc[e][4 + i] = c1[i]; ss[e][i] = s0[i]; ss[e][4 + i] = s1[i]; }
+            }
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float v[2][8];
+#pragma unroll
+            for (int el = 0; el < 2; ++el) {
+                const int e = 2 * hh + el;
+                float b8[8];
+                unpack8(bv[e], b8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[el][i] = acc[i][j][e] + b8[i];
+            }
+            if (tsel < 2) {
+                // the projection as the two-launch path stored it: one rounding to bf16
+#pragma unroll
+                for (int el = 0; el < 2; ++el) {
+                    const u32x4 r = pack8(v[el]);
+                    unpack8(r, v[el]);
+                }
+                float s0 = qkn_sum8(v[0]), s1 = qkn_sum8(v[1]);
+                s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64);
+                s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+                const float mean = (s0 + s1) * (1.0f / 64);
+                float q0 = qkn_centre_sq8(v[0], mean), q1 = qkn_centre_sq8(v[1], mean);
+                q0 += __shfl_xor(q0, 16, 64); q1 += __shfl_xor(q1, 16, 64);
+                q0 += __shfl_xor(q0, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+                const float rstd = rsqrtf((q0 + q1) * (1.0f / 64) + p.qkn_eps);
+                qkn_finish8(v[0], rstd, wv[0], bb[0], rope, cc[0], ss[0], ks);
+                qkn_finish8(v[1], rstd, wv[1], bb[1], rope, cc[1], ss[1], ks);
+            }
+#pragma unroll
+            for (int el = 0; el < 2; ++el) {
+                const int e = 2 * hh + el;
+                __builtin_amdgcn_raw_buffer_store_b128(pack8(v[el]), rsC, (mok && nok[e]) ? coff + colb[e] : 0xffffffffu, 0, 0);
+            }
+        }
+    }
+}
+
 // SPLIT = false: the instance for launches that will not split a tile (no workspace, short K, or nothing left over): its
 // epilogue has no slab branch -- that branch alone costs the ordinary path 1.5-2.5 % on K = 3072 shapes (same-box A/B,
 // profiles/r2_gemm_epilogue_variants_same_box.txt) because it cuts the unrolled epilogue into blocks.
-template <bool SPLIT, bool CONV = false>
+template <bool SPLIT, bool CONV = false, bool QKN = false>
 __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_m, int tiles_n, int batch, int split_arg,
                                                           int min_seg, unsigned epoch) {
     static_assert(!(SPLIT && CONV), "the convolution instance does not split K");
+    static_assert(!(QKN && (SPLIT || CONV)), "the q/k-norm instance is a plain, unsplit GEMM");
     const int split = SPLIT ? split_arg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 256, BN = 256, STAGE = (BM + BN) * BK * 2, TILE_A = BM * BK * 2;
@@ -1008,11 +1100,15 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         } else {
             // ---- whole tile (ordinary epilogue), or (role 1) a split tile's partial sums -> slab, then drained and counted
             float* const raw_out = (SPLIT && cur.role == 1) ? p.ws_slabs + (size_t)cur.slab * (GEMM_WS_SLAB_BYTES / 4) : nullptr;
-            auto run = [&](auto act_tag) {
-                epilogue_wide<decltype(act_tag)::value, 2, SPLIT, CONV>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc,
-                                                                        wave, lane, raw_out);
-            };
-            dispatch_act_big(p.act, run);
+            if constexpr (QKN) {
+                epilogue_qkn(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc);
+            } else {
+                auto run = [&](auto act_tag) {
+                    epilogue_wide<decltype(act_tag)::value, 2, SPLIT, CONV>(p, cur.z, cur.m0 + wm * 128, cur.n0 + wn * 128, fr, fq, acc,
+                                                                            wave, lane, raw_out);
+                };
+                dispatch_act_big(p.act, run);
+            }
             if (SPLIT && cur.role == 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");
@@ -1064,6 +1160,19 @@ int bya_launch_conv256p(const void* args, hipStream_t s) {
     static std::atomic<unsigned long long> attr_done{0};
     if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256p_kernel<false, true>), (int)lds, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
     BYA_LAUNCH((gemm256p_kernel<false, true>), dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, 1, 0, 1 << 30, 0u);
+    return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
+}
+
+// q|k|v projection with the q/k-norm + RoPE epilogue (bya_gemm_qkv_norm_rope): the QKN instance, never split
+int bya_launch_gemm256p_qkn(const void* args, int batch, hipStream_t s) {
+    const GemmArgs& a = *static_cast<const GemmArgs*>(args);
+    const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+    const long long total = (long long)tiles_m * tiles_n * batch;
+    const int blocks = (int)(total < 256 ? (total + 7) / 8 * 8 : 256);
+    const size_t lds = 2 * 512 * BK * 2;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (bya_allow_big_lds(reinterpret_cast<const void*>(gemm256p_kernel<false, false, true>), (int)lds, attr_done) != BYA_OK) return BYA_ERR_LAUNCH;
+    BYA_LAUNCH((gemm256p_kernel<false, false, true>), dim3(blocks), dim3(256), lds, s, a, tiles_m, tiles_n, batch, 0, 1 << 30, 0u);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 

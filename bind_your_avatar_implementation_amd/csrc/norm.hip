@@ -7,6 +7,7 @@
 // norm_q/norm_k (:380,:382), SpatialTemporalAttentionBlock.norm1-4 (:475-491), AudioAwareModel norm_q
 // (models/audio_model.py:249), diffusers Attention.norm_q/norm_k + apply_rotary_emb (transformer.py:204-208).
 #include "bya_common.h"
+#include "qknorm_math.h"
 #include "../../include/bya.h"
 #include <stdlib.h>
 
@@ -281,43 +282,29 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(QkArgs p) {
     const bf16_t* w = (which ? p.kw : p.qw) + d0;
     const bf16_t* b = (which ? p.kb : p.qb) + d0;
 
+    // (arithmetic in qknorm_math.h, shared with the QKV GEMM's fused epilogue: the two agree bit for bit)
     float v[8];
     unpack8(*reinterpret_cast<const u32x4*>(base), v);
-    float sum = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sum += v[e];
+    float sum = qkn_sum8(v);
     sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
     const float mean = sum * (1.0f / 64);
-    float sq = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { v[e] -= mean; sq += v[e] * v[e]; }
+    float sq = qkn_centre_sq8(v, mean);
     sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
     const float rstd = rsqrtf(sq * (1.0f / 64) + p.eps);
     float wv[8], bv[8];
     unpack8(*reinterpret_cast<const u32x4*>(w), wv);
     unpack8(*reinterpret_cast<const u32x4*>(b), bv);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * rstd * wv[e] + bv[e];
-    if (s >= p.text_rows) {
+    float cc[8] = {}, ss[8] = {};
+    const bool rope = s >= p.text_rows;
+    if (rope) {
         const float* c = p.cos + (long long)(s - p.text_rows) * 64 + d0;
         const float* sn = p.sin + (long long)(s - p.text_rows) * 64 + d0;
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sn), s1 = *reinterpret_cast<const f32x4*>(sn + 4);
-        const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-        float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {   // pair (2i, 2i+1): rot = (-x[2i+1], x[2i])
-            o[e] = v[e] * cc[e] - v[e + 1] * ss[e];
-            o[e + 1] = v[e + 1] * cc[e + 1] + v[e] * ss[e + 1];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = o[e];
+        for (int e = 0; e < 4; ++e) { cc[e] = c0[e]; cc[4 + e] = c1[e]; ss[e] = s0[e]; ss[4 + e] = s1[e]; }
     }
-    if (which && p.k_scale != 1.0f) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.k_scale;
-    }
+    qkn_finish8(v, rstd, wv, bv, rope, cc, ss, which ? p.k_scale : 1.0f);
     const u32x4 out = pack8(v);
     *reinterpret_cast<u32x4*>(base) = out;
     if constexpr (STATS) {

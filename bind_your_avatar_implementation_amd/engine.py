@@ -96,6 +96,8 @@ class DenoiseEngine:
         self.sp_allgather = os.environ.get("BYA_SP_ALLGATHER", "0") == "1"       # exchange A as a K/V all-gather (A/B)
         self.router_fused_attn = os.environ.get("BYA_ROUTER_FUSED_ATTN", "1") != "0"
         self.router_replicated = os.environ.get("BYA_ROUTER_REPLICATED", "0") == "1"
+        # q/k-norm + RoPE inside the q|k|v projection's epilogue (bya_gemm_qkv_norm_rope; bit-identical to the two launches)
+        self.qkn_epilogue = os.environ.get("BYA_QKN_EPILOGUE", "1") != "0"
         self._inv_cache = {}
         self._side = None              # side stream of the step-invariant conditioning
         self._ws_key, self._ws = None, None
@@ -272,6 +274,19 @@ class DenoiseEngine:
             self._ws["qk_flags"] = torch.zeros(max(n_bh, 64), dtype=torch.int32, device=self.dev)
         st.zero_()
         return 0.0, st
+
+    def _qkv_norm_rope(self, i, at, xn, out, split, xq, cos, sin, text_rows, heads, q_view, k_view, stats):
+        """Block ``i``'s packed q|k|v projection + q/k LayerNorm + RoPE (models/transformer.py:200-209, 241-245): ONE launch
+        with the norm in the GEMM's epilogue where the library takes it (bf16 weights, no statistics wanted), else the
+        projection and ``bya_qknorm_rope`` on its output -- the same bits either way."""
+        fused = self.qkn_epilogue and stats is None and (self.w8 is None or "qkv" not in self.w8) and xq is None
+        if fused and ops.gemm_qkv_norm_rope(xn, self.qkv_w[i], out, self.qkv_b[i], split, at.norm_q.weight, at.norm_q.bias,
+                                            at.norm_k.weight, at.norm_k.bias, cos, sin, text_rows, eps=at.norm_q.eps,
+                                            k_scale=self.k_scale):
+            return
+        self._dit_linear("qkv", i, xn, self.qkv_w[i], out, bias=self.qkv_b[i], split=split, quantised=xq)
+        ops.qknorm_rope(q_view, k_view, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
+                        heads=heads, text_rows=text_rows, eps=at.norm_q.eps, k_scale=self.k_scale, stats=stats)
 
     def _dit_linear(self, which, i, a, w, out, quantised=None, **kw):
         """One of the four big Linears of DiT block ``i`` (models/transformer.py:241-260): the bf16 GEMM, or -- when the
@@ -638,8 +653,9 @@ class DenoiseEngine:
                     if head_parallel:
                         # exchange A, head-parallel: the projection writes per-destination column blocks, q/k-norm +
                         # RoPE run on the local rows, then rows are traded for heads (every element moves once)
-                        self._dit_linear("qkv", i, xn[0], self.qkv_w[i], qkvb[0], bias=self.qkv_b[i], split=(Dl, S_loc * Dl),
-                                         quantised=None if xq is None else (xq[0][0], xq[1][0]))
+                        if sh.p2p is None:
+                            self._dit_linear("qkv", i, xn[0], self.qkv_w[i], qkvb[0], bias=self.qkv_b[i], split=(Dl, S_loc * Dl),
+                                             quantised=None if xq is None else (xq[0][0], xq[1][0]))
                         # v needs no norm: its exchange runs on the RCCL stream underneath q's norm + RoPE, q's exchange
                         # underneath k's; only k's is exposed (every exchange is enqueued on the communicator's stream,
                         # the compute stream waits by event right before the attention launch)
@@ -651,8 +667,8 @@ class DenoiseEngine:
                             # (device bound: this rank's rows give its partial maxima for ALL heads; the tables travel with
                             # the q|k|v exchange and the attention takes the maximum over the ranks' tables for its heads)
                             sb, st = self._attn_bound(i, H, slots=max(1, 64 // W))
-                            ops.qknorm_rope(qkvb[:W], qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
-                                            at.norm_k.bias, cos, sin, stats=st, **qk_kw)
+                            self._qkv_norm_rope(i, at, xn[0], qkvb[0], (Dl, S_loc * Dl), None if xq is None else (xq[0][0], xq[1][0]),
+                                                cos, sin, qk_kw["text_rows"], H // W, qkvb[:W], qkvb[W:2 * W], st)
                             qh_, kh_, vh_, st_all = sh.rows_to_heads_qkv(qkvb, st)
                             ops.self_attention(qh_[None], kh_[None], vh_[None], oh[None], heads=H // W, tag="joint", prescaled=True,
                                                score_bound=sb, bound=None if st is None else (st_all, sh.rank * (H // W), self._ws["qk_flags"]))
@@ -676,12 +692,10 @@ class DenoiseEngine:
                         self._dit_linear("out", i, xn, at.to_out[0].weight, x, bias=at.to_out[0].bias, res=x, gate0=mo[:, 5 * D:],
                                  gate1=mo[:, 2 * D:], gate_split=Tt_loc, gate_batch_stride=mbs)
                         continue
-                    self._dit_linear("qkv", i, xn, self.qkv_w[i], q, bias=self.qkv_b[i], split=(D, B * S_loc * D), quantised=xq)
                     # (rows of K from other ranks are not in this rank's statistics: the all-gather form keeps the worst case)
                     sb, st = self._attn_bound(i, B * H) if not sh.active else (self.score_bound[i], None)
-                    ops.qknorm_rope(q, k, at.norm_q.weight, at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin,
-                                    heads=H, text_rows=Tt_loc if cos is not None else S_loc, eps=at.norm_q.eps,
-                                        k_scale=self.k_scale, stats=st)
+                    self._qkv_norm_rope(i, at, xn, q, (D, B * S_loc * D), xq, cos, sin, Tt_loc if cos is not None else S_loc,
+                                        H, q, k, st)
                     if sh.active:      # exchange A (fallback when heads % world != 0): all-gather K and V
                         if sh.p2p is not None:
                             sh.gather_rows_many([k[0], v[0]], [k_full[0], v_full[0]])       # one exchange, double-buffered

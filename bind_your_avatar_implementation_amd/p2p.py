@@ -375,7 +375,7 @@ class P2PGroup:
             ch.cur = None
 
     # ---- health ----------------------------------------------------------------------------------------------------------
-    def self_test(self, rounds=24, elems=256 * 1024):
+    def self_test(self, rounds=12, elems=64 * 1024):
         """``rounds`` all-to-alls of ``elems`` int32 per peer INTO THE SAME receive buffer, payload changing every round, every
         word checked, with the consumer's reads (which leave the buffer's lines in this GPU's caches) and an acknowledging
         exchange between two pushes -- the re-use pattern of the step, where a stale line shows if remote stores are not seen.

@@ -67,6 +67,25 @@ typedef struct bya_gemm_desc {
 int bya_gemm_bf16(const void* A, const void* W, const void* bias, void* C, const void* res,
                   const void* gate0, const void* gate1, const bya_gemm_desc* desc, hipStream_t stream);
 
+/* The packed q|k|v projection of a DiT block WITH the per-head q/k LayerNorm(64, eps, affine) + interleaved-pair RoPE of
+ * bya_qknorm_rope in its epilogue (reference models/transformer.py:200-209,241-245 = diffusers Attention.to_q/k/v followed by
+ * CogVideoXAttnProcessor2_0's norm_q / norm_k / apply_rotary_emb): columns [0, width) of the product are q, [width, 2 width) k,
+ * [2 width, 3 width) v (plain bias epilogue); desc->n_split / c_split_stride place them as for bya_gemm_bf16.  q and k are
+ * normalised from the bf16-ROUNDED projection and with the arithmetic of csrc/qknorm_math.h, so the result equals
+ * bya_gemm_bf16 followed by bya_qknorm_rope BIT FOR BIT -- q and k are just written once instead of written, read and written
+ * again.  rows >= text_rows are rotated with cos / sin [rows - text_rows, 64] fp32 (row index = row of the launch, per batch
+ * entry); k_scale as for bya_qknorm_rope.  Constraints: no activation / residual / gates, width % 128 == 0, the persistent
+ * kernel's alignment rules; BYA_ERR_UNSUPPORTED otherwise (the caller then issues the two launches). */
+typedef struct bya_qknorm_desc {
+    const void* qw; const void* qb; const void* kw; const void* kb;   /* bf16 [64] each */
+    const float* cos; const float* sin;
+    int32_t text_rows;
+    int32_t width;                                                      /* heads * 64 */
+    float eps, k_scale;
+} bya_qknorm_desc;
+int bya_gemm_qkv_norm_rope(const void* A, const void* W, const void* bias, void* C, const bya_gemm_desc* desc,
+                           const bya_qknorm_desc* norm, hipStream_t stream);
+
 /* The same product for SKINNY launches -- at most 64 rows, N <= 8192, N % 16 == 0, K % 32 == 0, K >= 256, no gates, no
  * bias_rowscale, no n_split (anything else: BYA_ERR_UNSUPPORTED) -- on a weight-streaming kernel: one workgroup per 16
  * output columns (batch elements stacked as rows while they fit 64 together), 16 waves split K, partial sums added in a

@@ -797,6 +797,50 @@ def test_qknorm_rope(ops, dev):
     check(k, 0.18 * ref(k0, kw, kb), what="qknorm_rope k * k_scale (single rounding)")
 
 
+@pytest.mark.parametrize("B,M,K,width,blocks", [(1, 1000, 512, 384, 1), (2, 826, 3072, 3072, 1), (1, 2222, 3072, 3072, 8),
+                                                 (1, 300, 256, 128, 1)])
+def test_qkv_projection_with_the_norm_in_its_epilogue_is_bit_identical(ops, dev, B, M, K, width, blocks):
+    """bya_gemm_qkv_norm_rope = the packed q|k|v projection whose epilogue applies the per-head q/k LayerNorm(64) + RoPE + k
+    pre-scale (round 4: a second launch that re-read and re-wrote q and k).  It normalises the bf16-ROUNDED projection with the
+    arithmetic of csrc/qknorm_math.h in the stand-alone kernel's summation order, so it must equal bya_gemm_bf16 followed by
+    bya_qknorm_rope BIT FOR BIT: plain q | k | v outputs, a batch of two, ragged row counts, and the sharded step's form
+    (`blocks` column blocks per tensor = the heads of `blocks` destination ranks: [3 * blocks, M, width / blocks])."""
+    from bind_your_avatar_implementation_amd.synth import rope_table
+    text = 226 if M > 400 else 40
+    grid = None
+    n_video = M - text
+    for t in range(1, 40):                                   # a (t, h, w) grid with exactly n_video tokens, or rows of a bigger one
+        if n_video % t == 0:
+            grid = (t, n_video // t, 1)
+    cos, sin = (c.to(dev)[:n_video].contiguous() for c in rope_table(grid))
+    x = rnd((B, M, K), dev, 11)
+    w = rnd((3 * width, K), dev, 12, K ** -0.5)
+    bias = rnd((3 * width,), dev, 13, 0.5)
+    qw, qb, kw, kb = (rnd((64,), dev, 72 + i, 0.3) + (1 if i % 2 == 0 else 0) for i in range(4))
+    Dl = width // blocks
+    heads = width // 64
+    def outputs():
+        return torch.zeros(3 * blocks, B, M, Dl, dtype=torch.bfloat16, device=dev)
+    # (with blocks > 1 the engine runs one sample: B == 1)
+    two = outputs()
+    ops.gemm(x, w, two[0], bias=bias, split=(Dl, B * M * Dl))
+    if blocks == 1:
+        ops.qknorm_rope(two[0], two[1], qw, qb, kw, kb, cos, sin, heads=heads, text_rows=text, eps=1e-6, k_scale=0.18)
+    else:
+        ops.qknorm_rope(two[:blocks, 0], two[blocks:2 * blocks, 0], qw, qb, kw, kb, cos, sin, heads=heads // blocks, text_rows=text,
+                        eps=1e-6, k_scale=0.18)
+    one = outputs()
+    took = ops.gemm_qkv_norm_rope(x, w, one[0], bias, (Dl, B * M * Dl), qw, qb, kw, kb, cos, sin, text, eps=1e-6, k_scale=0.18)
+    torch.cuda.synchronize()
+    if width % 128 or K < 192:
+        assert not took
+        return
+    assert took
+    assert torch.equal(one, two), (float((one.float() - two.float()).abs().max()),
+                                   int((one != two).sum()), [int((one[t] != two[t]).sum()) for t in range(3 * blocks)])
+    assert float(one[:2 * blocks].float().abs().sum()) > 0
+
+
 def test_qknorm_rope_statistics_bound_every_row(ops, dev):
     """``stats``: the q/k-norm launch records, per (batch, head), the largest squared norm of the rows it WRITES (bf16-rounded,
     after RoPE and k_scale) in `slots` partial tables; their maximum is the data-dependent score bound the joint attention
