@@ -443,7 +443,7 @@ def main():
                              "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                              "frac": ach / PEAK_BF16_TFLOPS,
                              "traffic": pmc_traffic(world, *(("attn_joint_w4_kernel<true>", "attn_joint_w4_kernel<false>", "attn_joint_w4_kernel") if any("w4" in v for v in jv) else ()),
-                                                    "attn_fwd_kernel_d64_bounded2", "attn_fwd_kernel_d64_bounded", "attn_fwd_kernel_d64_prescaled"),
+                                                    "attn_fwd_kernel_d64_prescaled"),
                              "avg_launch_ms": avg * 1e3, "launches": len(attn),
                              "ms_per_step": sum(attn) / args.steps * 1e3}
             gemm = ktimes.get("bya_gemm_bf16", [])
@@ -466,7 +466,7 @@ def main():
                              "unit": "TFLOP/s", "frac": all_ach / PEAK_BF16_TFLOPS,
                              "all_linears_frac": all_ach / PEAK_BF16_TFLOPS,
                              "token_stream_frac": gflop / 1e12 / sum(gemm) / PEAK_BF16_TFLOPS,
-                             "traffic": pmc_traffic(world, "gemm256p_kernel<false, false>", "gemm256p_kernel<false>", "gemm256p_kernel", "gemm256_kernel"),
+                             "traffic": pmc_traffic(world, "gemm256p_kernel<false, false, false>", "gemm256p_kernel<false, false>", "gemm256p_kernel<false>", "gemm256p_kernel", "gemm256_kernel"),
                              "launches": len(gemm) + len(small),
                              "avg_launch_ms": (sum(gemm) + sum(small)) / (len(gemm) + len(small)) * 1e3,
                              "tflop_per_launch_avg": (gflop + sflop) / 1e12 / (len(gemm) + len(small)),

@@ -262,13 +262,19 @@ __device__ __forceinline__ void epilogue_qkn(const GemmArgs& p, int z, int m_wav
                     const u32x4 r = pack8(v[el]);
                     unpack8(r, v[el]);
                 }
-                float s0 = qkn_sum8(v[0]), s1 = qkn_sum8(v[1]);
-                s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64);
-                s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+                // lane ^ 16 and lane ^ 32 partners by v_permlane16_swap / v_permlane32_swap (one VALU instruction each; a
+                // __shfl_xor is a ds_bpermute round trip): swapping a value with itself leaves (own, partner's) in the two results
+                auto add16 = [](float x) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                };
+                auto add32 = [](float x) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                };
+                float s0 = add32(add16(qkn_sum8(v[0]))), s1 = add32(add16(qkn_sum8(v[1])));
                 const float mean = (s0 + s1) * (1.0f / 64);
-                float q0 = qkn_centre_sq8(v[0], mean), q1 = qkn_centre_sq8(v[1], mean);
-                q0 += __shfl_xor(q0, 16, 64); q1 += __shfl_xor(q1, 16, 64);
-                q0 += __shfl_xor(q0, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+                float q0 = add32(add16(qkn_centre_sq8(v[0], mean))), q1 = add32(add16(qkn_centre_sq8(v[1], mean)));
                 const float rstd = rsqrtf((q0 + q1) * (1.0f / 64) + p.qkn_eps);
                 qkn_finish8(v[0], rstd, wv[0], bb[0], rope, cc[0], ss[0], ks);
                 qkn_finish8(v[1], rstd, wv[1], bb[1], rope, cc[1], ss[1], ks);

@@ -4,8 +4,8 @@ TAG=${1:-r2}
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp
-timeout 700 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch_$TAG --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-fp8-variant > $R/gpurun_out/pmc_fetch_$TAG.log 2>&1
-timeout 700 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write_$TAG --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-fp8-variant > $R/gpurun_out/pmc_write_$TAG.log 2>&1
+timeout 700 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch_$TAG --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-fp8-variant --no-qk-gain-variant > $R/gpurun_out/pmc_fetch_$TAG.log 2>&1
+timeout 700 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write_$TAG --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-fp8-variant --no-qk-gain-variant > $R/gpurun_out/pmc_write_$TAG.log 2>&1
 cd $R
 python tools/pmc_aggregate.py gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/${TAG}_pmc_traffic.json
 find gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG -name "*.csv" -size +2M -delete
