@@ -184,9 +184,9 @@ class P2PGroup:
         self._p2p_enabled = set()
         self.pushes = 0
         self.side_stream = torch.cuda.Stream(self.dev)
-        limit = os.environ.get("BYA_P2P_TIMEOUT")            # seconds a wait may take before it gives up (default 30)
-        if limit:
-            _hip.check(_hip.load().bya_p2p_set_wait_limit_ms(int(float(limit) * 1000)), "bya_p2p_set_wait_limit_ms")
+        # seconds a wait may take before it gives up (wall clock; library-wide setting)
+        self.wait_limit_ms = int(float(os.environ.get("BYA_P2P_TIMEOUT", "30")) * 1000)
+        _hip.check(_hip.load().bya_p2p_set_wait_limit_ms(self.wait_limit_ms), "bya_p2p_set_wait_limit_ms")
         # the control block: peers store flags into it while this GPU's wait kernels poll them -> fine-grained memory
         # where the platform hands it out (RCCL allocates its flags that way for the same reason); coarse otherwise
         try:
@@ -390,16 +390,23 @@ class P2PGroup:
         ack = self.channel("__selftest_ack__", [(empty, j, "__selftest__", 0) for j in range(W)])
         src = torch.arange(W, dtype=torch.int32, device=self.dev)[:, None]
         bad = torch.zeros((), dtype=torch.int64, device=self.dev)
-        for it in range(rounds):
-            for j in range(W):
-                send[j] = ramp * (it + 1) + (self.rank * 64 + j) * 1000003 + it * 7919
-            if it % 2:
-                data.push().wait()
-            else:
-                data.exchange()
-            want = ramp[None, :] * (it + 1) + (src * 64 + self.rank) * 1000003 + it * 7919
-            bad += (recv != want).sum()                  # the consumer: reads every word through the ordinary cache path
-            ack.exchange()                               # "consumed": peers may overwrite the buffer from here on
+        lib = _hip.load()
+        _hip.check(lib.bya_p2p_set_wait_limit_ms(2000), "bya_p2p_set_wait_limit_ms")      # a dead link shows in seconds, not minutes
+        try:
+            for it in range(rounds):
+                for j in range(W):
+                    send[j] = ramp * (it + 1) + (self.rank * 64 + j) * 1000003 + it * 7919
+                if it % 2:
+                    data.push().wait()
+                else:
+                    data.exchange()
+                want = ramp[None, :] * (it + 1) + (src * 64 + self.rank) * 1000003 + it * 7919
+                bad += (recv != want).sum()                  # the consumer: reads every word through the ordinary cache path
+                ack.exchange()                               # "consumed": peers may overwrite the buffer from here on
+                if it % 4 == 3 and self.timeouts():          # (synchronises) nothing arrives: do not sit through every round
+                    break
+        finally:
+            _hip.check(lib.bya_p2p_set_wait_limit_ms(self.wait_limit_ms), "bya_p2p_set_wait_limit_ms")
         torch.cuda.synchronize(self.dev)
         if self.timeouts() or int(bad.item()):
             raise RuntimeError(f"P2P exchange self-test failed: {int(bad.item())} stale or missing words, "
