@@ -226,20 +226,28 @@ __device__ __forceinline__ void epilogue_qkn(const GemmArgs& p, int z, int m_wav
         unpack8(*reinterpret_cast<const u32x4*>(p.qkn_b[tn] + hc), bb[e]);
     }
     const float ks = tsel == 1 ? p.qkn_kscale : 1.0f;
+    const long long trows = (long long)p.M - p.qkn_text_rows;
+    const int tbytes = trows > 0 && p.qkn_cos ? (int)(trows * 256 > 0x7fffffffLL ? 0x7fffffffLL : trows * 256) : 0;
+    const __amdgpu_buffer_rsrc_t rsCos = __builtin_amdgcn_make_buffer_rsrc((void*)p.qkn_cos, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsSin = __builtin_amdgcn_make_buffer_rsrc((void*)p.qkn_sin, 0, tbytes, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int m = m_wave + 16 * j + fr;
         const bool mok = m < p.M;
         const uint32_t coff = (mok ? (uint32_t)m : 0u) * (uint32_t)(p.ldc * 2);
         const bool rope = tsel < 2 && m >= p.qkn_text_rows && mok;
-        float cc[2][8] = {}, ss[2][8] = {};
-        if (rope) {
-            const long long t0 = (long long)(m - p.qkn_text_rows) * 64;
+        // rotary-table row of this token, through buffer descriptors: no branch (other rows read zeros from an out-of-range
+        // offset and do not use them), so hipcc can keep the next row block's loads in flight under this one's arithmetic
+        float cc[2][8], ss[2][8];
+        {
+            const uint32_t t0 = rope ? (uint32_t)(m - p.qkn_text_rows) * 256u : 0xffffffffu;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int hc = (4 * e + fq) * 8;
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.qkn_cos + t0 + hc), c1 = *reinterpret_cast<const f32x4*>(p.qkn_cos + t0 + hc + 4);
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.qkn_sin + t0 + hc), s1 = *reinterpret_cast<const f32x4*>(p.qkn_sin + t0 + hc + 4);
+                const uint32_t off = rope ? t0 + (uint32_t)((4 * e + fq) * 32) : 0xffffffffu;
+                const f32x4 c0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsCos, off, 0, 0));
+                const f32x4 c1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsCos, rope ? off + 16u : off, 0, 0));
+                const f32x4 s0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsSin, off, 0, 0));
+                const f32x4 s1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsSin, rope ? off + 16u : off, 0, 0));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { cc[e][i] = c0[i]; cc[e][4 + i] = c1[i]; ss[e][i] = s0[i]; ss[e][4 + i] = s1[i]; }
             }

@@ -24,21 +24,20 @@ __device__ __forceinline__ float qkn_centre_sq8(float (&v)[8], float mean) {
     }
     return sq;
 }
-// centred values -> (x_hat * w + b), rotated by (cos, sin) when rope, times k_scale when it is not 1
+// centred values -> (x_hat * w + b), rotated by (cos, sin) where `rope` (a per-lane flag: branch-free, the rotation is
+// computed for every lane and selected), times k_scale when it is not 1
 __device__ __forceinline__ void qkn_finish8(float (&v)[8], float rstd, const float (&w)[8], const float (&b)[8], bool rope,
                                             const float (&cc)[8], const float (&ss)[8], float k_scale) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e] * rstd, w[e], b[e]);
-    if (rope) {
-        float o[8];
+    float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {   // pair (2i, 2i+1): rot = (-x[2i+1], x[2i])
-            o[e] = __builtin_fmaf(v[e], cc[e], -(v[e + 1] * ss[e]));
-            o[e + 1] = __builtin_fmaf(v[e + 1], cc[e + 1], v[e] * ss[e + 1]);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = o[e];
+    for (int e = 0; e < 8; e += 2) {   // pair (2i, 2i+1): rot = (-x[2i+1], x[2i])
+        o[e] = __builtin_fmaf(v[e], cc[e], -(v[e + 1] * ss[e]));
+        o[e + 1] = __builtin_fmaf(v[e + 1], cc[e + 1], v[e] * ss[e + 1]);
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = rope ? o[e] : v[e];
     if (k_scale != 1.0f) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= k_scale;
