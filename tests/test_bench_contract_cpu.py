@@ -1,5 +1,5 @@
 """The bench.py contract (one JSON line; metric / config of BASELINE.json; roofline and cpu_baseline objects) checked on the
-committed output of the end-of-round run (profiles/r4_final5_bench.json = stdout of ``python bench.py --steps 10 --warmup 3``
+committed output of the end-of-round run (profiles/r5_zz_bench.json = stdout of ``python bench.py --steps 10 --warmup 3``
 on an MI355X) and on the script's command line, without a GPU."""
 import json
 import os
@@ -17,7 +17,7 @@ def _line(path):
 
 def test_committed_bench_line_meets_the_contract():
     import glob
-    d = _line(os.path.join(ROOT, "profiles", "r4_final5_bench.json"))                        # the end-of-round line of round 4
+    d = _line(os.path.join(ROOT, "profiles", "r5_zz_bench.json"))                             # the end-of-round line of round 5
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     # BASELINE.json: "denoise-steps/sec + latent frames/sec, 49x480x720 bf16, 1/2/4/8 MI355X"
     assert base["metric"].startswith(d["metric"]) and d["unit"] == "steps/s" and "latent_frames_per_sec" in d
@@ -41,6 +41,16 @@ def test_committed_bench_line_meets_the_contract():
     # the dominant kernel by time is the one reported as `roofline`
     km = d["kernel_ms_per_step"]
     assert max(km, key=km.get) == "bya_gemm_bf16" and "bya_gemm_bf16" in r["kernel"]
+    # fixed names since round 5: `frac` prices EVERY Linear of the step (the definition of rounds 1-3), `token_stream_frac` leaves
+    # the conditioning's weight-streaming Linears out (round 4's `frac`); executed MFMA work beside the algorithmic 443.9 TFLOP
+    assert r["frac"] == r["all_linears_frac"] and r["token_stream_frac"] >= r["frac"]
+    assert 350 < d["executed_tflop_per_step"] < 443.9 and d["mfma_executed_frac"] < d["mfma_roofline_frac_whole_step"]
+    # the q/k-norm launches are gone (inside the QKV projection's epilogue); the variants beside the headline are there
+    assert "bya_qknorm_rope" not in km
+    assert d["large_qk_gain_variant"]["attention_variants"] == {"joint:d64_static_bound_w4": 168} and d["large_qk_gain_variant"]["finite"]
+    assert d["fp8_weights_variant"]["value"] > d["value"]
+    # the SURVEY 8(d) form of the CPU baseline is quoted from its committed run
+    assert c["config0_reference"]["file"].startswith("profiles/r5_") and c["config0_reference"]["value"] > 0
 
 
 def test_bench_command_line_parses_without_a_gpu():
