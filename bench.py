@@ -270,6 +270,12 @@ def main():
         return model(return_dict=False, denoise_step=0, **inp)[0]
 
     STRICT = {"BYA_GEMM_SPLITK": "0", "BYA_ATTN_STREAMK": "0"}     # both read per call by the library: summation order = the unsplit one
+    if share and world > 1:
+        # Split-K tails and the stream-K attention hand partial sums between workgroups of ONE launch and count on the whole
+        # grid being resident (one workgroup per CU on a GPU the process owns).  Processes that time-slice one GPU break
+        # that: two half-resident grids wait for each other until the bounded hand-off gives up (counted, and fatal below).
+        # The one-GPU rehearsal therefore runs everything in the unsplit mode; what it rehearses is the exchange code.
+        os.environ.update(STRICT)
 
     class strict_mode:
         def __enter__(self):
@@ -344,6 +350,8 @@ def main():
         noise_ok = everyone(diff <= bound and (getattr(model, "_seq_p2p", None) is None or model._seq_p2p.timeouts() == 0))
         validation = {"reference": "the unsharded step on every rank's own GPU (BYA_GEMM_SPLITK=0, BYA_ATTN_STREAMK=0)",
                       "rungs": tried, "default_mode_rel_fro_vs_reference": diff, "default_mode_bound": bound}
+        if share:
+            validation["ranks_share_one_gpu"] = "rehearsal of the N > 1 code path, split-K / stream-K off throughout: not a measurement"
         if not noise_ok:
             raise SystemExit(f"the sharded step in its default mode is not within bf16 summation noise of the unsharded step: {validation}")
         del ref_strict
