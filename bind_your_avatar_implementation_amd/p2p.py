@@ -44,6 +44,7 @@ CHUNK = 64 * 1024
 KINDS = {"coarse": 0, "fine": 1, "uncached": 2}
 TABLES_PER_CHANNEL = 4           # copy tables kept per channel besides the ones a captured graph owns
 LIVE_GROUPS = weakref.WeakSet()  # every P2PGroup of this process (ops.check_gemm_workspace asks each for timed-out waits)
+_RETIRED = []                    # buffers of closed groups (P2PGroup.close: never freed while peers might still store into them)
 
 
 class _FineUnavailable(RuntimeError):
@@ -183,6 +184,7 @@ class P2PGroup:
         self._channels = {}
         self._p2p_enabled = set()
         self.pushes = 0
+        self.closed = False
         self.side_stream = torch.cuda.Stream(self.dev)
         # seconds a wait may take before it gives up (wall clock; library-wide setting)
         self.wait_limit_ms = int(float(os.environ.get("BYA_P2P_TIMEOUT", "30")) * 1000)
@@ -199,6 +201,30 @@ class P2PGroup:
             self.ctrl_kind = "local (solo probe)"
         self.ctrl_peers = self._named["__ctrl__"][1]
         LIVE_GROUPS.add(self)
+
+    def _agree(self, err, what):
+        """COLLECTIVE: every rank reports how its local part of ``what`` went; if any rank failed, ALL raise.  Ranks must never
+        part ways inside the set-up (one in a barrier, another already in the caller's next collective: a hang on RCCL), so
+        every step that can fail on one rank alone ends here."""
+        errs = [err]
+        if self.world > 1 and self.solo is None:
+            errs = [None] * self.world
+            dist.all_gather_object(errs, None if err is None else str(err), group=self.group)
+        bad = [(j, e) for j, e in enumerate(errs) if e is not None]
+        if bad:
+            raise RuntimeError(f"P2P exchange engine, {what}: failed on rank(s) {bad}")
+
+    def close(self):
+        """Retire the group (a rung of the transport ladder that did not pass, or a model that is re-sharded): its sticky
+        time-out counters no longer count for ``ops.check_gemm_workspace``, its copy tables go.  The buffers are kept for the
+        life of the process ON PURPOSE -- a peer that fell behind may still store into them, and memory handed back to the
+        allocator would be somebody else's by then."""
+        LIVE_GROUPS.discard(self)
+        for ch in self._channels.values():
+            ch.tables.clear()
+            ch.cur = None
+        _RETIRED.append((self._named, self._keep))
+        self.closed = True
 
     # ---- symmetric buffers -------------------------------------------------------------------------------------------
     def symmetric(self, name, shape, dtype=torch.bfloat16, zero=False, kind=None):
@@ -225,9 +251,8 @@ class P2PGroup:
                     peers.insert(self.rank, _Peer(local.data_ptr(), shape, dtype, local))
                 self._named[name] = (local, peers)
                 return local
+            # (both end in _agree: nobody pushes before everybody has mapped, and a rank that could not map takes all down with it)
             local, peers = (self._symmetric_torch if kind == "coarse" else self._symmetric_ext)(shape, dtype, zero, kind)
-            if self.world > 1:
-                dist.barrier(group=self.group)          # nobody pushes before everybody has mapped
         self._named[name] = (local, peers)
         return local
 
@@ -239,22 +264,31 @@ class P2PGroup:
         peers = [None] * self.world
         peers[self.rank] = _Peer(local.data_ptr(), shape, dtype, local)
         if self.world > 1:
-            info = local.untyped_storage()._share_cuda_()
+            info, err = None, None
+            try:
+                info = local.untyped_storage()._share_cuda_()
+            except Exception as e:                      # noqa: BLE001  (no hipIpc export on this platform)
+                err = f"_share_cuda_: {e!r}"
             infos = [None] * self.world
             dist.all_gather_object(infos, (info, local.storage_offset(), tuple(shape)), group=self.group)
-            for j, (inf, off, shp) in enumerate(infos):
-                if j == self.rank:
-                    continue
-                st = torch.UntypedStorage._new_shared_cuda(*inf)
-                # (the mapped storage carries the OWNER's device index; only its address is used, by kernels of this GPU)
-                t = torch.empty(0, dtype=dtype, device=st.device).set_(st, off, shp)
-                if st.device != self.dev and (self.dev.index, st.device.index) not in self._p2p_enabled:
-                    # one process sees several GPUs (torchrun without per-rank visibility): a kernel of THIS GPU may only
-                    # dereference the peer's memory once peer access is enabled; torch does that on the first P2P copy
-                    probe = torch.empty(1, dtype=dtype, device=self.dev)
-                    probe.copy_(t.reshape(-1)[:1])
-                    self._p2p_enabled.add((self.dev.index, st.device.index))
-                peers[j] = _Peer(t.data_ptr(), shp, dtype, (st, t))
+            try:
+                for j, (inf, off, shp) in enumerate(infos):
+                    if j == self.rank or err is not None or inf is None:
+                        continue
+                    st = torch.UntypedStorage._new_shared_cuda(*inf)
+                    # (the mapped storage carries the OWNER's device index; only its address is used, by kernels of this GPU)
+                    t = torch.empty(0, dtype=dtype, device=st.device).set_(st, off, shp)
+                    if st.device != self.dev and (self.dev.index, st.device.index) not in self._p2p_enabled:
+                        # one process sees several GPUs (torchrun without per-rank visibility): a kernel of THIS GPU may only
+                        # dereference the peer's memory once peer access is enabled; torch does that on the first P2P copy
+                        probe = torch.empty(1, dtype=dtype, device=self.dev)
+                        probe.copy_(t.reshape(-1)[:1])
+                        self._p2p_enabled.add((self.dev.index, st.device.index))
+                    peers[j] = _Peer(t.data_ptr(), shp, dtype, (st, t))
+            except Exception as e:                      # noqa: BLE001  (a peer's handle does not open here)
+                err = f"mapping a peer's buffer: {e!r}"
+            self._keep.append(local)
+            self._agree(err, "mapping the peers' receive buffers (hipIpc through torch)")
         return local, peers
 
     def _symmetric_ext(self, shape, dtype, zero, kind):
@@ -292,16 +326,19 @@ class P2PGroup:
             raise _FineUnavailable(f"{kind} device memory unavailable on rank(s) {bad}")
         peers = [None] * self.world
         peers[self.rank] = _Peer(local.data_ptr(), shape, dtype, local)
+        err = None
         for j, (_, h, shp) in enumerate(infos):
-            if j == self.rank:
+            if j == self.rank or err is not None:
                 continue
             p = ctypes.c_void_p(0)
             rc = lib.bya_p2p_ipc_import((ctypes.c_ubyte * 64).from_buffer_copy(h), ctypes.byref(p))
             if rc != 0 or not p.value:
-                raise RuntimeError(f"bya_p2p_ipc_import of rank {j}'s buffer -> {_hip.ERRORS.get(rc, rc)}")
+                err = f"bya_p2p_ipc_import of rank {j}'s buffer -> {_hip.ERRORS.get(rc, rc)}"
+                continue
             blk = _Block(p.value, 0, False)
             self._keep.append(blk)
             peers[j] = _Peer(p.value, shp, dtype, blk)
+        self._agree(err, f"mapping the peers' {kind} buffers (bya_p2p_ipc_import)")
         return local, peers
 
     def peers(self, name):
@@ -408,11 +445,11 @@ class P2PGroup:
         finally:
             _hip.check(lib.bya_p2p_set_wait_limit_ms(self.wait_limit_ms), "bya_p2p_set_wait_limit_ms")
         torch.cuda.synchronize(self.dev)
+        err = None
         if self.timeouts() or int(bad.item()):
-            raise RuntimeError(f"P2P exchange self-test failed: {int(bad.item())} stale or missing words, "
-                               f"{self.timeouts()} timed-out waits ({self.mem} receive buffers, {self.ctrl_kind} flags)")
-        if self.world > 1 and self.solo is None:
-            dist.barrier(group=self.group)
+            err = (f"self-test: {int(bad.item())} stale or missing words, {self.timeouts()} timed-out waits "
+                   f"({self.mem} receive buffers, {self.ctrl_kind} flags)")
+        self._agree(err, "self-test")                    # (all ranks pass or all ranks raise; also the closing barrier)
 
     def timeouts(self):
         """Waits that gave up (0 on a healthy run); synchronises."""

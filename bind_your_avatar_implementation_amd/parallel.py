@@ -519,7 +519,7 @@ def shard_sequence(model, group=None, transport=None):
         raise ValueError(f"unknown transport {transport!r}: expected one of {TRANSPORTS}")
     old = getattr(model, "_seq_p2p", None)
     if old is not None:
-        old.drop_tables()
+        old.close()             # (its time-out counters are sticky: a rung that was left must not fail the run at its end)
     model._seq_p2p, model._seq_transport, notes = None, "torch", []
     for rung in TRANSPORTS[TRANSPORTS.index(transport):]:
         if rung == "torch":
@@ -531,14 +531,16 @@ def shard_sequence(model, group=None, transport=None):
             p2p = P2PGroup(model._seq_group, dev, mem="fine" if rung == "p2p-fine" else "coarse")
             p2p.self_test()
         except Exception as e:              # no hipIpc on this platform, peer access refused, stale words, ...
-            err = e
+            err = repr(e)                   # (the text only: the traceback would keep the failed group alive)
         # every rank must agree: one rank on collectives and another on push kernels would deadlock
         ok = [None] * model._seq_world
         dist.all_gather_object(ok, err is None, group=model._seq_group)
         if all(ok):
             model._seq_p2p, model._seq_transport = p2p, rung
             break
-        notes.append(f"{rung}: {err!r} on this rank; ranks ok: {ok}")
+        if p2p is not None:
+            p2p.close()
+        notes.append(f"{rung}: {err} on this rank; ranks ok: {ok}")
     if notes:
         import warnings
         warnings.warn("P2P exchange engine: " + "; ".join(notes) + f" -> running on {model._seq_transport!r}")

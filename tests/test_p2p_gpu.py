@@ -139,9 +139,16 @@ def _timeout_worker(rank, world, port, ret):
                 ops.check_gemm_workspace()
             except _hip.ByaError:
                 raised = True
-            ret[rank] = (healthy, g.timeouts(), bool(torch.isnan(out.float()).all()), raised)
+            # a retired group (a rung of the transport ladder that was left) no longer fails the run at its end
+            g.close()
+            clean = True
+            try:
+                ops.check_gemm_workspace()
+            except _hip.ByaError:
+                clean = False
+            ret[rank] = (healthy, g.timeouts(), bool(torch.isnan(out.float()).all()), raised, clean)
         else:
-            ret[rank] = (healthy, 0, True, True)
+            ret[rank] = (healthy, 0, True, True, True)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -150,14 +157,15 @@ def _timeout_worker(rank, world, port, ret):
 def test_p2p_wait_that_gives_up_is_loud(dev):
     """A wait whose peer never pushes gives up after BYA_P2P_TIMEOUT seconds (wall clock) instead of hanging the GPU, and
     that is not silent: the channel's time-out word is sticky, ``bya_p2p_poison`` turns the step's output into NaN, and
-    ``ops.check_gemm_workspace`` (pipeline end, bench end) raises."""
+    ``ops.check_gemm_workspace`` (pipeline end, bench end) raises -- until the group is retired (``close``: what the transport
+    ladder does with a rung it leaves)."""
     import torch.multiprocessing as mp
     ret = mp.Manager().dict()
     mp.spawn(_timeout_worker, args=(2, 32700 + os.getpid() % 200, ret), nprocs=2, join=True)
     print(dict(ret))
     for r in (0, 1):
         assert ret[r][0] == (True, True), ret[r]          # healthy run: no time-out, output untouched
-    assert ret[0][1] > 0 and ret[0][2] and ret[0][3], ret[0]
+    assert ret[0][1] > 0 and ret[0][2] and ret[0][3] and ret[0][4], ret[0]
 
 
 @pytest.mark.gpu
