@@ -19,8 +19,11 @@
 //
 // K/V tiles: LDS-DMA (buffer_load ... lds) three tiles ahead into a 3-stage ring (48 KiB), one s_barrier per tile at
 // the head of PV_2: by then every wave has read tile t's V (under QK_1) and tile t+1 must have landed.
-// Rows past Skv in the last tile: their K rows land as zeros (hardware range check) -> score 0 -> P = 1 exactly, their
-// V rows are zeros too, so only the row sum is off, by exactly the number of padded keys: subtracted at the end.
+// Rows past Skv in the last tile: their K and V rows land as zeros (hardware range check); the last tile of a piece runs the
+// 'M' copy of the stream, which sets their scores to -inf between its statements (P = 0: they are in no row sum).  (Until
+// round 5 they stayed at score 0 -> P = 1 and their count was subtracted from the row sum at the end: exact arithmetic, but a
+// row whose real scores all lay below ~-10 lost its sum in that subtraction -- a constant negative offset of a head, e.g.
+// from the q/k-LayerNorm biases, is within the +-90 the softmax promises to handle.)
 // Built WITHOUT -amdgpu-mfma-vgpr-form (O accumulators and the Q fragments live in AGPRs).
 #include "attn_common.h"
 #include <stdlib.h>
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
     u32x2 vh[2][4][2];
     bf16x8 kf[2][4];
     float psum[QB][2];
+    int keys_last = 64;                                    // keys that exist in the tile the 'M' stream runs on
 
     // per-lane LDS offsets inside a stage: K fragment (u, s) at kofs[s] + u * 32 rows; V fragment (d, ks, h) at
     // vofs[d] + (16 ks + 8 h) rows (transposed read: 4 rows x 64 B per half-wave, attn.hip)
@@ -181,7 +185,12 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
 #define BAR() asm volatile("s_barrier" ::: "memory")
     // K fragments of the tile in stage `kst`; V fragments of the tile in stage `vst`
 #define RK(U, S) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[U][S]) : "v"(kaddr[S]), "i"((U) * 32 * RB))
-    // One tile ('L') or the tail behind the last tile ('T').  kaddr: K fragment addresses of tile t + 1, vaddr: V
+    // scores of keys that do not exist (this lane's key of register v of a 32-key half: (v & 3) + 8 (v >> 2) + 4 hf) -> -inf
+#define MASKPAD(ACC, BASE)                                                                     \
+    if ((BASE) + 32 > keys_last)                         /* (wave-uniform: this half holds such keys at all) */ \
+        _Pragma("unroll") for (int v_ = 0; v_ < 16; ++v_)                                      \
+            if ((BASE) + (v_ & 3) + 8 * (v_ >> 2) + 4 * hf >= keys_last) ACC[v_] = -INFINITY
+    // One tile ('L'), the last tile of the piece ('M': 'L' + MASKPAD) or the tail behind the last tile ('T').  kaddr: K fragment addresses of tile t + 1, vaddr: V
     // fragment addresses of tile t, dma_dst / soffK / soffV: where tile t + 3 goes and comes from.
     auto body = [&](auto v_c, const uint32_t (&kaddr)[4], const uint32_t (&vaddr)[2], uint32_t dma_dst, uint32_t soffK,
                     uint32_t soffV) {
@@ -200,6 +209,27 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
             // period 3: QK_3 | PV_2
             { float t1_0; float t1_1; float t1_2; float t1_3; float t1_4; float t1_5; float t1_6; float t1_7; float t1_8; float t1_9; float t1_10; float t1_11; float t1_12; float t1_13; float t1_14; float t1_15; uint32_t w2_0; uint32_t w2_1; uint32_t w2_2; uint32_t w2_3; uint32_t w3_0; uint32_t w3_1; uint32_t w3_2; uint32_t w3_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, 0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %0, %32, %33, %0\n\tv_exp_f32 %3, %34\n\tv_add_f32 %5, %5, %1\n\tv_exp_f32 %4, %35\n\tv_add_f32 %6, %6, %2\n\tv_cvt_pk_bf16_f32 %7, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %36, %37, %0\n\tv_exp_f32 %8, %38\n\tv_add_f32 %5, %5, %3\n\tv_exp_f32 %9, %39\n\tv_add_f32 %6, %6, %4\n\tv_cvt_pk_bf16_f32 %10, %3, %4\n\tv_mfma_f32_32x32x16_bf16 %0, %40, %41, %0\n\tv_exp_f32 %11, %42\n\tv_add_f32 %5, %5, %8\n\tv_exp_f32 %12, %43\n\tv_add_f32 %6, %6, %9\n\tv_cvt_pk_bf16_f32 %13, %8, %9\n\tv_mfma_f32_32x32x16_bf16 %14, %44, %29, 0\n\tv_exp_f32 %15, %45\n\tv_add_f32 %5, %5, %11\n\tv_exp_f32 %16, %46\n\tv_add_f32 %6, %6, %12\n\tv_cvt_pk_bf16_f32 %17, %11, %12\n\tv_mfma_f32_32x32x16_bf16 %14, %47, %33, %14\n\tv_exp_f32 %18, %48\n\tv_add_f32 %5, %5, %15\n\tv_exp_f32 %19, %49\n\tv_add_f32 %6, %6, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %14, %50, %37, %14\n\tv_exp_f32 %21, %51\n\tv_add_f32 %5, %5, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %6, %6, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %14, %53, %41, %14\n\tv_exp_f32 %24, %54\n\tv_add_f32 %5, %5, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %6, %6, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %5, %5, %24\n\tv_add_f32 %6, %6, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "=&v"(sacc[1][0]), "=&v"(t1_0), "=&v"(t1_1), "=&v"(t1_2), "=&v"(t1_3), "+v"(psum[2][0]), "+v"(psum[2][1]), "=&v"(w2_0), "=&v"(t1_4), "=&v"(t1_5), "=&v"(w2_1), "=&v"(t1_6), "=&v"(t1_7), "=&v"(w2_2), "=&v"(sacc[1][1]), "=&v"(t1_8), "=&v"(t1_9), "=&v"(w2_3), "=&v"(t1_10), "=&v"(t1_11), "=&v"(w3_0), "=&v"(t1_12), "=&v"(t1_13), "=&v"(w3_1), "=&v"(t1_14), "=&v"(t1_15), "=&v"(w3_2), "=&v"(w3_3) : "v"(kf[0][0]), "a"(qf[3][0]), "v"(sacc[0][1][0]), "v"(sacc[0][1][1]), "v"(kf[0][1]), "a"(qf[3][1]), "v"(sacc[0][1][2]), "v"(sacc[0][1][3]), "v"(kf[0][2]), "a"(qf[3][2]), "v"(sacc[0][1][4]), "v"(sacc[0][1][5]), "v"(kf[0][3]), "a"(qf[3][3]), "v"(sacc[0][1][6]), "v"(sacc[0][1][7]), "v"(kf[1][0]), "v"(sacc[0][1][8]), "v"(sacc[0][1][9]), "v"(kf[1][1]), "v"(sacc[0][1][10]), "v"(sacc[0][1][11]), "v"(kf[1][2]), "v"(sacc[0][1][12]), "v"(sacc[0][1][13]), "v"(kf[1][3]), "v"(sacc[0][1][14]), "v"(sacc[0][1][15]) : "memory"); pf[0][2][0] = w2_0; pf[0][2][1] = w2_1; pf[0][2][2] = w2_2; pf[0][2][3] = w2_3; pf[0][3][0] = w3_0; pf[0][3][1] = w3_1; pf[0][3][2] = w3_2; pf[0][3][3] = w3_3; }
             { const u32x4 vv0_0 = {vh[0][0][0][0], vh[0][0][0][1], vh[0][0][1][0], vh[0][0][1][1]}; const u32x4 vv1_0 = {vh[1][0][0][0], vh[1][0][0][1], vh[1][0][1][0], vh[1][0][1][1]}; const u32x4 vv0_1 = {vh[0][1][0][0], vh[0][1][0][1], vh[0][1][1][0], vh[0][1][1][1]}; const u32x4 vv1_1 = {vh[1][1][0][0], vh[1][1][0][1], vh[1][1][1][0], vh[1][1][1][1]}; const u32x4 vv0_2 = {vh[0][2][0][0], vh[0][2][0][1], vh[0][2][1][0], vh[0][2][1][1]}; const u32x4 vv1_2 = {vh[1][2][0][0], vh[1][2][0][1], vh[1][2][1][0], vh[1][2][1][1]}; const u32x4 vv0_3 = {vh[0][3][0][0], vh[0][3][0][1], vh[0][3][1][0], vh[0][3][1][1]}; const u32x4 vv1_3 = {vh[1][3][0][0], vh[1][3][0][1], vh[1][3][1][0], vh[1][3][1][1]}; const uint32_t dma_dst0 = dma_dst + 0 + 0 * TILE_BYTES; const uint32_t dma_dst1 = dma_dst + 1024 + 0 * TILE_BYTES; const uint32_t dma_dst2 = dma_dst + 0 + 1 * TILE_BYTES; const uint32_t dma_dst3 = dma_dst + 1024 + 1 * TILE_BYTES; float t0_0; float t0_1; float t0_2; float t0_3; float t0_4; float t0_5; float t0_6; float t0_7; float t0_8; float t0_9; float t0_10; float t0_11; float t0_12; float t0_13; float t0_14; float t0_15; uint32_t w0_0; uint32_t w0_1; uint32_t w0_2; uint32_t w0_3; uint32_t w1_0; uint32_t w1_1; uint32_t w1_2; uint32_t w1_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %36, %37, %0\n\ts_waitcnt vmcnt(4)\n\ts_barrier\n\tds_read_b128 %1, %38 offset:0\n\tds_read_b128 %2, %39 offset:0\n\tv_exp_f32 %3, %40\n\tv_exp_f32 %4, %41\n\tv_mfma_f32_32x32x16_bf16 %5, %42, %37, %5\n\tds_read_b128 %6, %43 offset:0\n\tds_read_b128 %7, %44 offset:0\n\tv_exp_f32 %8, %45\n\tv_add_f32 %10, %10, %3\n\tv_exp_f32 %9, %46\n\tv_add_f32 %11, %11, %4\n\tv_cvt_pk_bf16_f32 %12, %3, %4\n\tv_mfma_f32_32x32x16_bf16 %0, %47, %48, %0\n\tds_read_b128 %13, %38 offset:4096\n\tds_read_b128 %14, %39 offset:4096\n\tv_exp_f32 %15, %49\n\tv_add_f32 %10, %10, %8\n\tv_exp_f32 %16, %50\n\tv_add_f32 %11, %11, %9\n\tv_cvt_pk_bf16_f32 %17, %8, %9\n\tv_mfma_f32_32x32x16_bf16 %5, %51, %48, %5\n\tds_read_b128 %18, %43 offset:4096\n\tds_read_b128 %19, %44 offset:4096\n\tv_exp_f32 %20, %52\n\tv_add_f32 %10, %10, %15\n\tv_exp_f32 %21, %53\n\tv_add_f32 %11, %11, %16\n\tv_cvt_pk_bf16_f32 %22, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %0, %54, %55, %0\n\ts_mov_b32 m0, %56\n\ts_nop 0\n\tbuffer_load_dwordx4 %57, %58, %59 offen lds\n\tv_exp_f32 %23, %60\n\tv_add_f32 %10, %10, %20\n\tv_exp_f32 %24, %61\n\tv_add_f32 %11, %11, %21\n\tv_cvt_pk_bf16_f32 %25, %20, %21\n\tv_mfma_f32_32x32x16_bf16 %5, %62, %55, %5\n\ts_mov_b32 m0, %63\n\ts_nop 0\n\tbuffer_load_dwordx4 %64, %58, %59 offen lds\n\tv_exp_f32 %26, %65\n\tv_add_f32 %10, %10, %23\n\tv_exp_f32 %27, %66\n\tv_add_f32 %11, %11, %24\n\tv_cvt_pk_bf16_f32 %28, %23, %24\n\tv_mfma_f32_32x32x16_bf16 %0, %67, %68, %0\n\ts_mov_b32 m0, %69\n\ts_nop 0\n\tbuffer_load_dwordx4 %70, %71, %72 offen lds\n\tv_exp_f32 %29, %73\n\tv_add_f32 %10, %10, %26\n\tv_exp_f32 %30, %74\n\tv_add_f32 %11, %11, %27\n\tv_cvt_pk_bf16_f32 %31, %26, %27\n\tv_mfma_f32_32x32x16_bf16 %5, %75, %68, %5\n\ts_mov_b32 m0, %76\n\ts_nop 0\n\tbuffer_load_dwordx4 %77, %71, %72 offen lds\n\tv_exp_f32 %32, %78\n\tv_add_f32 %10, %10, %29\n\tv_exp_f32 %33, %79\n\tv_add_f32 %11, %11, %30\n\tv_cvt_pk_bf16_f32 %34, %29, %30\n\tv_add_f32 %10, %10, %32\n\tv_add_f32 %11, %11, %33\n\tv_cvt_pk_bf16_f32 %35, %32, %33\n\ts_waitcnt lgkmcnt(0)" : "+a"(oacc[2][0]), "=&v"(kf[0][0]), "=&v"(kf[0][1]), "=&v"(t0_0), "=&v"(t0_1), "+a"(oacc[2][1]), "=&v"(kf[0][2]), "=&v"(kf[0][3]), "=&v"(t0_2), "=&v"(t0_3), "+v"(psum[3][0]), "+v"(psum[3][1]), "=&v"(w0_0), "=&v"(kf[1][0]), "=&v"(kf[1][1]), "=&v"(t0_4), "=&v"(t0_5), "=&v"(w0_1), "=&v"(kf[1][2]), "=&v"(kf[1][3]), "=&v"(t0_6), "=&v"(t0_7), "=&v"(w0_2), "=&v"(t0_8), "=&v"(t0_9), "=&v"(w0_3), "=&v"(t0_10), "=&v"(t0_11), "=&v"(w1_0), "=&v"(t0_12), "=&v"(t0_13), "=&v"(w1_1), "=&v"(t0_14), "=&v"(t0_15), "=&v"(w1_2), "=&v"(w1_3) : "v"(vv0_0), "v"(pf[0][0]), "v"(kaddr[0]), "v"(kaddr[1]), "v"(sacc[1][0][0]), "v"(sacc[1][0][1]), "v"(vv1_0), "v"(kaddr[2]), "v"(kaddr[3]), "v"(sacc[1][0][2]), "v"(sacc[1][0][3]), "v"(vv0_1), "v"(pf[0][1]), "v"(sacc[1][0][4]), "v"(sacc[1][0][5]), "v"(vv1_1), "v"(sacc[1][0][6]), "v"(sacc[1][0][7]), "v"(vv0_2), "v"(pf[0][2]), "s"(dma_dst0), "v"(dvo[0]), "s"(rsK), "s"(soffK), "v"(sacc[1][0][8]), "v"(sacc[1][0][9]), "v"(vv1_2), "s"(dma_dst1), "v"(dvo[1]), "v"(sacc[1][0][10]), "v"(sacc[1][0][11]), "v"(vv0_3), "v"(pf[0][3]), "s"(dma_dst2), "v"(dvo[2]), "s"(rsV), "s"(soffV), "v"(sacc[1][0][12]), "v"(sacc[1][0][13]), "v"(vv1_3), "s"(dma_dst3), "v"(dvo[3]), "v"(sacc[1][0][14]), "v"(sacc[1][0][15]) : "memory"); pf[1][0][0] = w0_0; pf[1][0][1] = w0_1; pf[1][0][2] = w0_2; pf[1][0][3] = w0_3; pf[1][1][0] = w1_0; pf[1][1][1] = w1_1; pf[1][1][2] = w1_2; pf[1][1][3] = w1_3; }
+        } else if constexpr (VAR == 'M') {
+            // period 0: QK_0 | PV_3
+            { float t1_0; float t1_1; float t1_2; float t1_3; float t1_4; float t1_5; float t1_6; float t1_7; float t1_8; float t1_9; float t1_10; float t1_11; float t1_12; float t1_13; float t1_14; float t1_15; uint32_t w2_0; uint32_t w2_1; uint32_t w2_2; uint32_t w2_3; uint32_t w3_0; uint32_t w3_1; uint32_t w3_2; uint32_t w3_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, 0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %0, %32, %33, %0\n\tv_exp_f32 %3, %34\n\tv_add_f32 %5, %5, %1\n\tv_exp_f32 %4, %35\n\tv_add_f32 %6, %6, %2\n\tv_cvt_pk_bf16_f32 %7, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %36, %37, %0\n\tv_exp_f32 %8, %38\n\tv_add_f32 %5, %5, %3\n\tv_exp_f32 %9, %39\n\tv_add_f32 %6, %6, %4\n\tv_cvt_pk_bf16_f32 %10, %3, %4\n\tv_mfma_f32_32x32x16_bf16 %0, %40, %41, %0\n\tv_exp_f32 %11, %42\n\tv_add_f32 %5, %5, %8\n\tv_exp_f32 %12, %43\n\tv_add_f32 %6, %6, %9\n\tv_cvt_pk_bf16_f32 %13, %8, %9\n\tv_mfma_f32_32x32x16_bf16 %14, %44, %29, 0\n\tv_exp_f32 %15, %45\n\tv_add_f32 %5, %5, %11\n\tv_exp_f32 %16, %46\n\tv_add_f32 %6, %6, %12\n\tv_cvt_pk_bf16_f32 %17, %11, %12\n\tv_mfma_f32_32x32x16_bf16 %14, %47, %33, %14\n\tv_exp_f32 %18, %48\n\tv_add_f32 %5, %5, %15\n\tv_exp_f32 %19, %49\n\tv_add_f32 %6, %6, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %14, %50, %37, %14\n\tv_exp_f32 %21, %51\n\tv_add_f32 %5, %5, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %6, %6, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %14, %53, %41, %14\n\tv_exp_f32 %24, %54\n\tv_add_f32 %5, %5, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %6, %6, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %5, %5, %24\n\tv_add_f32 %6, %6, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "=&v"(sacc[0][0]), "=&v"(t1_0), "=&v"(t1_1), "=&v"(t1_2), "=&v"(t1_3), "+v"(psum[3][0]), "+v"(psum[3][1]), "=&v"(w2_0), "=&v"(t1_4), "=&v"(t1_5), "=&v"(w2_1), "=&v"(t1_6), "=&v"(t1_7), "=&v"(w2_2), "=&v"(sacc[0][1]), "=&v"(t1_8), "=&v"(t1_9), "=&v"(w2_3), "=&v"(t1_10), "=&v"(t1_11), "=&v"(w3_0), "=&v"(t1_12), "=&v"(t1_13), "=&v"(w3_1), "=&v"(t1_14), "=&v"(t1_15), "=&v"(w3_2), "=&v"(w3_3) : "v"(kf[0][0]), "a"(qf[0][0]), "v"(sacc[1][1][0]), "v"(sacc[1][1][1]), "v"(kf[0][1]), "a"(qf[0][1]), "v"(sacc[1][1][2]), "v"(sacc[1][1][3]), "v"(kf[0][2]), "a"(qf[0][2]), "v"(sacc[1][1][4]), "v"(sacc[1][1][5]), "v"(kf[0][3]), "a"(qf[0][3]), "v"(sacc[1][1][6]), "v"(sacc[1][1][7]), "v"(kf[1][0]), "v"(sacc[1][1][8]), "v"(sacc[1][1][9]), "v"(kf[1][1]), "v"(sacc[1][1][10]), "v"(sacc[1][1][11]), "v"(kf[1][2]), "v"(sacc[1][1][12]), "v"(sacc[1][1][13]), "v"(kf[1][3]), "v"(sacc[1][1][14]), "v"(sacc[1][1][15]) : "memory"); pf[1][2][0] = w2_0; pf[1][2][1] = w2_1; pf[1][2][2] = w2_2; pf[1][2][3] = w2_3; pf[1][3][0] = w3_0; pf[1][3][1] = w3_1; pf[1][3][2] = w3_2; pf[1][3][3] = w3_3; }
+            MASKPAD(sacc[0][0], 0);
+            { const u32x4 vv0_0 = {vh[0][0][0][0], vh[0][0][0][1], vh[0][0][1][0], vh[0][0][1][1]}; const u32x4 vv1_0 = {vh[1][0][0][0], vh[1][0][0][1], vh[1][0][1][0], vh[1][0][1][1]}; const u32x4 vv0_1 = {vh[0][1][0][0], vh[0][1][0][1], vh[0][1][1][0], vh[0][1][1][1]}; const u32x4 vv1_1 = {vh[1][1][0][0], vh[1][1][0][1], vh[1][1][1][0], vh[1][1][1][1]}; const u32x4 vv0_2 = {vh[0][2][0][0], vh[0][2][0][1], vh[0][2][1][0], vh[0][2][1][1]}; const u32x4 vv1_2 = {vh[1][2][0][0], vh[1][2][0][1], vh[1][2][1][0], vh[1][2][1][1]}; const u32x4 vv0_3 = {vh[0][3][0][0], vh[0][3][0][1], vh[0][3][1][0], vh[0][3][1][1]}; const u32x4 vv1_3 = {vh[1][3][0][0], vh[1][3][0][1], vh[1][3][1][0], vh[1][3][1][1]}; float t0_0; float t0_1; float t0_2; float t0_3; float t0_4; float t0_5; float t0_6; float t0_7; float t0_8; float t0_9; float t0_10; float t0_11; float t0_12; float t0_13; float t0_14; float t0_15; uint32_t w0_0; uint32_t w0_1; uint32_t w0_2; uint32_t w0_3; uint32_t w1_0; uint32_t w1_1; uint32_t w1_2; uint32_t w1_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, %0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %3, %32, %29, %3\n\tv_exp_f32 %4, %33\n\tv_add_f32 %6, %6, %1\n\tv_exp_f32 %5, %34\n\tv_add_f32 %7, %7, %2\n\tv_cvt_pk_bf16_f32 %8, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %35, %36, %0\n\tv_exp_f32 %9, %37\n\tv_add_f32 %6, %6, %4\n\tv_exp_f32 %10, %38\n\tv_add_f32 %7, %7, %5\n\tv_cvt_pk_bf16_f32 %11, %4, %5\n\tv_mfma_f32_32x32x16_bf16 %3, %39, %36, %3\n\tv_exp_f32 %12, %40\n\tv_add_f32 %6, %6, %9\n\tv_exp_f32 %13, %41\n\tv_add_f32 %7, %7, %10\n\tv_cvt_pk_bf16_f32 %14, %9, %10\n\tv_mfma_f32_32x32x16_bf16 %0, %42, %43, %0\n\tv_exp_f32 %15, %44\n\tv_add_f32 %6, %6, %12\n\tv_exp_f32 %16, %45\n\tv_add_f32 %7, %7, %13\n\tv_cvt_pk_bf16_f32 %17, %12, %13\n\tv_mfma_f32_32x32x16_bf16 %3, %46, %43, %3\n\tv_exp_f32 %18, %47\n\tv_add_f32 %6, %6, %15\n\tv_exp_f32 %19, %48\n\tv_add_f32 %7, %7, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %0, %49, %50, %0\n\tv_exp_f32 %21, %51\n\tv_add_f32 %6, %6, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %7, %7, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %3, %53, %50, %3\n\tv_exp_f32 %24, %54\n\tv_add_f32 %6, %6, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %7, %7, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %6, %6, %24\n\tv_add_f32 %7, %7, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "+a"(oacc[3][0]), "=&v"(t0_0), "=&v"(t0_1), "+a"(oacc[3][1]), "=&v"(t0_2), "=&v"(t0_3), "+v"(psum[0][0]), "+v"(psum[0][1]), "=&v"(w0_0), "=&v"(t0_4), "=&v"(t0_5), "=&v"(w0_1), "=&v"(t0_6), "=&v"(t0_7), "=&v"(w0_2), "=&v"(t0_8), "=&v"(t0_9), "=&v"(w0_3), "=&v"(t0_10), "=&v"(t0_11), "=&v"(w1_0), "=&v"(t0_12), "=&v"(t0_13), "=&v"(w1_1), "=&v"(t0_14), "=&v"(t0_15), "=&v"(w1_2), "=&v"(w1_3) : "v"(vv0_0), "v"(pf[1][0]), "v"(sacc[0][0][0]), "v"(sacc[0][0][1]), "v"(vv1_0), "v"(sacc[0][0][2]), "v"(sacc[0][0][3]), "v"(vv0_1), "v"(pf[1][1]), "v"(sacc[0][0][4]), "v"(sacc[0][0][5]), "v"(vv1_1), "v"(sacc[0][0][6]), "v"(sacc[0][0][7]), "v"(vv0_2), "v"(pf[1][2]), "v"(sacc[0][0][8]), "v"(sacc[0][0][9]), "v"(vv1_2), "v"(sacc[0][0][10]), "v"(sacc[0][0][11]), "v"(vv0_3), "v"(pf[1][3]), "v"(sacc[0][0][12]), "v"(sacc[0][0][13]), "v"(vv1_3), "v"(sacc[0][0][14]), "v"(sacc[0][0][15]) : "memory"); pf[0][0][0] = w0_0; pf[0][0][1] = w0_1; pf[0][0][2] = w0_2; pf[0][0][3] = w0_3; pf[0][1][0] = w1_0; pf[0][1][1] = w1_1; pf[0][1][2] = w1_2; pf[0][1][3] = w1_3; }
+            MASKPAD(sacc[0][1], 32);
+            // period 1: QK_1 | PV_0
+            { float t1_0; float t1_1; float t1_2; float t1_3; float t1_4; float t1_5; float t1_6; float t1_7; float t1_8; float t1_9; float t1_10; float t1_11; float t1_12; float t1_13; float t1_14; float t1_15; uint32_t w2_0; uint32_t w2_1; uint32_t w2_2; uint32_t w2_3; uint32_t w3_0; uint32_t w3_1; uint32_t w3_2; uint32_t w3_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %44, %45, 0\n\tds_read_b64_tr_b16 %1, %46 offset:0\n\tds_read_b64_tr_b16 %2, %46 offset:1024\n\tds_read_b64_tr_b16 %3, %47 offset:0\n\tv_exp_f32 %4, %48\n\tv_exp_f32 %5, %49\n\tv_mfma_f32_32x32x16_bf16 %0, %50, %51, %0\n\tds_read_b64_tr_b16 %6, %47 offset:1024\n\tds_read_b64_tr_b16 %7, %46 offset:2048\n\tds_read_b64_tr_b16 %8, %46 offset:3072\n\tv_exp_f32 %9, %52\n\tv_add_f32 %11, %11, %4\n\tv_exp_f32 %10, %53\n\tv_add_f32 %12, %12, %5\n\tv_cvt_pk_bf16_f32 %13, %4, %5\n\tv_mfma_f32_32x32x16_bf16 %0, %54, %55, %0\n\tds_read_b64_tr_b16 %14, %47 offset:2048\n\tds_read_b64_tr_b16 %15, %47 offset:3072\n\tds_read_b64_tr_b16 %16, %46 offset:4096\n\tv_exp_f32 %17, %56\n\tv_add_f32 %11, %11, %9\n\tv_exp_f32 %18, %57\n\tv_add_f32 %12, %12, %10\n\tv_cvt_pk_bf16_f32 %19, %9, %10\n\tv_mfma_f32_32x32x16_bf16 %0, %58, %59, %0\n\tds_read_b64_tr_b16 %20, %46 offset:5120\n\tds_read_b64_tr_b16 %21, %47 offset:4096\n\tds_read_b64_tr_b16 %22, %47 offset:5120\n\tv_exp_f32 %23, %60\n\tv_add_f32 %11, %11, %17\n\tv_exp_f32 %24, %61\n\tv_add_f32 %12, %12, %18\n\tv_cvt_pk_bf16_f32 %25, %17, %18\n\tv_mfma_f32_32x32x16_bf16 %26, %62, %45, 0\n\tds_read_b64_tr_b16 %27, %46 offset:6144\n\tds_read_b64_tr_b16 %28, %46 offset:7168\n\tv_exp_f32 %29, %63\n\tv_add_f32 %11, %11, %23\n\tv_exp_f32 %30, %64\n\tv_add_f32 %12, %12, %24\n\tv_cvt_pk_bf16_f32 %31, %23, %24\n\tv_mfma_f32_32x32x16_bf16 %26, %65, %51, %26\n\tds_read_b64_tr_b16 %32, %47 offset:6144\n\tds_read_b64_tr_b16 %33, %47 offset:7168\n\tv_exp_f32 %34, %66\n\tv_add_f32 %11, %11, %29\n\tv_exp_f32 %35, %67\n\tv_add_f32 %12, %12, %30\n\tv_cvt_pk_bf16_f32 %36, %29, %30\n\tv_mfma_f32_32x32x16_bf16 %26, %68, %55, %26\n\tv_exp_f32 %37, %69\n\tv_add_f32 %11, %11, %34\n\tv_exp_f32 %38, %70\n\tv_add_f32 %12, %12, %35\n\tv_cvt_pk_bf16_f32 %39, %34, %35\n\tv_mfma_f32_32x32x16_bf16 %26, %71, %59, %26\n\tv_exp_f32 %40, %72\n\tv_add_f32 %11, %11, %37\n\tv_exp_f32 %41, %73\n\tv_add_f32 %12, %12, %38\n\tv_cvt_pk_bf16_f32 %42, %37, %38\n\tv_add_f32 %11, %11, %40\n\tv_add_f32 %12, %12, %41\n\tv_cvt_pk_bf16_f32 %43, %40, %41\n\ts_waitcnt lgkmcnt(0)" : "=&v"(sacc[1][0]), "=&v"(vh[0][0][0]), "=&v"(vh[0][0][1]), "=&v"(vh[1][0][0]), "=&v"(t1_0), "=&v"(t1_1), "=&v"(vh[1][0][1]), "=&v"(vh[0][1][0]), "=&v"(vh[0][1][1]), "=&v"(t1_2), "=&v"(t1_3), "+v"(psum[0][0]), "+v"(psum[0][1]), "=&v"(w2_0), "=&v"(vh[1][1][0]), "=&v"(vh[1][1][1]), "=&v"(vh[0][2][0]), "=&v"(t1_4), "=&v"(t1_5), "=&v"(w2_1), "=&v"(vh[0][2][1]), "=&v"(vh[1][2][0]), "=&v"(vh[1][2][1]), "=&v"(t1_6), "=&v"(t1_7), "=&v"(w2_2), "=&v"(sacc[1][1]), "=&v"(vh[0][3][0]), "=&v"(vh[0][3][1]), "=&v"(t1_8), "=&v"(t1_9), "=&v"(w2_3), "=&v"(vh[1][3][0]), "=&v"(vh[1][3][1]), "=&v"(t1_10), "=&v"(t1_11), "=&v"(w3_0), "=&v"(t1_12), "=&v"(t1_13), "=&v"(w3_1), "=&v"(t1_14), "=&v"(t1_15), "=&v"(w3_2), "=&v"(w3_3) : "v"(kf[0][0]), "a"(qf[1][0]), "v"(vaddr[0]), "v"(vaddr[1]), "v"(sacc[0][1][0]), "v"(sacc[0][1][1]), "v"(kf[0][1]), "a"(qf[1][1]), "v"(sacc[0][1][2]), "v"(sacc[0][1][3]), "v"(kf[0][2]), "a"(qf[1][2]), "v"(sacc[0][1][4]), "v"(sacc[0][1][5]), "v"(kf[0][3]), "a"(qf[1][3]), "v"(sacc[0][1][6]), "v"(sacc[0][1][7]), "v"(kf[1][0]), "v"(sacc[0][1][8]), "v"(sacc[0][1][9]), "v"(kf[1][1]), "v"(sacc[0][1][10]), "v"(sacc[0][1][11]), "v"(kf[1][2]), "v"(sacc[0][1][12]), "v"(sacc[0][1][13]), "v"(kf[1][3]), "v"(sacc[0][1][14]), "v"(sacc[0][1][15]) : "memory"); pf[0][2][0] = w2_0; pf[0][2][1] = w2_1; pf[0][2][2] = w2_2; pf[0][2][3] = w2_3; pf[0][3][0] = w3_0; pf[0][3][1] = w3_1; pf[0][3][2] = w3_2; pf[0][3][3] = w3_3; }
+            MASKPAD(sacc[1][0], 0);
+            { const u32x4 vv0_0 = {vh[0][0][0][0], vh[0][0][0][1], vh[0][0][1][0], vh[0][0][1][1]}; const u32x4 vv1_0 = {vh[1][0][0][0], vh[1][0][0][1], vh[1][0][1][0], vh[1][0][1][1]}; const u32x4 vv0_1 = {vh[0][1][0][0], vh[0][1][0][1], vh[0][1][1][0], vh[0][1][1][1]}; const u32x4 vv1_1 = {vh[1][1][0][0], vh[1][1][0][1], vh[1][1][1][0], vh[1][1][1][1]}; const u32x4 vv0_2 = {vh[0][2][0][0], vh[0][2][0][1], vh[0][2][1][0], vh[0][2][1][1]}; const u32x4 vv1_2 = {vh[1][2][0][0], vh[1][2][0][1], vh[1][2][1][0], vh[1][2][1][1]}; const u32x4 vv0_3 = {vh[0][3][0][0], vh[0][3][0][1], vh[0][3][1][0], vh[0][3][1][1]}; const u32x4 vv1_3 = {vh[1][3][0][0], vh[1][3][0][1], vh[1][3][1][0], vh[1][3][1][1]}; float t0_0; float t0_1; float t0_2; float t0_3; float t0_4; float t0_5; float t0_6; float t0_7; float t0_8; float t0_9; float t0_10; float t0_11; float t0_12; float t0_13; float t0_14; float t0_15; uint32_t w0_0; uint32_t w0_1; uint32_t w0_2; uint32_t w0_3; uint32_t w1_0; uint32_t w1_1; uint32_t w1_2; uint32_t w1_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, %0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %3, %32, %29, %3\n\tv_exp_f32 %4, %33\n\tv_add_f32 %6, %6, %1\n\tv_exp_f32 %5, %34\n\tv_add_f32 %7, %7, %2\n\tv_cvt_pk_bf16_f32 %8, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %35, %36, %0\n\tv_exp_f32 %9, %37\n\tv_add_f32 %6, %6, %4\n\tv_exp_f32 %10, %38\n\tv_add_f32 %7, %7, %5\n\tv_cvt_pk_bf16_f32 %11, %4, %5\n\tv_mfma_f32_32x32x16_bf16 %3, %39, %36, %3\n\tv_exp_f32 %12, %40\n\tv_add_f32 %6, %6, %9\n\tv_exp_f32 %13, %41\n\tv_add_f32 %7, %7, %10\n\tv_cvt_pk_bf16_f32 %14, %9, %10\n\tv_mfma_f32_32x32x16_bf16 %0, %42, %43, %0\n\tv_exp_f32 %15, %44\n\tv_add_f32 %6, %6, %12\n\tv_exp_f32 %16, %45\n\tv_add_f32 %7, %7, %13\n\tv_cvt_pk_bf16_f32 %17, %12, %13\n\tv_mfma_f32_32x32x16_bf16 %3, %46, %43, %3\n\tv_exp_f32 %18, %47\n\tv_add_f32 %6, %6, %15\n\tv_exp_f32 %19, %48\n\tv_add_f32 %7, %7, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %0, %49, %50, %0\n\tv_exp_f32 %21, %51\n\tv_add_f32 %6, %6, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %7, %7, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %3, %53, %50, %3\n\tv_exp_f32 %24, %54\n\tv_add_f32 %6, %6, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %7, %7, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %6, %6, %24\n\tv_add_f32 %7, %7, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "+a"(oacc[0][0]), "=&v"(t0_0), "=&v"(t0_1), "+a"(oacc[0][1]), "=&v"(t0_2), "=&v"(t0_3), "+v"(psum[1][0]), "+v"(psum[1][1]), "=&v"(w0_0), "=&v"(t0_4), "=&v"(t0_5), "=&v"(w0_1), "=&v"(t0_6), "=&v"(t0_7), "=&v"(w0_2), "=&v"(t0_8), "=&v"(t0_9), "=&v"(w0_3), "=&v"(t0_10), "=&v"(t0_11), "=&v"(w1_0), "=&v"(t0_12), "=&v"(t0_13), "=&v"(w1_1), "=&v"(t0_14), "=&v"(t0_15), "=&v"(w1_2), "=&v"(w1_3) : "v"(vv0_0), "v"(pf[0][0]), "v"(sacc[1][0][0]), "v"(sacc[1][0][1]), "v"(vv1_0), "v"(sacc[1][0][2]), "v"(sacc[1][0][3]), "v"(vv0_1), "v"(pf[0][1]), "v"(sacc[1][0][4]), "v"(sacc[1][0][5]), "v"(vv1_1), "v"(sacc[1][0][6]), "v"(sacc[1][0][7]), "v"(vv0_2), "v"(pf[0][2]), "v"(sacc[1][0][8]), "v"(sacc[1][0][9]), "v"(vv1_2), "v"(sacc[1][0][10]), "v"(sacc[1][0][11]), "v"(vv0_3), "v"(pf[0][3]), "v"(sacc[1][0][12]), "v"(sacc[1][0][13]), "v"(vv1_3), "v"(sacc[1][0][14]), "v"(sacc[1][0][15]) : "memory"); pf[1][0][0] = w0_0; pf[1][0][1] = w0_1; pf[1][0][2] = w0_2; pf[1][0][3] = w0_3; pf[1][1][0] = w1_0; pf[1][1][1] = w1_1; pf[1][1][2] = w1_2; pf[1][1][3] = w1_3; }
+            MASKPAD(sacc[1][1], 32);
+            // period 2: QK_2 | PV_1
+            { float t1_0; float t1_1; float t1_2; float t1_3; float t1_4; float t1_5; float t1_6; float t1_7; float t1_8; float t1_9; float t1_10; float t1_11; float t1_12; float t1_13; float t1_14; float t1_15; uint32_t w2_0; uint32_t w2_1; uint32_t w2_2; uint32_t w2_3; uint32_t w3_0; uint32_t w3_1; uint32_t w3_2; uint32_t w3_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, 0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %0, %32, %33, %0\n\tv_exp_f32 %3, %34\n\tv_add_f32 %5, %5, %1\n\tv_exp_f32 %4, %35\n\tv_add_f32 %6, %6, %2\n\tv_cvt_pk_bf16_f32 %7, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %36, %37, %0\n\tv_exp_f32 %8, %38\n\tv_add_f32 %5, %5, %3\n\tv_exp_f32 %9, %39\n\tv_add_f32 %6, %6, %4\n\tv_cvt_pk_bf16_f32 %10, %3, %4\n\tv_mfma_f32_32x32x16_bf16 %0, %40, %41, %0\n\tv_exp_f32 %11, %42\n\tv_add_f32 %5, %5, %8\n\tv_exp_f32 %12, %43\n\tv_add_f32 %6, %6, %9\n\tv_cvt_pk_bf16_f32 %13, %8, %9\n\tv_mfma_f32_32x32x16_bf16 %14, %44, %29, 0\n\tv_exp_f32 %15, %45\n\tv_add_f32 %5, %5, %11\n\tv_exp_f32 %16, %46\n\tv_add_f32 %6, %6, %12\n\tv_cvt_pk_bf16_f32 %17, %11, %12\n\tv_mfma_f32_32x32x16_bf16 %14, %47, %33, %14\n\tv_exp_f32 %18, %48\n\tv_add_f32 %5, %5, %15\n\tv_exp_f32 %19, %49\n\tv_add_f32 %6, %6, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %14, %50, %37, %14\n\tv_exp_f32 %21, %51\n\tv_add_f32 %5, %5, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %6, %6, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %14, %53, %41, %14\n\tv_exp_f32 %24, %54\n\tv_add_f32 %5, %5, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %6, %6, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %5, %5, %24\n\tv_add_f32 %6, %6, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "=&v"(sacc[0][0]), "=&v"(t1_0), "=&v"(t1_1), "=&v"(t1_2), "=&v"(t1_3), "+v"(psum[1][0]), "+v"(psum[1][1]), "=&v"(w2_0), "=&v"(t1_4), "=&v"(t1_5), "=&v"(w2_1), "=&v"(t1_6), "=&v"(t1_7), "=&v"(w2_2), "=&v"(sacc[0][1]), "=&v"(t1_8), "=&v"(t1_9), "=&v"(w2_3), "=&v"(t1_10), "=&v"(t1_11), "=&v"(w3_0), "=&v"(t1_12), "=&v"(t1_13), "=&v"(w3_1), "=&v"(t1_14), "=&v"(t1_15), "=&v"(w3_2), "=&v"(w3_3) : "v"(kf[0][0]), "a"(qf[2][0]), "v"(sacc[1][1][0]), "v"(sacc[1][1][1]), "v"(kf[0][1]), "a"(qf[2][1]), "v"(sacc[1][1][2]), "v"(sacc[1][1][3]), "v"(kf[0][2]), "a"(qf[2][2]), "v"(sacc[1][1][4]), "v"(sacc[1][1][5]), "v"(kf[0][3]), "a"(qf[2][3]), "v"(sacc[1][1][6]), "v"(sacc[1][1][7]), "v"(kf[1][0]), "v"(sacc[1][1][8]), "v"(sacc[1][1][9]), "v"(kf[1][1]), "v"(sacc[1][1][10]), "v"(sacc[1][1][11]), "v"(kf[1][2]), "v"(sacc[1][1][12]), "v"(sacc[1][1][13]), "v"(kf[1][3]), "v"(sacc[1][1][14]), "v"(sacc[1][1][15]) : "memory"); pf[1][2][0] = w2_0; pf[1][2][1] = w2_1; pf[1][2][2] = w2_2; pf[1][2][3] = w2_3; pf[1][3][0] = w3_0; pf[1][3][1] = w3_1; pf[1][3][2] = w3_2; pf[1][3][3] = w3_3; }
+            MASKPAD(sacc[0][0], 0);
+            { const u32x4 vv0_0 = {vh[0][0][0][0], vh[0][0][0][1], vh[0][0][1][0], vh[0][0][1][1]}; const u32x4 vv1_0 = {vh[1][0][0][0], vh[1][0][0][1], vh[1][0][1][0], vh[1][0][1][1]}; const u32x4 vv0_1 = {vh[0][1][0][0], vh[0][1][0][1], vh[0][1][1][0], vh[0][1][1][1]}; const u32x4 vv1_1 = {vh[1][1][0][0], vh[1][1][0][1], vh[1][1][1][0], vh[1][1][1][1]}; const u32x4 vv0_2 = {vh[0][2][0][0], vh[0][2][0][1], vh[0][2][1][0], vh[0][2][1][1]}; const u32x4 vv1_2 = {vh[1][2][0][0], vh[1][2][0][1], vh[1][2][1][0], vh[1][2][1][1]}; const u32x4 vv0_3 = {vh[0][3][0][0], vh[0][3][0][1], vh[0][3][1][0], vh[0][3][1][1]}; const u32x4 vv1_3 = {vh[1][3][0][0], vh[1][3][0][1], vh[1][3][1][0], vh[1][3][1][1]}; float t0_0; float t0_1; float t0_2; float t0_3; float t0_4; float t0_5; float t0_6; float t0_7; float t0_8; float t0_9; float t0_10; float t0_11; float t0_12; float t0_13; float t0_14; float t0_15; uint32_t w0_0; uint32_t w0_1; uint32_t w0_2; uint32_t w0_3; uint32_t w1_0; uint32_t w1_1; uint32_t w1_2; uint32_t w1_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, %0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %3, %32, %29, %3\n\tv_exp_f32 %4, %33\n\tv_add_f32 %6, %6, %1\n\tv_exp_f32 %5, %34\n\tv_add_f32 %7, %7, %2\n\tv_cvt_pk_bf16_f32 %8, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %35, %36, %0\n\tv_exp_f32 %9, %37\n\tv_add_f32 %6, %6, %4\n\tv_exp_f32 %10, %38\n\tv_add_f32 %7, %7, %5\n\tv_cvt_pk_bf16_f32 %11, %4, %5\n\tv_mfma_f32_32x32x16_bf16 %3, %39, %36, %3\n\tv_exp_f32 %12, %40\n\tv_add_f32 %6, %6, %9\n\tv_exp_f32 %13, %41\n\tv_add_f32 %7, %7, %10\n\tv_cvt_pk_bf16_f32 %14, %9, %10\n\tv_mfma_f32_32x32x16_bf16 %0, %42, %43, %0\n\tv_exp_f32 %15, %44\n\tv_add_f32 %6, %6, %12\n\tv_exp_f32 %16, %45\n\tv_add_f32 %7, %7, %13\n\tv_cvt_pk_bf16_f32 %17, %12, %13\n\tv_mfma_f32_32x32x16_bf16 %3, %46, %43, %3\n\tv_exp_f32 %18, %47\n\tv_add_f32 %6, %6, %15\n\tv_exp_f32 %19, %48\n\tv_add_f32 %7, %7, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %0, %49, %50, %0\n\tv_exp_f32 %21, %51\n\tv_add_f32 %6, %6, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %7, %7, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %3, %53, %50, %3\n\tv_exp_f32 %24, %54\n\tv_add_f32 %6, %6, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %7, %7, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %6, %6, %24\n\tv_add_f32 %7, %7, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "+a"(oacc[1][0]), "=&v"(t0_0), "=&v"(t0_1), "+a"(oacc[1][1]), "=&v"(t0_2), "=&v"(t0_3), "+v"(psum[2][0]), "+v"(psum[2][1]), "=&v"(w0_0), "=&v"(t0_4), "=&v"(t0_5), "=&v"(w0_1), "=&v"(t0_6), "=&v"(t0_7), "=&v"(w0_2), "=&v"(t0_8), "=&v"(t0_9), "=&v"(w0_3), "=&v"(t0_10), "=&v"(t0_11), "=&v"(w1_0), "=&v"(t0_12), "=&v"(t0_13), "=&v"(w1_1), "=&v"(t0_14), "=&v"(t0_15), "=&v"(w1_2), "=&v"(w1_3) : "v"(vv0_0), "v"(pf[1][0]), "v"(sacc[0][0][0]), "v"(sacc[0][0][1]), "v"(vv1_0), "v"(sacc[0][0][2]), "v"(sacc[0][0][3]), "v"(vv0_1), "v"(pf[1][1]), "v"(sacc[0][0][4]), "v"(sacc[0][0][5]), "v"(vv1_1), "v"(sacc[0][0][6]), "v"(sacc[0][0][7]), "v"(vv0_2), "v"(pf[1][2]), "v"(sacc[0][0][8]), "v"(sacc[0][0][9]), "v"(vv1_2), "v"(sacc[0][0][10]), "v"(sacc[0][0][11]), "v"(vv0_3), "v"(pf[1][3]), "v"(sacc[0][0][12]), "v"(sacc[0][0][13]), "v"(vv1_3), "v"(sacc[0][0][14]), "v"(sacc[0][0][15]) : "memory"); pf[0][0][0] = w0_0; pf[0][0][1] = w0_1; pf[0][0][2] = w0_2; pf[0][0][3] = w0_3; pf[0][1][0] = w1_0; pf[0][1][1] = w1_1; pf[0][1][2] = w1_2; pf[0][1][3] = w1_3; }
+            MASKPAD(sacc[0][1], 32);
+            // period 3: QK_3 | PV_2
+            { float t1_0; float t1_1; float t1_2; float t1_3; float t1_4; float t1_5; float t1_6; float t1_7; float t1_8; float t1_9; float t1_10; float t1_11; float t1_12; float t1_13; float t1_14; float t1_15; uint32_t w2_0; uint32_t w2_1; uint32_t w2_2; uint32_t w2_3; uint32_t w3_0; uint32_t w3_1; uint32_t w3_2; uint32_t w3_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %28, %29, 0\n\tv_exp_f32 %1, %30\n\tv_exp_f32 %2, %31\n\tv_mfma_f32_32x32x16_bf16 %0, %32, %33, %0\n\tv_exp_f32 %3, %34\n\tv_add_f32 %5, %5, %1\n\tv_exp_f32 %4, %35\n\tv_add_f32 %6, %6, %2\n\tv_cvt_pk_bf16_f32 %7, %1, %2\n\tv_mfma_f32_32x32x16_bf16 %0, %36, %37, %0\n\tv_exp_f32 %8, %38\n\tv_add_f32 %5, %5, %3\n\tv_exp_f32 %9, %39\n\tv_add_f32 %6, %6, %4\n\tv_cvt_pk_bf16_f32 %10, %3, %4\n\tv_mfma_f32_32x32x16_bf16 %0, %40, %41, %0\n\tv_exp_f32 %11, %42\n\tv_add_f32 %5, %5, %8\n\tv_exp_f32 %12, %43\n\tv_add_f32 %6, %6, %9\n\tv_cvt_pk_bf16_f32 %13, %8, %9\n\tv_mfma_f32_32x32x16_bf16 %14, %44, %29, 0\n\tv_exp_f32 %15, %45\n\tv_add_f32 %5, %5, %11\n\tv_exp_f32 %16, %46\n\tv_add_f32 %6, %6, %12\n\tv_cvt_pk_bf16_f32 %17, %11, %12\n\tv_mfma_f32_32x32x16_bf16 %14, %47, %33, %14\n\tv_exp_f32 %18, %48\n\tv_add_f32 %5, %5, %15\n\tv_exp_f32 %19, %49\n\tv_add_f32 %6, %6, %16\n\tv_cvt_pk_bf16_f32 %20, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %14, %50, %37, %14\n\tv_exp_f32 %21, %51\n\tv_add_f32 %5, %5, %18\n\tv_exp_f32 %22, %52\n\tv_add_f32 %6, %6, %19\n\tv_cvt_pk_bf16_f32 %23, %18, %19\n\tv_mfma_f32_32x32x16_bf16 %14, %53, %41, %14\n\tv_exp_f32 %24, %54\n\tv_add_f32 %5, %5, %21\n\tv_exp_f32 %25, %55\n\tv_add_f32 %6, %6, %22\n\tv_cvt_pk_bf16_f32 %26, %21, %22\n\tv_add_f32 %5, %5, %24\n\tv_add_f32 %6, %6, %25\n\tv_cvt_pk_bf16_f32 %27, %24, %25" : "=&v"(sacc[1][0]), "=&v"(t1_0), "=&v"(t1_1), "=&v"(t1_2), "=&v"(t1_3), "+v"(psum[2][0]), "+v"(psum[2][1]), "=&v"(w2_0), "=&v"(t1_4), "=&v"(t1_5), "=&v"(w2_1), "=&v"(t1_6), "=&v"(t1_7), "=&v"(w2_2), "=&v"(sacc[1][1]), "=&v"(t1_8), "=&v"(t1_9), "=&v"(w2_3), "=&v"(t1_10), "=&v"(t1_11), "=&v"(w3_0), "=&v"(t1_12), "=&v"(t1_13), "=&v"(w3_1), "=&v"(t1_14), "=&v"(t1_15), "=&v"(w3_2), "=&v"(w3_3) : "v"(kf[0][0]), "a"(qf[3][0]), "v"(sacc[0][1][0]), "v"(sacc[0][1][1]), "v"(kf[0][1]), "a"(qf[3][1]), "v"(sacc[0][1][2]), "v"(sacc[0][1][3]), "v"(kf[0][2]), "a"(qf[3][2]), "v"(sacc[0][1][4]), "v"(sacc[0][1][5]), "v"(kf[0][3]), "a"(qf[3][3]), "v"(sacc[0][1][6]), "v"(sacc[0][1][7]), "v"(kf[1][0]), "v"(sacc[0][1][8]), "v"(sacc[0][1][9]), "v"(kf[1][1]), "v"(sacc[0][1][10]), "v"(sacc[0][1][11]), "v"(kf[1][2]), "v"(sacc[0][1][12]), "v"(sacc[0][1][13]), "v"(kf[1][3]), "v"(sacc[0][1][14]), "v"(sacc[0][1][15]) : "memory"); pf[0][2][0] = w2_0; pf[0][2][1] = w2_1; pf[0][2][2] = w2_2; pf[0][2][3] = w2_3; pf[0][3][0] = w3_0; pf[0][3][1] = w3_1; pf[0][3][2] = w3_2; pf[0][3][3] = w3_3; }
+            MASKPAD(sacc[1][0], 0);
+            { const u32x4 vv0_0 = {vh[0][0][0][0], vh[0][0][0][1], vh[0][0][1][0], vh[0][0][1][1]}; const u32x4 vv1_0 = {vh[1][0][0][0], vh[1][0][0][1], vh[1][0][1][0], vh[1][0][1][1]}; const u32x4 vv0_1 = {vh[0][1][0][0], vh[0][1][0][1], vh[0][1][1][0], vh[0][1][1][1]}; const u32x4 vv1_1 = {vh[1][1][0][0], vh[1][1][0][1], vh[1][1][1][0], vh[1][1][1][1]}; const u32x4 vv0_2 = {vh[0][2][0][0], vh[0][2][0][1], vh[0][2][1][0], vh[0][2][1][1]}; const u32x4 vv1_2 = {vh[1][2][0][0], vh[1][2][0][1], vh[1][2][1][0], vh[1][2][1][1]}; const u32x4 vv0_3 = {vh[0][3][0][0], vh[0][3][0][1], vh[0][3][1][0], vh[0][3][1][1]}; const u32x4 vv1_3 = {vh[1][3][0][0], vh[1][3][0][1], vh[1][3][1][0], vh[1][3][1][1]}; const uint32_t dma_dst0 = dma_dst + 0 + 0 * TILE_BYTES; const uint32_t dma_dst1 = dma_dst + 1024 + 0 * TILE_BYTES; const uint32_t dma_dst2 = dma_dst + 0 + 1 * TILE_BYTES; const uint32_t dma_dst3 = dma_dst + 1024 + 1 * TILE_BYTES; float t0_0; float t0_1; float t0_2; float t0_3; float t0_4; float t0_5; float t0_6; float t0_7; float t0_8; float t0_9; float t0_10; float t0_11; float t0_12; float t0_13; float t0_14; float t0_15; uint32_t w0_0; uint32_t w0_1; uint32_t w0_2; uint32_t w0_3; uint32_t w1_0; uint32_t w1_1; uint32_t w1_2; uint32_t w1_3; asm volatile("v_mfma_f32_32x32x16_bf16 %0, %36, %37, %0\n\ts_waitcnt vmcnt(4)\n\ts_barrier\n\tds_read_b128 %1, %38 offset:0\n\tds_read_b128 %2, %39 offset:0\n\tv_exp_f32 %3, %40\n\tv_exp_f32 %4, %41\n\tv_mfma_f32_32x32x16_bf16 %5, %42, %37, %5\n\tds_read_b128 %6, %43 offset:0\n\tds_read_b128 %7, %44 offset:0\n\tv_exp_f32 %8, %45\n\tv_add_f32 %10, %10, %3\n\tv_exp_f32 %9, %46\n\tv_add_f32 %11, %11, %4\n\tv_cvt_pk_bf16_f32 %12, %3, %4\n\tv_mfma_f32_32x32x16_bf16 %0, %47, %48, %0\n\tds_read_b128 %13, %38 offset:4096\n\tds_read_b128 %14, %39 offset:4096\n\tv_exp_f32 %15, %49\n\tv_add_f32 %10, %10, %8\n\tv_exp_f32 %16, %50\n\tv_add_f32 %11, %11, %9\n\tv_cvt_pk_bf16_f32 %17, %8, %9\n\tv_mfma_f32_32x32x16_bf16 %5, %51, %48, %5\n\tds_read_b128 %18, %43 offset:4096\n\tds_read_b128 %19, %44 offset:4096\n\tv_exp_f32 %20, %52\n\tv_add_f32 %10, %10, %15\n\tv_exp_f32 %21, %53\n\tv_add_f32 %11, %11, %16\n\tv_cvt_pk_bf16_f32 %22, %15, %16\n\tv_mfma_f32_32x32x16_bf16 %0, %54, %55, %0\n\ts_mov_b32 m0, %56\n\ts_nop 0\n\tbuffer_load_dwordx4 %57, %58, %59 offen lds\n\tv_exp_f32 %23, %60\n\tv_add_f32 %10, %10, %20\n\tv_exp_f32 %24, %61\n\tv_add_f32 %11, %11, %21\n\tv_cvt_pk_bf16_f32 %25, %20, %21\n\tv_mfma_f32_32x32x16_bf16 %5, %62, %55, %5\n\ts_mov_b32 m0, %63\n\ts_nop 0\n\tbuffer_load_dwordx4 %64, %58, %59 offen lds\n\tv_exp_f32 %26, %65\n\tv_add_f32 %10, %10, %23\n\tv_exp_f32 %27, %66\n\tv_add_f32 %11, %11, %24\n\tv_cvt_pk_bf16_f32 %28, %23, %24\n\tv_mfma_f32_32x32x16_bf16 %0, %67, %68, %0\n\ts_mov_b32 m0, %69\n\ts_nop 0\n\tbuffer_load_dwordx4 %70, %71, %72 offen lds\n\tv_exp_f32 %29, %73\n\tv_add_f32 %10, %10, %26\n\tv_exp_f32 %30, %74\n\tv_add_f32 %11, %11, %27\n\tv_cvt_pk_bf16_f32 %31, %26, %27\n\tv_mfma_f32_32x32x16_bf16 %5, %75, %68, %5\n\ts_mov_b32 m0, %76\n\ts_nop 0\n\tbuffer_load_dwordx4 %77, %71, %72 offen lds\n\tv_exp_f32 %32, %78\n\tv_add_f32 %10, %10, %29\n\tv_exp_f32 %33, %79\n\tv_add_f32 %11, %11, %30\n\tv_cvt_pk_bf16_f32 %34, %29, %30\n\tv_add_f32 %10, %10, %32\n\tv_add_f32 %11, %11, %33\n\tv_cvt_pk_bf16_f32 %35, %32, %33\n\ts_waitcnt lgkmcnt(0)" : "+a"(oacc[2][0]), "=&v"(kf[0][0]), "=&v"(kf[0][1]), "=&v"(t0_0), "=&v"(t0_1), "+a"(oacc[2][1]), "=&v"(kf[0][2]), "=&v"(kf[0][3]), "=&v"(t0_2), "=&v"(t0_3), "+v"(psum[3][0]), "+v"(psum[3][1]), "=&v"(w0_0), "=&v"(kf[1][0]), "=&v"(kf[1][1]), "=&v"(t0_4), "=&v"(t0_5), "=&v"(w0_1), "=&v"(kf[1][2]), "=&v"(kf[1][3]), "=&v"(t0_6), "=&v"(t0_7), "=&v"(w0_2), "=&v"(t0_8), "=&v"(t0_9), "=&v"(w0_3), "=&v"(t0_10), "=&v"(t0_11), "=&v"(w1_0), "=&v"(t0_12), "=&v"(t0_13), "=&v"(w1_1), "=&v"(t0_14), "=&v"(t0_15), "=&v"(w1_2), "=&v"(w1_3) : "v"(vv0_0), "v"(pf[0][0]), "v"(kaddr[0]), "v"(kaddr[1]), "v"(sacc[1][0][0]), "v"(sacc[1][0][1]), "v"(vv1_0), "v"(kaddr[2]), "v"(kaddr[3]), "v"(sacc[1][0][2]), "v"(sacc[1][0][3]), "v"(vv0_1), "v"(pf[0][1]), "v"(sacc[1][0][4]), "v"(sacc[1][0][5]), "v"(vv1_1), "v"(sacc[1][0][6]), "v"(sacc[1][0][7]), "v"(vv0_2), "v"(pf[0][2]), "s"(dma_dst0), "v"(dvo[0]), "s"(rsK), "s"(soffK), "v"(sacc[1][0][8]), "v"(sacc[1][0][9]), "v"(vv1_2), "s"(dma_dst1), "v"(dvo[1]), "v"(sacc[1][0][10]), "v"(sacc[1][0][11]), "v"(vv0_3), "v"(pf[0][3]), "s"(dma_dst2), "v"(dvo[2]), "s"(rsV), "s"(soffV), "v"(sacc[1][0][12]), "v"(sacc[1][0][13]), "v"(vv1_3), "s"(dma_dst3), "v"(dvo[3]), "v"(sacc[1][0][14]), "v"(sacc[1][0][15]) : "memory"); pf[1][0][0] = w0_0; pf[1][0][1] = w0_1; pf[1][0][2] = w0_2; pf[1][0][3] = w0_3; pf[1][1][0] = w1_0; pf[1][1][1] = w1_1; pf[1][1][2] = w1_2; pf[1][1][3] = w1_3; }
+            MASKPAD(sacc[1][1], 32);
         } else if constexpr (VAR == 'T') {
             // period 4: rest of block 3's softmax | PV_3
             { float t1_0; float t1_1; float t1_2; float t1_3; float t1_4; float t1_5; float t1_6; float t1_7; float t1_8; float t1_9; float t1_10; float t1_11; float t1_12; float t1_13; float t1_14; float t1_15; uint32_t w2_0; uint32_t w2_1; uint32_t w2_2; uint32_t w2_3; uint32_t w3_0; uint32_t w3_1; uint32_t w3_2; uint32_t w3_3; asm volatile("v_exp_f32 %0, %26\n\tv_exp_f32 %1, %27\n\tv_exp_f32 %2, %28\n\tv_add_f32 %4, %4, %0\n\tv_exp_f32 %3, %29\n\tv_add_f32 %5, %5, %1\n\tv_cvt_pk_bf16_f32 %6, %0, %1\n\tv_exp_f32 %7, %30\n\tv_add_f32 %4, %4, %2\n\tv_exp_f32 %8, %31\n\tv_add_f32 %5, %5, %3\n\tv_cvt_pk_bf16_f32 %9, %2, %3\n\tv_exp_f32 %10, %32\n\tv_add_f32 %4, %4, %7\n\tv_exp_f32 %11, %33\n\tv_add_f32 %5, %5, %8\n\tv_cvt_pk_bf16_f32 %12, %7, %8\n\tv_exp_f32 %13, %34\n\tv_add_f32 %4, %4, %10\n\tv_exp_f32 %14, %35\n\tv_add_f32 %5, %5, %11\n\tv_cvt_pk_bf16_f32 %15, %10, %11\n\tv_exp_f32 %16, %36\n\tv_add_f32 %4, %4, %13\n\tv_exp_f32 %17, %37\n\tv_add_f32 %5, %5, %14\n\tv_cvt_pk_bf16_f32 %18, %13, %14\n\tv_exp_f32 %19, %38\n\tv_add_f32 %4, %4, %16\n\tv_exp_f32 %20, %39\n\tv_add_f32 %5, %5, %17\n\tv_cvt_pk_bf16_f32 %21, %16, %17\n\tv_exp_f32 %22, %40\n\tv_add_f32 %4, %4, %19\n\tv_exp_f32 %23, %41\n\tv_add_f32 %5, %5, %20\n\tv_cvt_pk_bf16_f32 %24, %19, %20\n\tv_add_f32 %4, %4, %22\n\tv_add_f32 %5, %5, %23\n\tv_cvt_pk_bf16_f32 %25, %22, %23" : "=&v"(t1_0), "=&v"(t1_1), "=&v"(t1_2), "=&v"(t1_3), "+v"(psum[3][0]), "+v"(psum[3][1]), "=&v"(w2_0), "=&v"(t1_4), "=&v"(t1_5), "=&v"(w2_1), "=&v"(t1_6), "=&v"(t1_7), "=&v"(w2_2), "=&v"(t1_8), "=&v"(t1_9), "=&v"(w2_3), "=&v"(t1_10), "=&v"(t1_11), "=&v"(w3_0), "=&v"(t1_12), "=&v"(t1_13), "=&v"(w3_1), "=&v"(t1_14), "=&v"(t1_15), "=&v"(w3_2), "=&v"(w3_3) : "v"(sacc[1][1][0]), "v"(sacc[1][1][1]), "v"(sacc[1][1][2]), "v"(sacc[1][1][3]), "v"(sacc[1][1][4]), "v"(sacc[1][1][5]), "v"(sacc[1][1][6]), "v"(sacc[1][1][7]), "v"(sacc[1][1][8]), "v"(sacc[1][1][9]), "v"(sacc[1][1][10]), "v"(sacc[1][1][11]), "v"(sacc[1][1][12]), "v"(sacc[1][1][13]), "v"(sacc[1][1][14]), "v"(sacc[1][1][15]) : "memory"); pf[1][2][0] = w2_0; pf[1][2][1] = w2_1; pf[1][2][2] = w2_2; pf[1][2][3] = w2_3; pf[1][3][0] = w3_0; pf[1][3][1] = w3_1; pf[1][3][2] = w3_2; pf[1][3][3] = w3_3; }
@@ -323,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
             LGKM(0);
         }
         int st = 0;                                            // ring stage of tile t (= of tile t + 3)
-        for (int t = 0; t < ntiles; ++t) {
+        for (int t = 0; t < ntiles - 1; ++t) {
             const int st1 = st == NST - 1 ? 0 : st + 1;
             uint32_t kaddr[4], vaddr[2];
 #pragma unroll
@@ -335,14 +365,24 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
             st = st1;
         }
         {
+            // the piece's last tile: keys past Skv (only the piece that holds the sequence's last tile has any) masked
+            const int t = ntiles - 1, st1 = st == NST - 1 ? 0 : st + 1;
+            keys_last = skv_left - t * KV_TILE;               // >= 64: every key of the tile exists
+            uint32_t kaddr[4], vaddr[2];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kaddr[s] = kofs[s] + st1 * STAGE_BYTES;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) vaddr[d] = vofs[d] + st * STAGE_BYTES;
+            body(IntTagC<'M'>{}, kaddr, vaddr, lds0s + st * STAGE_BYTES, (uint32_t)(t + 3) * k_tile_stride,
+                 (uint32_t)(t + 3) * v_tile_stride);
+        }
+        {
             const uint32_t none4[4] = {0u, 0u, 0u, 0u}, none2[2] = {0u, 0u};
             body(IntTagC<'T'>{}, none4, none2, 0u, 0u, 0u);
         }
         // the MFMAs are inline asm: pad their last results before compiler code reads them; drain the tail prefetches
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");
 
-        // keys of the LAST tile that do not exist: P = 1 each (only the piece that holds the last tile sees them)
-        const float pad_keys = it.tb + it.nt == it.nt_all ? (float)(it.nt_all * KV_TILE - p.Skv) : 0.f;
         if (SK && it.role == 1) {
             // ---- a suffix piece of a leftover item: hand the un-normalised accumulators and row sums to the item's main
             const int my_slot = it.slot;
@@ -356,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
                         f32x4 w = {oacc[b][d][gq * 4 + 0], oacc[b][d][gq * 4 + 1], oacc[b][d][gq * 4 + 2], oacc[b][d][gq * 4 + 3]};
                         *reinterpret_cast<f32x4*>(slot + ((size_t)(((wave * QB + b) * 2 + d) * 4 + gq) * 64 + lane) * 4) = w;
                     }
-                slot[4 * QB * 2 * 16 * 64 + (wave * QB + b) * 64 + lane] = psum[b][0] + psum[b][1] - 0.5f * pad_keys;
+                slot[4 * QB * 2 * 16 * 64 + (wave * QB + b) * 64 + lane] = psum[b][0] + psum[b][1];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -411,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void attn_joint_w4_kernel(AttnArgs p) {
         for (int b = 0; b < QB; ++b) {
             const float l_half = psum[b][0] + psum[b][1];
             const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_half), __float_as_uint(l_half), false, false);
-            const float inv = 1.0f / (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1]) - pad_keys);
+            const float inv = 1.0f / (__uint_as_float(lsw[0]) + __uint_as_float(lsw[1]));
             bf16_t* orow = Op + (long long)(q_valid[b] ? q0 + b * 32 + r : 0) * p.o_row;
 #pragma unroll
             for (int d = 0; d < 2; ++d) store_o_tile(orow + d * 32, oacc[b][d], inv, hf, q_valid[b], p.o_wide != 0);

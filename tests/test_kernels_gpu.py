@@ -1118,7 +1118,7 @@ def test_attn_static_bound_softmax(ops, dev, S):
     within +-11.6 in exp2 units and the kernel may drop the running maximum (P = exp2(s)).  Must agree with the fp32 softmax
     like the running-max kernel does, including rows whose scores sit far below the bound.  The hand-placed
     one-wave-per-SIMD kernel (csrc/attn_w4.hip, 512 query rows per workgroup) is the only static-bound kernel since round 5.
-    Sizes: fewer keys than one tile (40: the padded keys of the only tile are subtracted from the row sums), ragged tails
+    Sizes: fewer keys than one tile (40: the keys past Skv of the only tile are masked), ragged tails
     (200 = 3 x 64 + 8, 4133), fewer rows than a workgroup holds."""
     H, D = 4, 64
     g = torch.Generator().manual_seed(S)
@@ -1140,6 +1140,36 @@ def test_attn_static_bound_softmax(ops, dev, S):
     out2 = torch.empty_like(out)
     ops.self_attention(q.view(1, S, H * D), k.view(1, S, H * D), v, out2, heads=H, prescaled=True, score_bound=500.0)
     check(out2.view(1, S, H, D).transpose(1, 2), ref, tol=ATTN_TOL, what="unusable bound -> running-max kernel")
+
+
+@pytest.mark.parametrize("S", [200, 1350, 17776])
+def test_attn_static_bound_softmax_is_shift_tolerant(ops, dev, S):
+    """Softmax does not care about a constant added to every score of a row; the static-bound kernel (P = exp2(s), no running
+    maximum) must not either while the scores stay inside its bound.  q = a u + noise, k = -c u + noise puts a constant of
+    about -5 ... -44 (exp2 units) under every score of a head -- what q/k-LayerNorm biases of opposite sign do.  Until round 5
+    the keys past Skv of the last tile counted as P = 1 each and were subtracted from the row sum at the end: rows whose real
+    sum was tiny lost it in that subtraction (16 + 1e-9 - 16).  They are masked to -inf now.  Every S here leaves a ragged last
+    tile (8, 6 and 48 keys)."""
+    H, D = 4, 64
+    g = torch.Generator().manual_seed(7 * S + 1)
+    u = torch.randn(D, generator=g)
+    u = u / u.norm()
+    k_scale = D ** -0.5 * 1.4426950408889634
+    off = torch.tensor([3.0, 6.0, 9.0, 0.0]).view(1, 1, H, 1)                      # head 3: no offset (the ordinary case)
+    q32 = off * u + torch.randn(1, S, H, D, generator=g) * 0.5
+    k32 = -off * u * 3.0 + torch.randn(1, S, H, D, generator=g) * 0.5
+    q, k = bf(q32).to(dev), bf(k32 * k_scale).to(dev)
+    v = rnd((1, S, H * D), dev, 5)
+    qf, kf, vf = (t_.float().view(1, S, H, D).transpose(1, 2) for t_ in (q, k, v))
+    scores = qf @ kf.transpose(-1, -2)
+    assert scores[0, 2].max().item() < -20 and scores.abs().max().item() < 85, (scores[0, 2].max().item(), scores.abs().max().item())
+    ref = torch.softmax(scores * math.log(2.0), dim=-1) @ vf
+    out = torch.empty(1, S, H * D, dtype=torch.bfloat16, device=dev)
+    ops.ATTN_VARIANTS.clear()
+    ops.self_attention(q.view(1, S, H * D), k.view(1, S, H * D), v, out, heads=H, prescaled=True, score_bound=88.0)
+    assert [v for (_, v) in ops.ATTN_VARIANTS] == ["d64_static_bound_w4"], ops.ATTN_VARIANTS
+    for h in range(H):
+        check(out.view(1, S, H, D).transpose(1, 2)[:, h], ref[:, h], tol=ATTN_TOL, what=f"shifted scores S={S} head {h}")
 
 
 @pytest.mark.parametrize("S,H", [(17776, 48), (5000, 16), (33976, 8), (17776, 12)])

@@ -28,8 +28,11 @@ are kept by construction: an exp result is consumed >= 3 instructions later, a P
 score >= 4 MFMAs after the MFMA that finished it.  Every output is early-clobber: an LDS read lands asynchronously, it
 must not share a register with anything the statement still reads.
 
-Variants: 'L' = the loop body (one tile); 'T' = the tail behind the last tile (the u = 1 half of block 3's softmax, then
-PV_3).  Edit the tables, run the script: it rewrites the block between the GENERATED markers of csrc/attn_w4.hip;
+Variants: 'L' = the loop body (one tile); 'M' = the same stream for the LAST tile of a piece, with the scores of keys that do
+not exist (rows past Skv: zeros in LDS) set to -inf between the statements -- MASKPAD(half, first key of the half), compiler
+code: the u = 0 half of block b behind QK_b (its last MFMA is four MFMAs old by then), the u = 1 half behind PV_{b-1} (eight
+MFMAs later), each before the softmax that reads it; 'T' = the tail behind the last tile (the u = 1 half of block 3's softmax,
+then PV_3).  Edit the tables, run the script: it rewrites the block between the GENERATED markers of csrc/attn_w4.hip;
 --check verifies the committed source is what the tables generate (tests/test_abi_cpu.py).
 """
 import os
@@ -205,12 +208,16 @@ def group_b(variant, b):
 
 def emit():
     lines = []
-    for v in "LT":
+    for v in "LMT":
         lines.append(f"        {'if' if v == 'L' else '} else if'} constexpr (VAR == '{v}') {{")
-        for b in (range(4) if v == "L" else [4]):
-            lines.append(f"            // period {b}: " + (f"QK_{b} | PV_{(b - 1) % 4}" if v == "L" else "rest of block 3's softmax | PV_3"))
-            lines.append(group_a(v, b).render("            "))
-            lines.append(group_b(v, b).render("            "))
+        for b in (range(4) if v in "LM" else [4]):
+            lines.append(f"            // period {b}: " + (f"QK_{b} | PV_{(b - 1) % 4}" if v in "LM" else "rest of block 3's softmax | PV_3"))
+            lines.append(group_a("L" if v == "M" else v, b).render("            "))
+            if v == "M":
+                lines.append(f"            MASKPAD(sacc[{b & 1}][0], 0);")
+            lines.append(group_b("L" if v == "M" else v, b).render("            "))
+            if v == "M":
+                lines.append(f"            MASKPAD(sacc[{b & 1}][1], 32);")
     lines.append("        }")
     return "\n".join(lines)
 
