@@ -1,5 +1,5 @@
 """The bench.py contract (one JSON line; metric / config of BASELINE.json; roofline and cpu_baseline objects) checked on the
-committed output of the end-of-round run (profiles/r5_zzz_bench.json = stdout of ``python bench.py --steps 10 --warmup 3``
+committed output of the end-of-round run (profiles/r5_final_bench.json = stdout of ``python bench.py --steps 10 --warmup 3``
 on an MI355X) and on the script's command line, without a GPU."""
 import json
 import os
@@ -17,7 +17,7 @@ def _line(path):
 
 def test_committed_bench_line_meets_the_contract():
     import glob
-    d = _line(os.path.join(ROOT, "profiles", "r5_zzz_bench.json"))                             # the end-of-round line of round 5
+    d = _line(os.path.join(ROOT, "profiles", "r5_final_bench.json"))                             # the end-of-round line of round 5
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     # BASELINE.json: "denoise-steps/sec + latent frames/sec, 49x480x720 bf16, 1/2/4/8 MI355X"
     assert base["metric"].startswith(d["metric"]) and d["unit"] == "steps/s" and "latent_frames_per_sec" in d
