@@ -152,3 +152,51 @@ def test_cfg_split(world):
     ret = mgr.dict()
     mp.spawn(_cfg_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+def _ladder_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        from bind_your_avatar_implementation_amd.parallel import shard_sequence
+
+        class Model(torch.nn.Module):             # what shard_sequence touches of the transformer
+            def __init__(self):
+                super().__init__()
+                self.w = torch.nn.Parameter(torch.zeros(1))
+                self.invalidated = 0
+
+            def invalidate_engine(self):
+                self.invalidated += 1
+        m = Model()
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            shard_sequence(m, dist.group.WORLD, transport="p2p")
+        # no GPU here: both P2P rungs fail at set-up ON EVERY RANK, the ranks agree and land on the collectives together
+        assert m._seq_transport == "torch" and m._seq_p2p is None and m._seq_world == world and m._seq_rank == rank
+        assert len(m._seq_transport_notes) == 2 and m._seq_transport_notes[0].startswith("p2p:")
+        assert m._seq_transport_notes[1].startswith("p2p-fine:") and m.invalidated == 1
+        assert any("running on 'torch'" in str(w.message) for w in caught)
+        # the collectives still work afterwards (no rank is left inside a half-finished set-up collective)
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        assert t.item() == world * (world + 1) / 2
+        shard_sequence(m, dist.group.WORLD, transport="torch")
+        assert m._seq_transport == "torch" and m._seq_transport_notes == [] and m.invalidated == 2
+        with pytest.raises(ValueError):
+            shard_sequence(m, dist.group.WORLD, transport="carrier pigeon")
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transport_ladder_walks_down_together_without_a_gpu():
+    """shard_sequence's ladder p2p -> p2p-fine -> torch (bench.py --gpus N relies on it): where the P2P
+    engine cannot be set up -- here: no GPU at all -- every rank records why, all ranks agree, and the model runs on
+    torch.distributed collectives."""
+    world, port = 2, 33100 + (os.getpid() % 1500)
+    ret = mp.Manager().dict()
+    mp.spawn(_ladder_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}
