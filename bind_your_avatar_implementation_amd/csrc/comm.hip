@@ -132,9 +132,18 @@ std::atomic<long long> g_wait_limit_ticks{30ll * 100000000ll};          // s_mem
 // the copy loop of one workgroup.  A table entry is a 2-D piece: `rows` rows of `row_bytes` bytes, `src_pitch` / `dst_pitch`
 // bytes apart (a contiguous piece is one row).  Its chunks: a row longer than P2P_CHUNK is cut into P2P_CHUNK-byte chunks
 // (chunks_per_row > 1, one row per chunk); shorter rows are grouped, rows_per_chunk = P2P_CHUNK / row_bytes of them per chunk.
-__device__ __forceinline__ void p2p_copy_chunks(const bya_p2p_copy* __restrict__ copies, int n_copies, long long total_chunks) {
+// Order: the host's tables list the pieces peer by peer, so chunk index ~ destination.  Walking the chunks in index order would
+// have every workgroup store to the SAME peer at any moment -- one xGMI link busy, six idle (the links are point to point).
+// The walk therefore goes down the columns of a [world x ceil(chunks / world)] arrangement of the chunk indices: consecutive
+// iterations -- what the workgroups of the grid work on at the same time -- are about one peer's share apart, and rank r
+// starts with the share of peer r + 1, so that the ranks do not all open on peer 0's ingress either.
+__device__ __forceinline__ void p2p_copy_chunks(const bya_p2p_copy* __restrict__ copies, int n_copies, long long total_chunks, int world,
+                                                int rank) {
     const int tid = threadIdx.x;
-    for (long long c = blockIdx.x; c < total_chunks; c += gridDim.x) {
+    const long long share = (total_chunks + world - 1) / world, walk = share * world;
+    for (long long it = blockIdx.x; it < walk; it += gridDim.x) {
+        const long long c = ((it + rank + 1) % world) * share + it / world;
+        if (c >= total_chunks) continue;
         int i = 0;
         while (i + 1 < n_copies && copies[i + 1].chunk0 <= c) ++i;               // <= ~100 entries: a linear scan
         const bya_p2p_copy e = copies[i];
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256) void p2p_push_kernel(const bya_p2p_copy* __res
     const int tid = threadIdx.x;
     unsigned expect = 0;
     if (WAIT) expect = __hip_atomic_load(ctrl + P2P_EXPECT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;   // (before anybody can advance it)
-    p2p_copy_chunks(copies, n_copies, total_chunks);
+    p2p_copy_chunks(copies, n_copies, total_chunks, world, rank);
     __threadfence_system();
     __syncthreads();
     if (tid == 0) {

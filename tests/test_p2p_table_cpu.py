@@ -24,16 +24,24 @@ class _FakeGroup:
         return [p2p._Peer(t.data_ptr(), t.shape, t.dtype, t) for t in self._bufs[name]]
 
 
-def run_table(table, n_rows, total_chunks, grid, mem):
-    """p2p_copy_chunks: workgroup b takes chunks b, b + grid, ...; `mem` maps an address to (numpy byte array, base address)."""
+def run_table(table, n_rows, total_chunks, grid, mem, world=1, rank=0):
+    """p2p_copy_chunks: workgroup b takes iterations b, b + grid, ... of the walk down the columns of a [world x share]
+    arrangement of the chunk indices (consecutive iterations = different peers' shares; rank r opens on peer r + 1);
+    `mem` maps an address to (numpy byte array, base address)."""
     def view(addr, n):
         for arr, base in mem:
             if base <= addr and addr + n <= base + arr.size:
                 return arr[addr - base:addr - base + n]
         raise AssertionError(f"address {addr:#x} + {n} outside every buffer")
     rows = table.tolist()
+    share = -(-total_chunks // world)
+    seen = []
     for b in range(grid):
-        for c in range(b, total_chunks, grid):
+        for it in range(b, share * world, grid):
+            c = ((it + rank + 1) % world) * share + it // world
+            if c >= total_chunks:
+                continue
+            seen.append(c)
             i = 0
             while i + 1 < n_rows and rows[i + 1][6] <= c:
                 i += 1
@@ -55,10 +63,30 @@ def run_table(table, n_rows, total_chunks, grid, mem):
                 d = view(dst + (r0 + r) * dp + col0, n)
                 d += 1                                                  # count the writes of every byte ...
                 view(dst + (r0 + r) * dp + col0 + (1 << 40), n)[:] = view(src + (r0 + r) * sp + col0, n)     # ... and copy (shadow)
+    assert sorted(seen) == list(range(total_chunks))                    # the walk is a permutation of the chunks
+    return seen
 
 
-@pytest.mark.parametrize("grid", [1, 7, 64])
-def test_copy_table_covers_every_byte_once(grid):
+def test_chunk_walk_spreads_concurrent_workgroups_over_the_peers():
+    """What the 64 workgroups of a push work on at the same time must not all go to one peer (xGMI links are point to point):
+    with pieces listed peer by peer -- the layout of every table the engine builds -- the first `world` iterations of the
+    walk land in `world` different peers' shares, starting with peer rank + 1."""
+    world, per_peer = 8, 81                                  # the packed q|k|v exchange of an 8-rank step: 81 chunks per peer
+    total = world * per_peer
+    for rank in (0, 3, 7):
+        share = -(-total // world)
+        first = [(((it + rank + 1) % world) * share + it // world) // per_peer for it in range(64)]
+        assert first[:world] == [(rank + 1 + j) % world for j in range(world)]
+        assert all(first.count(pr) == 8 for pr in range(world))          # 64 workgroups: 8 on every link
+    # ragged totals: still a permutation
+    for total, world in ((1, 8), (5, 8), (17, 4), (640, 8), (641, 8), (100, 3)):
+        share = -(-total // world)
+        cs = [((it + 2) % world) * share + it // world for it in range(share * world)]
+        assert sorted(c for c in cs if c < total) == list(range(total))
+
+
+@pytest.mark.parametrize("grid,world,rank", [(1, 1, 0), (7, 2, 1), (64, 8, 5), (64, 2, 0)])
+def test_copy_table_covers_every_byte_once(grid, world, rank):
     torch.manual_seed(0)
     P, L, F = 5, 37, 96                                    # pairs x locations x features: row = 96 bf16 = 192 bytes
     xa = torch.randn(P, L, F).to(torch.bfloat16)
@@ -86,7 +114,7 @@ def test_copy_table_covers_every_byte_once(grid):
         mem.append((counts, t.data_ptr()))
         mem.append((shadow, t.data_ptr() + (1 << 40)))
         shadows.append((t, counts, shadow))
-    run_table(table, n, total_chunks, grid, mem)
+    run_table(table, n, total_chunks, grid, mem, world, rank)
 
     def got(t):
         for tt, counts, shadow in shadows:
