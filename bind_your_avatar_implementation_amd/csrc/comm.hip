@@ -126,6 +126,9 @@ constexpr int P2P_CTRL_WORDS = 64;                   // per channel: [0..31] fla
 constexpr int P2P_SENT = 32, P2P_EXPECT = 33, P2P_DONE = 34, P2P_TIMEOUTS = 35, P2P_WAITED = 36;   // [34] push workgroups done,
                                                                                                    // [35] time-outs, [36] wait workgroups done
 constexpr int P2P_WAIT_GROUPS = 16;                  // workgroups of a wait: two per XCD under round-robin dispatch
+constexpr int P2P_THREADS = 256;                    // lanes of a push workgroup: 16 waves x 4 loads of 16 bytes in flight per lane (a 4-wave
+                                                     // workgroup per CU kept 16 KB in flight: 11 GB/s per CU at HBM latency)
+constexpr int P2P_MAX_GROUPS = 128;                  // workgroups of a push (BYA_P2P_GROUPS: probe switch, read per call)
 
 std::atomic<long long> g_wait_limit_ticks{30ll * 100000000ll};          // s_memrealtime ticks (100 MHz)
 
@@ -170,16 +173,40 @@ __device__ __forceinline__ void p2p_copy_chunks(const bya_p2p_copy* __restrict__
         char* dst = static_cast<char*>(e.dst) + row0 * e.dst_pitch + col0;
         const bool wide = ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) && (nrows == 1 || ((e.src_pitch | e.dst_pitch | n) & 15) == 0);
         if (wide) {
+            // four independent 16-byte loads in flight per lane before the first store (one load -> one store per iteration
+            // moved 0.5 TB/s against LOCAL memory: latency-bound long before any link is)
             const int n16 = n & ~15, per_row = n16 >> 4, total = per_row * nrows;
-            for (int t = tid; t < total; t += 256) {
-                const int r = nrows == 1 ? 0 : t / per_row, b = (t - r * per_row) << 4;
-                *reinterpret_cast<u32x4*>(dst + (long long)r * e.dst_pitch + b) = *reinterpret_cast<const u32x4*>(src + (long long)r * e.src_pitch + b);
+            const float inv_row = 1.0f / (float)per_row;
+            auto off = [&](int t, long long& so, long long& d_o) {
+                if (nrows == 1) { so = d_o = (long long)t << 4; return; }
+                int r = (int)((float)t * inv_row);                       // t < 4096: exact up to the correction below
+                r -= (r * per_row > t);
+                r += ((r + 1) * per_row <= t);
+                const long long b = (long long)(t - r * per_row) << 4;
+                so = (long long)r * e.src_pitch + b;
+                d_o = (long long)r * e.dst_pitch + b;
+            };
+            int t = tid;
+            for (; t + 3 * P2P_THREADS < total; t += 4 * P2P_THREADS) {
+                long long s0, s1, s2, s3, d0, d1, d2, d3;
+                off(t, s0, d0); off(t + P2P_THREADS, s1, d1); off(t + 2 * P2P_THREADS, s2, d2); off(t + 3 * P2P_THREADS, s3, d3);
+                const u32x4 a = *reinterpret_cast<const u32x4*>(src + s0), b = *reinterpret_cast<const u32x4*>(src + s1);
+                const u32x4 c2 = *reinterpret_cast<const u32x4*>(src + s2), d = *reinterpret_cast<const u32x4*>(src + s3);
+                __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(dst + d0));
+                __builtin_nontemporal_store(b, reinterpret_cast<u32x4*>(dst + d1));
+                __builtin_nontemporal_store(c2, reinterpret_cast<u32x4*>(dst + d2));
+                __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(dst + d3));
             }
-            for (int b = n16 + tid * 2; b < n; b += 256 * 2)            // (nrows == 1 here: a piece ends on a bf16 element, not on 16 bytes)
+            for (; t < total; t += P2P_THREADS) {
+                long long s0, d0;
+                off(t, s0, d0);
+                *reinterpret_cast<u32x4*>(dst + d0) = *reinterpret_cast<const u32x4*>(src + s0);
+            }
+            for (int b = n16 + tid * 2; b < n; b += P2P_THREADS * 2)            // (nrows == 1 here: a piece ends on a bf16 element, not on 16 bytes)
                 *reinterpret_cast<uint16_t*>(dst + b) = *reinterpret_cast<const uint16_t*>(src + b);
         } else {                                                        // small odd-sized pieces (the router's logits)
             const int per_row = n >> 1, total = per_row * nrows;
-            for (int t = tid; t < total; t += 256) {
+            for (int t = tid; t < total; t += P2P_THREADS) {
                 const int r = nrows == 1 ? 0 : t / per_row, b = (t - r * per_row) << 1;
                 *reinterpret_cast<uint16_t*>(dst + (long long)r * e.dst_pitch + b) = *reinterpret_cast<const uint16_t*>(src + (long long)r * e.src_pitch + b);
             }
@@ -217,7 +244,7 @@ __device__ __forceinline__ void p2p_wait_flags(unsigned* __restrict__ ctrl, int 
 // WAIT: the same workgroups then wait for the peers' pushes of this exchange (push + wait as one launch; every workgroup has
 // finished its own copies before it starts to poll, and publishing never depends on a poller, so nothing can wait in a circle)
 template <bool WAIT>
-__global__ __launch_bounds__(256) void p2p_push_kernel(const bya_p2p_copy* __restrict__ copies, int n_copies, long long total_chunks,
+__global__ __launch_bounds__(P2P_THREADS) void p2p_push_kernel(const bya_p2p_copy* __restrict__ copies, int n_copies, long long total_chunks,
                                                         unsigned* const* __restrict__ peer_ctrl, int world, int rank,
                                                         unsigned* __restrict__ ctrl, long long limit_ticks) {
     const int tid = threadIdx.x;
@@ -237,9 +264,11 @@ __global__ __launch_bounds__(256) void p2p_push_kernel(const bya_p2p_copy* __res
                 __hip_atomic_store(peer_ctrl[p] + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (WAIT) {
+    if (WAIT && blockIdx.x < P2P_WAIT_GROUPS) {
+        // the first P2P_WAIT_GROUPS workgroups (two per XCD under round-robin dispatch, like the wait kernel's) stay to wait;
+        // with all 128 polling the exchange of an 8-rank step took 8 us longer than push + a separate wait launch
         __syncthreads();
-        if (tid < 64) p2p_wait_flags(ctrl, world, expect, limit_ticks, gridDim.x);
+        if (tid < 64) p2p_wait_flags(ctrl, world, expect, limit_ticks, gridDim.x < P2P_WAIT_GROUPS ? gridDim.x : P2P_WAIT_GROUPS);
     }
 }
 
@@ -258,6 +287,12 @@ __global__ __launch_bounds__(256) void p2p_poison_kernel(const unsigned* __restr
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = 0x7fc0u;
 }
 
+inline long long p2p_max_groups() {
+    const char* e = getenv("BYA_P2P_GROUPS");
+    const int v = e ? atoi(e) : 0;
+    return v >= P2P_WAIT_GROUPS && v <= 1024 ? v : P2P_MAX_GROUPS;
+}
+
 int p2p_check(const void* copies_dev, const void* peer_ctrl_dev, const void* ctrl, int32_t n_copies, int64_t total_chunks, int32_t world,
               int32_t rank) {
     if (!copies_dev || !peer_ctrl_dev || !ctrl || n_copies <= 0 || total_chunks <= 0) return BYA_ERR_SHAPE;
@@ -272,9 +307,9 @@ extern "C" int bya_p2p_push(const bya_p2p_copy* copies_dev, int32_t n_copies, in
                             int32_t world, int32_t rank, void* ctrl, hipStream_t stream) {
     const int rc = p2p_check(copies_dev, peer_ctrl_dev, ctrl, n_copies, total_chunks, world, rank);
     if (rc != BYA_OK) return rc;
-    // enough workgroups to keep every xGMI link and the local HBM busy, few enough to leave the CUs to the compute stream
-    const long long want = total_chunks < 64 ? total_chunks : 64;
-    BYA_LAUNCH(p2p_push_kernel<false>, dim3((unsigned)want), dim3(256), 0, stream, copies_dev, n_copies, (long long)total_chunks,
+    // enough workgroups to keep every xGMI link and the local HBM busy, few enough to leave CUs to the compute stream
+    const long long cap = p2p_max_groups(), want = total_chunks < cap ? total_chunks : cap;
+    BYA_LAUNCH(p2p_push_kernel<false>, dim3((unsigned)want), dim3(P2P_THREADS), 0, stream, copies_dev, n_copies, (long long)total_chunks,
                reinterpret_cast<unsigned* const*>(peer_ctrl_dev), world, rank, static_cast<unsigned*>(ctrl), 0ll);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
@@ -291,9 +326,10 @@ extern "C" int bya_p2p_exchange(const bya_p2p_copy* copies_dev, int32_t n_copies
     const int rc = p2p_check(copies_dev, peer_ctrl_dev, ctrl, n_copies, total_chunks, world, rank);
     if (rc != BYA_OK) return rc;
     // at least P2P_WAIT_GROUPS workgroups, so that the acquire at the end of the wait reaches every XCD
-    long long want = total_chunks < 64 ? total_chunks : 64;
+    const long long cap = p2p_max_groups();
+    long long want = total_chunks < cap ? total_chunks : cap;
     if (want < P2P_WAIT_GROUPS) want = P2P_WAIT_GROUPS;
-    BYA_LAUNCH(p2p_push_kernel<true>, dim3((unsigned)want), dim3(256), 0, stream, copies_dev, n_copies, (long long)total_chunks,
+    BYA_LAUNCH(p2p_push_kernel<true>, dim3((unsigned)want), dim3(P2P_THREADS), 0, stream, copies_dev, n_copies, (long long)total_chunks,
                reinterpret_cast<unsigned* const*>(peer_ctrl_dev), world, rank, static_cast<unsigned*>(ctrl),
                g_wait_limit_ticks.load(std::memory_order_relaxed));
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
