@@ -198,7 +198,7 @@ class P2PGroup:
             self.ctrl = self.symmetric("__ctrl__", (MAX_CHANNELS, CTRL_WORDS), torch.int32, zero=True, kind="coarse")
             self.ctrl_kind = "coarse"
         if solo is not None:
-            self.ctrl_kind = "local (solo probe)"
+            self.ctrl_kind = f"local (solo probe, {getattr(self, 'solo_ctrl', 'coarse')})"
         self.ctrl_peers = self._named["__ctrl__"][1]
         LIVE_GROUPS.add(self)
 
@@ -243,6 +243,16 @@ class P2PGroup:
                 # multiply zeros draw less power and clock higher than they would on a node)
                 local = (torch.randn(*shape, device=self.dev) * 0.5).to(dtype) if dtype == torch.bfloat16 else \
                     torch.zeros(*shape, dtype=dtype, device=self.dev)
+                if name == "__ctrl__" and kind == "fine":
+                    # the control block in the memory kind a node would use (polls and counters cost more there): the probe
+                    # should pay for it too.  Falls back to the torch allocation above where the platform refuses.
+                    n = local.numel() * local.element_size()
+                    ptr = ctypes.c_void_p(0)
+                    if _hip.load().bya_p2p_alloc(n, KINDS["fine"], ctypes.byref(ptr)) == 0 and ptr.value:
+                        blk = _Block(ptr.value, n, True)
+                        self._keep.append(blk)
+                        local = torch.as_tensor(blk, device=self.dev).view(dtype).view(*shape)
+                        self.solo_ctrl = "fine"
                 if name == "__ctrl__":
                     peers = [_Peer(local.data_ptr(), shape, dtype, local)] * self.world     # every flag lands in the own block
                 else:

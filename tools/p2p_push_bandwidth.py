@@ -26,7 +26,7 @@ def main():
         pieces = [(blocks[t * W + j], j, name, (t * 17776 + 1 * S_loc) * Dl) for j in range(W) for t in range(3)]
         ch = g.channel(("probe", W), pieces)
         nbytes = blocks.numel() * 2
-        row = {"bytes": nbytes}
+        row = {"bytes": nbytes, "control_block": g.ctrl_kind}
         for form, fn in (("exchange (one launch)", lambda: ch.exchange()), ("push + wait (two launches)", lambda: ch.push().wait()),
                          ("push alone", lambda: ch.push())):
             for _ in range(5):
@@ -47,6 +47,23 @@ def main():
                     ch.wait()
                 torch.cuda.synchronize()
         res[f"W={W}"] = row
+        # a small exchange (the router's repartitions and logits: fixed cost only)
+        tiny = torch.randn(W, 4096, device=dev).to(torch.bfloat16)
+        g.symmetric(f"tiny{W}", (W, 4096), torch.bfloat16)
+        ct = g.channel(("tiny", W), [(tiny[j], j, f"tiny{W}", 1 * 4096) for j in range(W)])
+        for _ in range(5):
+            ct.exchange()
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(50):
+                ct.exchange()
+            e.record()
+            torch.cuda.synchronize()
+            best = min(best, s.elapsed_time(e) / 50 * 1e3)
+        row["64 KB exchange (one launch)"] = {"us": round(best, 1)}
         print(W, res[f"W={W}"], flush=True)
         assert g.timeouts() == 0
     if len(sys.argv) > 1:
