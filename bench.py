@@ -355,6 +355,14 @@ def main():
         if not noise_ok:
             raise SystemExit(f"the sharded step in its default mode is not within bf16 summation noise of the unsharded step: {validation}")
         del ref_strict
+        if getattr(model, "_seq_p2p", None) is not None:
+            # what the push kernel does to the links of THIS node: one all-to-all of the packed q|k|v exchange's size, every
+            # rank's figure (diagnostic, outside the timed region)
+            probe = model._seq_p2p.exchange_probe(mbytes_per_peer=max(1, 40 // model._seq_p2p.world))
+            got = [None] * world
+            dist.all_gather_object(got, probe if getattr(model, "_seq_world", 1) > 1 else None)
+            validation["p2p_exchange_probe"] = {"per_rank": got, "what": "one all-to-all launch of that many bytes to the peers, us per exchange"
+                                                + ("; ranks share one GPU: local copies" if share else "")}
     else:
         for _ in range(args.warmup):
             out = step()

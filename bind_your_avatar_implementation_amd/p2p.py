@@ -461,6 +461,28 @@ class P2PGroup:
                    f"({self.mem} receive buffers, {self.ctrl_kind} flags)")
         self._agree(err, "self-test")                    # (all ranks pass or all ranks raise; also the closing barrier)
 
+    def exchange_probe(self, mbytes_per_peer=6, reps=5):
+        """COLLECTIVE diagnostic (bench.py --gpus N puts it into its line): time an all-to-all of ``mbytes_per_peer`` MB to
+        every rank (the size of the packed q|k|v exchange of an 8-rank step is 5 MB per peer) as ONE exchange launch.
+        -> {"bytes_sent": to the W - 1 peers, "us": per exchange on this rank, "GBps_out": bytes_sent / us}.  On a node this is
+        the first number anyone gets for what the push kernel does to the xGMI links; with the ranks on one GPU it measures
+        local copies."""
+        W, n = self.world, int(mbytes_per_peer * (1 << 20)) // 2
+        self.symmetric("__probe__", (W, n), torch.bfloat16)
+        send = torch.zeros(W, n, dtype=torch.bfloat16, device=self.dev)
+        ch = self.channel("__probe__", [(send[j], j, "__probe__", self.rank * n) for j in range(W)])
+        for _ in range(2):
+            ch.exchange()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            ch.exchange()
+        e.record()
+        torch.cuda.synchronize(self.dev)
+        us = s.elapsed_time(e) / reps * 1e3
+        sent = (W - 1) * n * 2
+        return {"bytes_sent": sent, "us": round(us, 1), "GBps_out": round(sent / us * 1e-3, 1)}
+
     def timeouts(self):
         """Waits that gave up (0 on a healthy run); synchronises."""
         torch.cuda.synchronize(self.dev)
