@@ -13,7 +13,7 @@ projector) is RECOMPUTED every step exactly like the reference does (no cached o
 N > 1 shards the token axis of the same step across ranks (sequence parallel: head-parallel all-to-all around the joint
 attention, sharded Embedding Router): total work is fixed => "scaling": "strong".  Before anything is timed every rank runs
 the UNSHARDED step once on its own GPU and the sharded step must reproduce it -- bit for bit with the two summation-order
-switches off (BYA_GEMM_SPLITK=0, BYA_ATTN_STREAMK=0), to bf16 noise in the default mode -- after enough warm-up steps that
+switches off (library options gemm_splitk = 0, attn_streamk = 0), to bf16 noise in the default mode -- after enough warm-up steps that
 every receive buffer has been re-used; a transport that fails moves ALL ranks one rung down the ladder
 p2p (coarse receive buffers) -> p2p-fine (fine-grained) -> torch.distributed, and the line says which rung ran.
 
@@ -28,6 +28,10 @@ import sys
 import time
 
 import torch
+
+# timer buckets (ops._begin names) of the Embedding Router's launches
+ROUTER_TIMERS = ("bya_rowgemm512", "bya_router_group_attn", "bya_router_group_attn_out", "bya_router_mlp_fused", "bya_attn_tiny",
+                 "bya_attn_fwd:other", "bya_router_scores", "bya_router_head")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -269,26 +273,15 @@ def main():
     def step():
         return model(return_dict=False, denoise_step=0, **inp)[0]
 
-    STRICT = {"BYA_GEMM_SPLITK": "0", "BYA_ATTN_STREAMK": "0"}     # both read per call by the library: summation order = the unsplit one
+    # strict summation order = options gemm_splitk = 0, attn_streamk = 0 of the library (ops.strict_summation)
     if share and world > 1:
         # Split-K tails and the stream-K attention hand partial sums between workgroups of ONE launch and count on the whole
         # grid being resident (one workgroup per CU on a GPU the process owns).  Processes that time-slice one GPU break
         # that: two half-resident grids wait for each other until the bounded hand-off gives up (counted, and fatal below).
         # The one-GPU rehearsal therefore runs everything in the unsplit mode; what it rehearses is the exchange code.
-        os.environ.update(STRICT)
-
-    class strict_mode:
-        def __enter__(self):
-            self.old = {k: os.environ.get(k) for k in STRICT}
-            os.environ.update(STRICT)
-
-        def __exit__(self, *exc):
-            for k, v in self.old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
-            return False
+        ops.set_option("gemm_splitk", 0)
+        ops.set_option("attn_streamk", 0)
+    strict_mode = ops.strict_summation
 
     transport_note, validation = None, None
     if world > 1:
@@ -348,7 +341,7 @@ def main():
         bound = 3e-2
         diff = ((out.float() - ref_strict.float()).norm() / ref_strict.float().norm()).item()
         noise_ok = everyone(diff <= bound and (getattr(model, "_seq_p2p", None) is None or model._seq_p2p.timeouts() == 0))
-        validation = {"reference": "the unsharded step on every rank's own GPU (BYA_GEMM_SPLITK=0, BYA_ATTN_STREAMK=0)",
+        validation = {"reference": "the unsharded step on every rank's own GPU (library options gemm_splitk = 0, attn_streamk = 0)",
                       "rungs": tried, "default_mode_rel_fro_vs_reference": diff, "default_mode_bound": bound}
         if share:
             validation["ranks_share_one_gpu"] = "rehearsal of the N > 1 code path, split-K / stream-K off throughout: not a measurement"
@@ -450,6 +443,8 @@ def main():
             tot = {k: sum(v) for k, v in ktimes.items()}
             per_step = {k: tot[k] / args.steps for k in tot}
             res["kernel_ms_per_step"] = {k: round(v * 1e3, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
+            # the Embedding Router's share (every launch of MultiIPRouter.forward: scores, the four ST blocks, head)
+            res["router_ms_per_step"] = round(1e3 * sum(per_step.get(k, 0.0) for k in ROUTER_TIMERS), 3)
             res["attention_variants"] = {f"{tag}:{var}": n for (tag, var), n in sorted(ops.ATTN_VARIANTS.items())}
             attn = [t for t in ktimes.get("bya_attn_fwd:joint", [])]
             attn_roof = None

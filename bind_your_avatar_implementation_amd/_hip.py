@@ -51,6 +51,8 @@ class SchedCoef(_c.Structure):
 # name -> argtypes (all return int32 status); mirrors include/bya.h one-to-one
 SIGNATURES = {
     "bya_abi_version": [],
+    "bya_set_option": [_i32, _i32],
+    "bya_get_option": [_i32, _c.POINTER(_i32)],
     "bya_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
     "bya_gemm_skinny_bf16": [_vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
     "bya_gemm_qkv_norm_rope": [_vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _c.POINTER(QkNormDesc), _vp],
@@ -83,6 +85,9 @@ SIGNATURES = {
     "bya_act_add": [_vp, _vp, _vp, _i64, _i32, _vp],
     "bya_rowgemm512": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp],
     "bya_router_group_attn": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _f32, _vp],
+    "bya_router_mlp_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp],
+    "bya_router_group_attn_out": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _f32,
+                                  _i32, _vp],
     "bya_masks_to_routing_logits": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "bya_vae_patches": [_vp, _vp, _vp] + [_i32] * 14 + [_vp],
     "bya_vae_groupnorm_stats": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
@@ -103,6 +108,21 @@ SIGNATURES = {
     "bya_p2p_ipc_import": [_vp, _c.POINTER(_vp)],
     "bya_p2p_ipc_release": [_vp],
     "bya_cfg_scheduler_step": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _c.POINTER(SchedCoef), _vp],
+}
+
+# bya_option keys / BYA_REF_* bits of include/bya.h
+OPTIONS = {"gemm_splitk": 0, "gemm_splitk_min": 1, "gemm_tile": 2, "gemm_variant": 3, "attn_streamk": 4, "fp8_kernel": 5,
+           "p2p_groups": 6, "reference_forms": 7}
+REFERENCE_FORMS = {"rowgemm_chunked": 1, "kv_mix_generic": 2, "ln_generic": 4, "router_scores_wave": 8, "attn_narrow_store": 16}
+# environment variable -> (option, parser): read ONCE, when the library is loaded (the C entry points never call getenv)
+ENV_OPTIONS = {
+    "BYA_GEMM_SPLITK": ("gemm_splitk", int),
+    "BYA_GEMM_SPLITK_MIN": ("gemm_splitk_min", int),
+    "BYA_GEMM_TILE": ("gemm_tile", int),
+    "BYA_GEMM_VARIANT": ("gemm_variant", lambda v: 1 if v == "w8" else 0),
+    "BYA_ATTN_STREAMK": ("attn_streamk", int),
+    "BYA_FP8_KERNEL": ("fp8_kernel", lambda v: 1 if v.startswith("1") else 0),
+    "BYA_P2P_GROUPS": ("p2p_groups", int),
 }
 
 ERRORS = {-1: "BYA_ERR_SHAPE", -2: "BYA_ERR_ALIGN", -3: "BYA_ERR_LAUNCH", -4: "BYA_ERR_UNSUPPORTED"}
@@ -129,7 +149,32 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _i32
     _lib = lib
+    apply_env_options()
     return lib
+
+
+def set_option(name, value):
+    """bya_set_option by name (``OPTIONS``); raises on an unknown name or a value outside the option's range."""
+    check(load().bya_set_option(OPTIONS[name], int(value)), f"bya_set_option({name}={value})")
+
+
+def get_option(name):
+    v = _i32(0)
+    check(load().bya_get_option(OPTIONS[name], _c.byref(v)), f"bya_get_option({name})")
+    return v.value
+
+
+OPTION_DEFAULTS = {"gemm_splitk": 1, "gemm_splitk_min": 0, "gemm_tile": -1, "gemm_variant": 0, "attn_streamk": 1, "fp8_kernel": 0,
+                   "p2p_groups": 0, "reference_forms": 0}
+
+
+def apply_env_options():
+    """Hand the BYA_* tuning variables of the environment to the library's option table; an option whose variable is unset
+    goes back to its default.  Runs when the library is loaded; call it again after changing one of the variables in a live
+    process (tools/ do)."""
+    for var, (name, parse) in ENV_OPTIONS.items():
+        v = os.environ.get(var)
+        set_option(name, parse(v) if v not in (None, "") else OPTION_DEFAULTS[name])
 
 
 class ByaError(RuntimeError):

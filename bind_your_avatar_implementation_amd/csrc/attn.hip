@@ -16,6 +16,7 @@
 #include "attn_common.h"
 #include "routing_weights.h"
 #include <stdlib.h>
+#include "options.h"
 
 namespace {
 
@@ -801,8 +802,7 @@ extern "C" int bya_attn_fwd(const void* q, const void* k, const void* v, void* o
     a.k_s1 = d->k_s1; a.k_s2 = d->k_s2; a.k_row = d->k_row;
     a.v_s1 = d->v_s1; a.v_s2 = d->v_s2; a.v_row = d->v_row;
     a.o_s1 = d->o_s1; a.o_s2 = d->o_s2; a.o_row = d->o_row;
-    const char* ew = getenv("BYA_ATTN_WIDE_STORE");              // A/B switch, read per call
-    a.o_wide = !((uintptr_t)o & 15) && (d->o_s1 | d->o_s2 | d->o_row) % 8 == 0 && !(ew && ew[0] == '0');
+    a.o_wide = !((uintptr_t)o & 15) && (d->o_s1 | d->o_s2 | d->o_row) % 8 == 0 && !bya_ref_form(BYA_REF_ATTN_NARROW_STORE);
     a.scale_log2 = d->scale * 1.4426950408889634f;
     a.prescaled = d->scores_prescaled;
     if (a.prescaled && d->head_dim != 64) return BYA_ERR_UNSUPPORTED;
@@ -837,8 +837,7 @@ extern "C" int bya_attn_kv_mix(const void* q, const void* k, const void* v, cons
     a.q_grp = d->q_grp; a.q_row = d->q_row; a.k_id = d->k_id; a.k_grp = d->k_grp; a.k_row = d->k_row;
     a.v_id = d->v_id; a.v_grp = d->v_grp; a.v_row = d->v_row; a.z_grp = d->z_grp; a.z_row = d->z_row;
     a.scale_log2 = d->scale * 1.4426950408889634f;
-    const char* e32 = getenv("BYA_KV_MIX32");                    // A/B switch, read per call
-    if (d->Skv <= 32 && !(e32 && e32[0] == '0') && !((uintptr_t)z & 15) && (d->z_grp | d->z_row) % 8 == 0) {
+    if (d->Skv <= 32 && !bya_ref_form(BYA_REF_KV_MIX_GENERIC) && !((uintptr_t)z & 15) && (d->z_grp | d->z_row) % 8 == 0) {
         // row chunks per (group, head): about three 32-row tiles per wave, and at least ~4 workgroups per CU in total
         const int n32 = (d->Sq + 31) / 32;
         int nqc = (n32 + 11) / 12;

@@ -27,6 +27,7 @@
 // Built WITHOUT -amdgpu-mfma-vgpr-form (O accumulators and the Q fragments live in AGPRs).
 #include "attn_common.h"
 #include <stdlib.h>
+#include "options.h"
 
 namespace {
 
@@ -506,7 +507,7 @@ int bya_launch_attn_w4(const void* args, hipStream_t s) {
     const int nbh = a.nb1 * a.nb2 * a.heads;
     const int dev = sk_device();
     char* const ws = dev < 0 ? nullptr : static_cast<char*>(g_attn_ws[dev].load());
-    const char* e = getenv("BYA_ATTN_STREAMK");              // A/B switch, read per call; default on when a workspace exists
+    const bool sk_on = bya_opt(BYA_OPT_ATTN_STREAMK) != 0;   // default on when a workspace exists
     const long long nt_all = (a.Skv + KV_TILE - 1) / KV_TILE;
     const long long items = (long long)nbh * a.nqt;
     // stream-K pays when an XCD's items make at least one whole round of its 32 CUs plus a partial one.  Measured
@@ -518,7 +519,7 @@ int bya_launch_attn_w4(const void* args, hipStream_t s) {
     // power budget to the busy ones as clock, and filling them buys little; below one round the hand-offs cost more.
     const long long ipx = items / 8;                            // per XCD, +- one item when 8 does not divide
     const long long rem = ipx % (SK_GRID / 8);
-    const bool sk = ws && !(e && e[0] == '0') && ipx >= SK_GRID / 8 && (items % SK_GRID != 0) && rem * nt_all >= 8 * (SK_GRID / 8) &&
+    const bool sk = ws && sk_on && ipx >= SK_GRID / 8 && (items % SK_GRID != 0) && rem * nt_all >= 8 * (SK_GRID / 8) &&
                     nt_all >= 16 && items * nt_all < (1LL << 31);
     if (sk) {
         a.sk_flags = reinterpret_cast<unsigned*>(ws);

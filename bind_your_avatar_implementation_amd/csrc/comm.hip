@@ -12,6 +12,7 @@
 #include "../../include/bya.h"
 #include <dlfcn.h>
 #include <string.h>
+#include "options.h"
 
 namespace {
 
@@ -288,8 +289,7 @@ __global__ __launch_bounds__(256) void p2p_poison_kernel(const unsigned* __restr
 }
 
 inline long long p2p_max_groups() {
-    const char* e = getenv("BYA_P2P_GROUPS");
-    const int v = e ? atoi(e) : 0;
+    const int v = bya_opt(BYA_OPT_P2P_GROUPS);
     return v >= P2P_WAIT_GROUPS && v <= 1024 ? v : P2P_MAX_GROUPS;
 }
 

@@ -15,6 +15,7 @@
 #include "gemm_common.h"
 #include <stdlib.h>
 #include <string.h>
+#include "options.h"
 
 namespace {
 
@@ -317,9 +318,8 @@ int launch256(const GemmArgs& a, int batch, hipStream_t s) {
     // its 16-byte epilogue accesses are aligned and K has at least three K-tiles, else the 8-wave kernel below.
     // BYA_GEMM_VARIANT (read per call so one process can A/B them, tools/gemm_probe.py): "w8" = this file's 8-wave
     // kernel (the fallback), anything else = gemm_v4.hip.
-    const char* variant = getenv("BYA_GEMM_VARIANT");
     const bool v4_ok = v4_eligible(a);
-    if (v4_ok && !(variant && variant[0] == 'w' && variant[1] == '8')) return bya_launch_gemm256p(&a, batch, s);
+    if (v4_ok && !bya_opt(BYA_OPT_GEMM_VARIANT)) return bya_launch_gemm256p(&a, batch, s);
     BYA_LAUNCH(gemm256_kernel, grid, dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
@@ -582,12 +582,9 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
     char* const ws = reinterpret_cast<char*>(a.ws_counters);
     struct { int M, N, K, batch, act; } dd{a.M, a.N, a.K, nbatch, a.act};
     const auto* d = &dd;
-    const char* tile_env = getenv("BYA_GEMM_TILE");            // tuning / test switch, read per call
-    const int forced = tile_env ? atoi(tile_env) : -1;
-    const char* sk_env = getenv("BYA_GEMM_SPLITK");
-    const char* var_env = getenv("BYA_GEMM_VARIANT");
-    const bool splitk = ws && !(sk_env && sk_env[0] == '0') && a.K / BK >= 2 * bya_gemm_split_min_ktiles() && v4_eligible(a) &&
-        (!var_env || (var_env[0] == 'v' && var_env[1] == '4'));
+    const int forced = bya_opt(BYA_OPT_GEMM_TILE);              // tuning / test option
+    const bool splitk = ws && bya_opt(BYA_OPT_GEMM_SPLITK) != 0 && a.K / BK >= 2 * bya_gemm_split_min_ktiles() && v4_eligible(a) &&
+        !bya_opt(BYA_OPT_GEMM_VARIANT);
     switch (pick_tile(d->M, d->N, d->K, d->batch, forced, d->act, splitk)) {
         case 0: return launch<128, 64, 2, 2>(a, d->batch, stream);
         case 1: return launch<128, 128, 2, 2>(a, d->batch, stream);

@@ -12,6 +12,7 @@
 // rows, i.e. exactly the staging / XOR-swizzle image of the bf16 128 x 128 kernel (gemm.hip) at twice the FLOPs per byte.
 // Same epilogue as every other GEMM here (bias, activation, gate, residual, q|k|v split): gemm_common.h.
 #include "gemm_fp8_kernel.h"
+#include "options.h"
 
 bool bya_gemm256p_fp8_eligible(const void* args);                                                       // gemm_fp8_v4.hip
 int bya_launch_gemm256p_fp8(const void* args, const float* sa, const float* sw, int batch, int gm, hipStream_t s);
@@ -103,9 +104,8 @@ extern "C" int bya_gemm_fp8(const void* A8, const float* a_scale, const void* W8
     // hipcc's schedule (profiles/r2_fp8_probe.txt; both removed from the tree in round 3).
     // ... until the loop was placed by hand: gemm_fp8_v4.hip (one wave per SIMD, persistent) takes every launch that is big
     // enough to fill its 256 x 256 tiles; BYA_FP8_KERNEL=128 (read per call: A/B runs) keeps everything on the kernel above.
-    const char* kv = getenv("BYA_FP8_KERNEL");
     const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch;
-    const bool big = !(kv && kv[0] == '1') && tiles256 >= 200;        // (about a round of its 256 workgroups, or more)
+    const bool big = !bya_opt(BYA_OPT_FP8_KERNEL) && tiles256 >= 200;        // (about a round of its 256 workgroups, or more)
     const int gm = 4;                                                 // row-tiles per group of the persistent kernel's tile order
     return gemm_row_chunks(a, d->batch, 1, [&](const GemmArgs& piece, int batch, long long row0) {
         if (big && bya_gemm256p_fp8_eligible(&piece))

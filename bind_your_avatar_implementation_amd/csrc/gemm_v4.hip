@@ -36,6 +36,7 @@
 // explicit s_nops.  This translation unit is compiled WITHOUT -amdgpu-mfma-vgpr-form (accumulators in AGPRs).
 #include "gemm_common.h"
 #include "qknorm_math.h"
+#include "options.h"
 
 #ifndef BYA_GEMM_ABLATE
 #define BYA_GEMM_ABLATE 0
@@ -1191,8 +1192,8 @@ int bya_launch_gemm256p_qkn(const void* args, int batch, hipStream_t s) {
 }
 
 int bya_gemm_split_min_ktiles() {
-    const char* e = getenv("BYA_GEMM_SPLITK_MIN");           // test / tuning switch, read per call
-    const int v = e ? atoi(e) : DEFAULT_MIN_SPLIT_KTILES;
+    const int o = bya_opt(BYA_OPT_GEMM_SPLITK_MIN);           // test / tuning option
+    const int v = o ? o : DEFAULT_MIN_SPLIT_KTILES;
     return v < 3 ? 3 : v;
 }
 
@@ -1201,9 +1202,9 @@ int bya_launch_gemm256p(const void* args, int batch, hipStream_t s) {
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
     const long long total = (long long)tiles_m * tiles_n * batch;
     // split the last partial round along K when a workspace is registered (BYA_GEMM_SPLITK=0 switches it off, read per call)
-    const char* sk = getenv("BYA_GEMM_SPLITK");
+    const int sk = bya_opt(BYA_OPT_GEMM_SPLITK);
     const int min_seg = bya_gemm_split_min_ktiles();
-    const int split = (a.ws_slabs && a.ws_counters && !(sk && sk[0] == '0') && a.K / BK >= 2 * min_seg) ? (sk && sk[0] == '2' ? 2 : 1) : 0;
+    const int split = (a.ws_slabs && a.ws_counters && sk != 0 && a.K / BK >= 2 * min_seg) ? (sk == 2 ? 2 : 1) : 0;
     int blocks = (int)(total < 256 && !split ? (total + 7) / 8 * 8 : 256);
     const size_t lds = 2 * 512 * BK * 2;
     static std::atomic<unsigned long long> attr_done{0}, attr_done_s{0};

@@ -3,6 +3,7 @@
 // forcing max-over-frames, patchify / unpatchify and a generic activation(+add).
 #include "bya_common.h"
 #include "../../include/bya.h"
+#include "options.h"
 #include "routing_weights.h"
 
 namespace {
@@ -327,7 +328,34 @@ masks_to_logits_kernel(const uint8_t* __restrict__ masks, bf16_t* __restrict__ o
 
 }  // namespace
 
-extern "C" int bya_abi_version(void) { return 1; }
+extern "C" int bya_abi_version(void) { return 2; }
+
+// ---- process-wide options (include/bya.h, csrc/options.h): defaults, ranges, setter ----------------------------------
+std::atomic<int32_t> g_bya_options[BYA_OPT_COUNT] = {
+    {1},      // BYA_OPT_GEMM_SPLITK
+    {0},      // BYA_OPT_GEMM_SPLITK_MIN
+    {-1},     // BYA_OPT_GEMM_TILE
+    {0},      // BYA_OPT_GEMM_VARIANT
+    {1},      // BYA_OPT_ATTN_STREAMK
+    {0},      // BYA_OPT_FP8_KERNEL
+    {0},      // BYA_OPT_P2P_GROUPS
+    {0},      // BYA_OPT_REFERENCE_FORMS
+};
+
+extern "C" int bya_set_option(int32_t key, int32_t value) {
+    static const int32_t lo[BYA_OPT_COUNT] = {0, 0, -1, 0, 0, 0, 0, 0};
+    static const int32_t hi[BYA_OPT_COUNT] = {2, 1 << 20, 4, 1, 1, 1, 1024, 31};
+    if (key < 0 || key >= BYA_OPT_COUNT || value < lo[key] || value > hi[key]) return BYA_ERR_SHAPE;
+    if (key == BYA_OPT_P2P_GROUPS && value != 0 && value < 16) return BYA_ERR_SHAPE;
+    g_bya_options[key].store(value, std::memory_order_relaxed);
+    return BYA_OK;
+}
+
+extern "C" int bya_get_option(int32_t key, int32_t* value) {
+    if (key < 0 || key >= BYA_OPT_COUNT || !value) return BYA_ERR_SHAPE;
+    *value = g_bya_options[key].load(std::memory_order_relaxed);
+    return BYA_OK;
+}
 
 extern "C" int bya_linear_small_m(const void* x, const void* W, const void* bias, void* out, int32_t M, int32_t N,
                                   int32_t K, int32_t silu_in, int32_t act_out, hipStream_t stream) {

@@ -10,6 +10,7 @@
 #include "qknorm_math.h"
 #include "../../include/bya.h"
 #include <stdlib.h>
+#include "options.h"
 
 namespace {
 
@@ -346,9 +347,8 @@ extern "C" int bya_layernorm(const void* x, void* y, const void* w, const void* 
         case 1024: return launch_ln<8, 2>(a, stream);
         case 2048: return launch_ln<8, 4>(a, stream);
         case 3072: {
-            const char* e = getenv("BYA_LN_ROWS");               // A/B switch, read per call
             // (whatever the row count: a shard of the sequence must round exactly like the whole)
-            if (a.w && a.b && !(e && e[0] == '0')) return launch_ln_adaln_rows<6>(a, stream);
+            if (a.w && a.b && !bya_ref_form(BYA_REF_LN_GENERIC)) return launch_ln_adaln_rows<6>(a, stream);
             return launch_ln<8, 6>(a, stream);
         }
         default: return BYA_ERR_UNSUPPORTED;

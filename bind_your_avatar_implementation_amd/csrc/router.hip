@@ -8,6 +8,7 @@
 #include "bya_common.h"
 #include "../../include/bya.h"
 #include <stdlib.h>
+#include "options.h"
 
 namespace {
 
@@ -365,8 +366,7 @@ extern "C" int bya_router_scores(const void* qr, const void* kr, const void* ln_
     if (heads != R_HEADS || face_tokens != R_TOK) return BYA_ERR_UNSUPPORTED;
     if (((uintptr_t)qr | (uintptr_t)kr | (uintptr_t)ln_w | (uintptr_t)ln_b | (uintptr_t)pos_emb | (uintptr_t)out) & 15)
         return BYA_ERR_ALIGN;
-    const char* el = getenv("BYA_ROUTER_SCORES_LDS");            // A/B switch, read per call
-    if (N >= 4096 && n_id <= 256 && !(el && el[0] == '0')) {
+    if (N >= 4096 && n_id <= 256 && !bya_ref_form(BYA_REF_ROUTER_SCORES_WAVE)) {
         static std::atomic<unsigned long long> big{0};
         if (bya_allow_big_lds(reinterpret_cast<const void*>(router_scores_lds_kernel), 160 * 1024, big) != BYA_OK) return BYA_ERR_LAUNCH;
         const int grid = 256 / n_id * n_id;                      // one workgroup per CU, whole identities

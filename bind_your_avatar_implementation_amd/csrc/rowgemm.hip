@@ -34,9 +34,9 @@
 // so the GEMM runs on the RAW rows and the epilogue applies the two row statistics.  The statistics come from the
 // matrix core as well: sum(x) = ones . x^T and sum(x^2) = diag(x . x^T), 64 extra MFMAs per wave instead of ~3000
 // VALU cycles (fp32 accumulation of exact bf16 products).
-#include "bya_common.h"
+#include "rowgemm_common.h"
 #include "../../include/bya.h"
-#include <stdlib.h>
+#include "options.h"
 
 #ifndef BYA_ROWGEMM_ABLATE
 #define BYA_ROWGEMM_ABLATE 0     // timing-only ablations (tools/): 1 = no X loads, 2 = no output stores
@@ -44,104 +44,29 @@
 
 namespace {
 
+using namespace rowk;      // RK, CH, NJ, LPC, STAGE_BYTES, the ring's layout and fragment readers, gelu_erf_f (rowgemm_common.h)
+
 struct RowGemmArgs {
     const bf16_t* X; const bf16_t* W; const float* colsum; const float* cvec; const bf16_t* res; bf16_t* C;
     int M, N, ldx, ldc, ldres;
     float eps;
 };
 
-constexpr int RK = 512;                   // K
-#ifndef BYA_ROWGEMM_CH
-#define BYA_ROWGEMM_CH 64                 // output columns per chunk (64: one 8-wave workgroup per CU; 32: two 4-wave ones)
-#endif
-constexpr int CH = BYA_ROWGEMM_CH;
-constexpr int NJ = CH / 16;               // 16-column W fragments per chunk
-constexpr int LPC = CH / 4;               // output columns a lane ends up with per chunk (the fused attention kernel below
-                                          // keeps them consecutive: LPC g + 4 j + e)
-// Row GEMMs: which output column of a chunk sits in MFMA tile j, tile row i = 4 g + e (LDS row (i, j) of a stage), and the
-// first of the 8 columns lane group g stores with its u-th 16-byte access.  The four lane groups of a token write 8 g ..+7
-// of the chunk's half u: 64 CONTIGUOUS bytes per row and instruction (and per residual load).  (Until round 4 a lane
-// owned 16 consecutive columns -- 16-byte pieces at a 32-byte stride, eight partial requests per 128-byte line.)
-__device__ __forceinline__ constexpr uint32_t wrow_of(int i, int j) {
-    return (uint32_t)((CH / 2) * (j >> 1) + 8 * (i >> 2) + 4 * (j & 1) + (i & 3));
-}
-__device__ __forceinline__ constexpr uint32_t lane_col(uint32_t g, int u) { return (uint32_t)(CH / 2) * (uint32_t)u + 8u * g; }
-constexpr int STAGE_BYTES = CH * RK * 2;  // 64 / 32 KiB
-#ifndef BYA_ROWGEMM_HB
-#define BYA_ROWGEMM_HB 2                 // 16-row halves per wave: 2 = 32 rows of X in 128 registers, 4 = 64 rows in 256
-#endif
-constexpr int HB = BYA_ROWGEMM_HB;
+// (The build-time alternatives BYA_ROWGEMM_CH = 32 and BYA_ROWGEMM_HB = 4 of rounds 2-3 -- measured, lost, see the header
+// comment -- are gone from the source since round 6; the constants below are what they selected between.)
+constexpr int HB = 2;                     // 16-row halves per wave: 32 rows of X in 128 registers
 constexpr int NW = CH / (4 * HB);         // waves per workgroup (16*HB rows each)
 constexpr int SR = CH / NW;               // W rows of a chunk every wave stages
 constexpr int RB = 16 * HB * NW;          // rows per workgroup pass
-constexpr int WG_PER_CU = (CH == 64) ? 1 : 2;
-constexpr int AHEAD = CH == 64 ? 1 : 2;   // k-steps of W fragments in flight (a k-step is 2*NJ MFMAs)
-static_assert(CH == 64 || CH == 32, "chunk width");
-
-template <int OFF>
-__device__ __forceinline__ void lds_read_w(bf16x8& dst, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
-}
-template <int OFF>
-__device__ __forceinline__ void lds_read_f(f32x4& dst, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait(bf16x8 (&w)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "i"(N));
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait(bf16x8 (&w)[2]) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "i"(N));
-}
-// the NJ W fragments (column blocks j) of k-step 4*KH + kl; kl selects the lane-constant address
-template <int KH>
-__device__ __forceinline__ void read_quad(bf16x8 (&wf)[NJ], uint32_t addr) {
-    lds_read_w<0 * 16384 + KH * 256>(wf[0], addr);
-    lds_read_w<1 * 16384 + KH * 256>(wf[1], addr);
-    if constexpr (NJ == 4) {
-        lds_read_w<2 * 16384 + KH * 256>(wf[2], addr);
-        lds_read_w<3 * 16384 + KH * 256>(wf[3], addr);
-    }
-}
-__device__ __forceinline__ void read_kstep(bf16x8 (&wf)[NJ], const uint32_t (&wa)[4], int ks) {
-    switch (ks >> 2) {            // ks is a constant after unrolling: the switch folds away
-        case 0: read_quad<0>(wf, wa[ks & 3]); break;
-        case 1: read_quad<1>(wf, wa[ks & 3]); break;
-        case 2: read_quad<2>(wf, wa[ks & 3]); break;
-        default: read_quad<3>(wf, wa[ks & 3]); break;
-    }
-}
-
-// A lane constant the compiler may not hoist out of the chunk loop: hoisted address registers do not fit beside the 128
-// X-fragment registers, get spilled, and every scratch reload comes with an s_waitcnt vmcnt(0) -- in front of each LDS-DMA
-// instruction that serialised eight memory round trips per chunk.  Recomputing an address costs one or two VALU ops.
-__device__ __forceinline__ uint32_t lane_now() {      // the lane id, recomputed where it is used (volatile: never hoisted)
-    uint32_t l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-}
-
-// GELU(erf) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output step): one rcp,
-// one exp2 and six FMAs instead of libm's two-regime erff -- the MLP epilogue evaluates it 18 M times per launch.
-__device__ __forceinline__ float gelu_erf_f(float v) {
-    const float x = v * 0.70710678118654752f, ax = fabsf(x);
-    const float tt = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float poly = fmaf(1.061405429f, tt, -1.453152027f);
-    poly = fmaf(poly, tt, 1.421413741f);
-    poly = fmaf(poly, tt, -0.284496736f);
-    poly = fmaf(poly, tt, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-    const float erf_abs = fmaf(-poly * tt, e, 1.0f);
-    return 0.5f * v * (1.0f + copysignf(erf_abs, x));
-}
+constexpr int WG_PER_CU = 1;
+constexpr int AHEAD = 1;                  // k-steps of W fragments in flight (a k-step is 2*NJ MFMAs)
 
 // Persistent blocks of 8 waves (256 rows).  The work list is every (row block, 64-column chunk) pair in row-block-major
 // order, cut into gridDim.x equal contiguous ranges: every CU gets the same number of chunks (+-1) no matter how M and N
 // divide, and a range touches at most two or three row blocks, so the X fragments (and the row statistics) are
 // reloaded only there.  The W-chunk LDS-DMA pipeline runs straight through a row-block change.
 template <bool LN, bool RES, int ACT>
-__global__ __launch_bounds__(64 * NW, HB == 4 ? 1 : 2) void rowgemm512_kernel(RowGemmArgs p) {
+__global__ __launch_bounds__(64 * NW, 2) void rowgemm512_kernel(RowGemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -364,7 +289,6 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
 // 16-row tiles two at a time, and X travels through an 8-k-step register ring that is refilled 8 k-steps ahead -- across
 // tile pairs too -- so HBM streams steadily under the MFMAs.  (No LayerNorm-folding instance: mlp[0] keeps the
 // chunk-balanced kernel; accumulating row statistics from streamed fragments does not fit two waves per SIMD.)
-#if BYA_ROWGEMM_CH == 64 && BYA_ROWGEMM_HB == 2
 template <bool LN, bool RES, int ACT>
 __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) {
     static_assert(!LN, "the W-stationary form has no LayerNorm-folding instance");
@@ -539,7 +463,6 @@ int launch_rowgemm_q(const RowGemmArgs& a, hipStream_t s) {
     BYA_LAUNCH((rowgemm512q_kernel<LN, RES, ACT>), dim3(256), dim3(64 * NW), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
-#endif
 
 // =====================================================================================================================
 // Fused  LayerNorm -> q|k|v projection -> grouped tiny attention  for the router's temporal and multi-ID sub-blocks
@@ -569,7 +492,6 @@ struct RowAttnArgs {
     float eps, scale_log2;
 };
 
-#if BYA_ROWGEMM_CH == 64 && BYA_ROWGEMM_HB == 2
 constexpr int RA_N = 1536, RA_HEADS = 8;
 constexpr int RA_CONST_BYTES = RA_N * 8 + NW * HB * 32 * 4;      // colsum | cvec | per-wave (mean[16], rstd[16]) per tile
 
@@ -874,7 +796,6 @@ __global__ __launch_bounds__(64 * NW, 2) void rowattn512_kernel(RowAttnArgs p) {
         }
     }
 }
-#endif
 
 }  // namespace
 
@@ -894,19 +815,16 @@ extern "C" int bya_rowgemm512(const void* X, const void* W, const float* colsum,
     a.C = (bf16_t*)C; a.M = M; a.N = N; a.ldx = ldx; a.ldc = ldc; a.ldres = res ? ldres : ldc;
     a.eps = eps;
     const bool gelu = act == BYA_ACT_GELU_ERF;
-#if BYA_ROWGEMM_CH == 64 && BYA_ROWGEMM_HB == 2
     // N = 512: the W-stationary, barrier-free form (one W quarter per workgroup).  The rows M * ld must stay below 2 GiB like
     // everywhere here; tiles outside a wave's range are addressed outside the descriptors.
-    const char* qe = getenv("BYA_ROWGEMM_Q");                     // A/B switch, read per call
     // measured (profiles/r4_v_rowgemm_q_probe.json): -4 % at 35100 rows, -22 % at 17550, -47 % at 8788, -29 % at 4394 and
     // 2194, level at 70200 -- above that the chunk-balanced kernel's finer work units win back what its barriers cost
-    if (N == 512 && !ln && M >= 2048 && M <= 65536 && !(qe && qe[0] == '0')) {
+    if (N == 512 && !ln && M >= 2048 && M <= 65536 && !bya_ref_form(BYA_REF_ROWGEMM_CHUNKED)) {
         // (the LayerNorm-folding instance -- mlp[0] -- keeps the chunk-balanced kernel: accumulating the row statistics from
         // the streamed fragments needs ~40 more registers than two waves per SIMD leave, and spills)
         if (res) return gelu ? launch_rowgemm_q<false, true, BYA_ACT_GELU_ERF>(a, stream) : launch_rowgemm_q<false, true, BYA_ACT_NONE>(a, stream);
         return gelu ? launch_rowgemm_q<false, false, BYA_ACT_GELU_ERF>(a, stream) : launch_rowgemm_q<false, false, BYA_ACT_NONE>(a, stream);
     }
-#endif
     if (ln) {
         if (res) return gelu ? launch_rowgemm<true, true, BYA_ACT_GELU_ERF>(a, stream)
                              : launch_rowgemm<true, true, BYA_ACT_NONE>(a, stream);
@@ -922,7 +840,6 @@ extern "C" int bya_rowgemm512(const void* X, const void* W, const float* colsum,
 extern "C" int bya_router_group_attn(const void* X, const void* Wqkv, const float* colsum, const float* cvec, void* O,
                                      int32_t M, int32_t ldx, int32_t ldo, int32_t L, int64_t n_outer, int64_t n_inner,
                                      int64_t outer_stride, int64_t seq_stride, float eps, float scale, hipStream_t stream) {
-#if BYA_ROWGEMM_CH == 64 && BYA_ROWGEMM_HB == 2
     if (!X || !Wqkv || !colsum || !cvec || !O || M <= 0 || n_outer <= 0 || n_inner <= 0) return BYA_ERR_SHAPE;
     if (L < 1 || L > 32) return BYA_ERR_UNSUPPORTED;                  // a group must fit the two 16-row MFMA tiles of a wave
     if (outer_stride < 0 || seq_stride < 0) return BYA_ERR_SHAPE;
@@ -952,7 +869,4 @@ extern "C" int bya_router_group_attn(const void* X, const void* Wqkv, const floa
         BYA_LAUNCH(rowattn512_kernel<false>, dim3(blocks), dim3(64 * NW), lds, stream, a);
     }
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
-#else
-    return BYA_ERR_UNSUPPORTED;
-#endif
 }

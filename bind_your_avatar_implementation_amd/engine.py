@@ -95,6 +95,11 @@ class DenoiseEngine:
         self.side_stream_conditioning = os.environ.get("BYA_INVARIANTS_SIDE_STREAM", "1") != "0"
         self.sp_allgather = os.environ.get("BYA_SP_ALLGATHER", "0") == "1"       # exchange A as a K/V all-gather (A/B)
         self.router_fused_attn = os.environ.get("BYA_ROUTER_FUSED_ATTN", "1") != "0"
+        # (r6) the location-major sub-blocks as chains (csrc/rowchain.hip: attention + to_out + residual, MLP pair): "1" where
+        # the measurements say a chain wins (ROUTER_CHAIN_ROWS: the 2- and 4-rank shard shapes; at the one-GPU 35100 rows the
+        # remainder pass eats the gain, at an 8-rank shard 34 workgroups are too few), "0" never, "all" always.  A chain is
+        # bit-identical to its two launches, so the choice by row count keeps "a rank's shard rounds like the whole clip".
+        self.router_chain = os.environ.get("BYA_ROUTER_CHAIN", "1")
         self.router_replicated = os.environ.get("BYA_ROUTER_REPLICATED", "0") == "1"
         # q/k-norm + RoPE inside the q|k|v projection's epilogue (bya_gemm_qkv_norm_rope; bit-identical to the two launches)
         self.qkn_epilogue = os.environ.get("BYA_QKN_EPILOGUE", "1") != "0"
@@ -868,6 +873,33 @@ class DenoiseEngine:
         return ops.attn_tiny(qkv, qkv[:, F:], qkv[:, 2 * F:], out, L, heads, n_outer, n_inner, outer_stride, seq_stride,
                              3 * F, F, hd ** -0.5)
 
+    # row ranges in which a chain beats its two launches (profiles/r6_a_router_chain_probe.json, same box, us: MLP 50.5 -> 39.0 at
+    # 17550 rows, 37.8 -> 28.9 at 8788, 69.2 -> 69.8 at 35100, 23.8 -> 26.8 at 4394; multi-ID 64.3 -> 60.2, 47.1 -> 43.2, 93.4 ->
+    # 109, 28.6 -> 41.4; temporal level or slower everywhere)
+    ROUTER_CHAIN_ROWS = {"mlp": (6000, 24000), "multi_id_attn": (6000, 24000), "temporal_attn": (1, 0)}
+
+    def _chain_ok(self, rows, kind):
+        lo, hi = self.ROUTER_CHAIN_ROWS[kind]
+        return self.router_chain == "all" or (self.router_chain != "0" and lo <= rows <= hi)
+
+    def _r_attn_block(self, x, tmp, qkv, a, ln, pk, name, to_out, L, heads, n_outer, n_inner, outer_stride, seq_stride):
+        """x += to_out(Attention over groups of L rows of LN(x)): one sub-block of SpatialTemporalAttentionBlock (temporal /
+        multi-ID, models/router.py:482-487).  One chain launch where it pays, else group attention + out-projection."""
+        rg = pk.get("rg_" + name)
+        if rg is not None and L <= 16 and heads == 8 and self.router_fused_attn and self._chain_ok(x.shape[0], name):
+            return ops.router_group_attn_out(x, rg[0], rg[2], L, n_outer, n_inner, outer_stride, seq_stride, eps=rg[1],
+                                             scale=64 ** -0.5)
+        self._r_group_attn(x, tmp, qkv, a, ln, pk, name, L, heads, n_outer, n_inner, outer_stride, seq_stride)
+        return self._r_linres(a, pk, "rg_" + name, to_out, x)
+
+    def _r_mlp_block(self, x, tmp, h, st, pk):
+        """x += mlp(norm4(x)) (models/router.py:491): one chain launch where it pays, else the two row GEMMs."""
+        rg = pk.get("rg_mlp")
+        if rg is not None and rg[0]["w"].shape[0] == 512 and self._chain_ok(x.shape[0], "mlp"):      # (hidden width 512: mlp_ratio 1)
+            return ops.router_mlp_fused(x, rg[0], rg[2], eps=rg[1])
+        self._r_lnlin(x, tmp, st.norm4, pk, "rg_mlp", st.mlp[0].weight, st.mlp[0].bias, h, act="gelu_erf")
+        return self._r_linres(h, pk, "rg_mlp", st.mlp[2], x)
+
     def _r_linres(self, a, pk, key, lin, x):
         """x += Linear(a) on router rows."""
         rg = pk.get(key)
@@ -912,14 +944,13 @@ class DenoiseEngine:
                           o_strides=(per_frame * F, 0, F), scale=hd ** -0.5, prescaled="rg_spatial_attn" in pk)
             self._r_linres(ra, pk, "rg_spatial_attn", st.spatial_attn.to_out[0], rs2)
             # 2. temporal: every (sample, id, location) attends over its T frames
-            self._r_group_attn(rs2, rn, qkv, ra, st.norm2, pk, "temporal_attn", T, heads, B * n_id, per_frame, N, per_frame)
-            self._r_linres(ra, pk, "rg_temporal_attn", st.temporal_attn.to_out[0], rs2)
+            self._r_attn_block(rs2, rn, qkv, ra, st.norm2, pk, "temporal_attn", st.temporal_attn.to_out[0], T, heads,
+                               B * n_id, per_frame, N, per_frame)
             # 3. multi-ID: every (sample, token) attends over the ids
-            self._r_group_attn(rs2, rn, qkv, ra, st.norm3, pk, "multi_id_attn", n_id, heads, B, N, n_id * N, N)
-            self._r_linres(ra, pk, "rg_multi_id_attn", st.multi_id_attn.to_out[0], rs2)
+            self._r_attn_block(rs2, rn, qkv, ra, st.norm3, pk, "multi_id_attn", st.multi_id_attn.to_out[0], n_id, heads,
+                               B, N, n_id * N, N)
             # 4. MLP (GELU erf)
-            self._r_lnlin(rs2, rn, st.norm4, pk, "rg_mlp", st.mlp[0].weight, st.mlp[0].bias, rh, act="gelu_erf")
-            self._r_linres(rh, pk, "rg_mlp", st.mlp[2], rs2)
+            self._r_mlp_block(rs2, rn, rh, st, pk)
         logits = buf("r_logits", B, N, n_id)
         fp = r.final_proj[0]
         rs4 = rs2.view(B, n_id, N, F)
@@ -972,12 +1003,11 @@ class DenoiseEngine:
             # ---- location-major: temporal, multi-ID, MLP
             rp.a_to_b(xa, xb, overlap=overlap if bi == 0 else None)
             xb2 = xb.view(RB, F)
-            self._r_group_attn(xb2, rn_b, qkv_b, ra_b, st.norm2, pk, "temporal_attn", T, heads, n_id, rp.nLB, T * rp.nLB, rp.nLB)
-            self._r_linres(ra_b, pk, "rg_temporal_attn", st.temporal_attn.to_out[0], xb2)
-            self._r_group_attn(xb2, rn_b, qkv_b, ra_b, st.norm3, pk, "multi_id_attn", n_id, heads, 1, T * rp.nLB, 0, T * rp.nLB)
-            self._r_linres(ra_b, pk, "rg_multi_id_attn", st.multi_id_attn.to_out[0], xb2)
-            self._r_lnlin(xb2, rn_b, st.norm4, pk, "rg_mlp", st.mlp[0].weight, st.mlp[0].bias, rh_b, act="gelu_erf")
-            self._r_linres(rh_b, pk, "rg_mlp", st.mlp[2], xb2)
+            self._r_attn_block(xb2, rn_b, qkv_b, ra_b, st.norm2, pk, "temporal_attn", st.temporal_attn.to_out[0], T, heads,
+                               n_id, rp.nLB, T * rp.nLB, rp.nLB)
+            self._r_attn_block(xb2, rn_b, qkv_b, ra_b, st.norm3, pk, "multi_id_attn", st.multi_id_attn.to_out[0], n_id, heads,
+                               1, T * rp.nLB, 0, T * rp.nLB)
+            self._r_mlp_block(xb2, rn_b, rh_b, st, pk)
             if bi + 1 < nblk:
                 xa = rp.b_to_a(xb, xa)
         fp = r.final_proj[0]

@@ -110,6 +110,39 @@ class weight_streaming:
         return False
 
 
+# ---- library options (include/bya.h bya_set_option): the C entry points read no environment ---------------------------
+set_option, get_option = _hip.set_option, _hip.get_option
+
+
+class options:
+    """``with ops.options(gemm_splitk=0, attn_streamk=0): ...`` -- set library options (names: ``_hip.OPTIONS``;
+    ``reference_forms`` takes a mask or an iterable of ``_hip.REFERENCE_FORMS`` names) for the launches ENQUEUED inside the
+    block, restore the previous values on exit."""
+
+    def __init__(self, **kw):
+        forms = kw.get("reference_forms")
+        if forms is not None and not isinstance(forms, int):
+            kw["reference_forms"] = sum(_hip.REFERENCE_FORMS[f] for f in ([forms] if isinstance(forms, str) else forms))
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
+
+
+def strict_summation():
+    """No split-K tails, no stream-K attention: every output element is summed in ONE fixed order whatever the launch's
+    row count -- the mode in which a rank's shard reproduces the unsharded step bit for bit."""
+    return options(gemm_splitk=0, attn_streamk=0)
+
+
 # ---- optional per-entry-point timers (HIP events recorded on the launch stream; used by bench.py) -------------
 _TIMERS = None
 _FLOPS = {}
@@ -729,6 +762,42 @@ def router_group_attn(x, pack, out, L, n_outer, n_inner, outer_stride, seq_strid
     check(lib.bya_router_group_attn(_p(x), _p(pack["w"]), _p(pack["colsum"]), _p(pack["cvec"]), _p(out), M, x.stride(0),
                                     out.stride(0), int(L), int(n_outer), int(n_inner), int(outer_stride), int(seq_stride),
                                     float(eps), float(scale), _stream()), "bya_router_group_attn")
+    _end(tok)
+    return out
+
+
+def router_mlp_fused(x, pack1, pack2, eps=1e-5, out=None, tiles_pass0=0):
+    """x += mlp[2](GELU(mlp[0](LayerNorm(x)))) on router rows in ONE launch, the hidden activation in registers (reference
+    models/router.py:491; include/bya.h bya_router_mlp_fused).  ``pack1`` = ``pack_rowgemm512`` of mlp[0] with norm4 folded
+    in, ``pack2`` of mlp[2].  Bit-identical to ``rowgemm512(x, pack1, h, act="gelu_erf"); rowgemm512(h, pack2, x, res=x)``."""
+    lib = _hip.load()
+    M, K = x.shape
+    out = x if out is None else out
+    assert K == 512 and pack1["ln"] and not pack2["ln"] and pack1["w"].shape == (512, 512) and pack2["w"].shape == (512, 512)
+    assert x.stride(1) == 1 and out.stride(1) == 1 and out.shape == x.shape
+    tok = _begin("bya_router_mlp_fused", 4.0 * M * 512 * K)
+    check(lib.bya_router_mlp_fused(_p(x), _p(pack1["w"]), _p(pack1["colsum"]), _p(pack1["cvec"]), _p(pack2["w"]),
+                                   _p(pack2["cvec"]), _p(out), M, x.stride(0), out.stride(0), float(eps), int(tiles_pass0),
+                                   _stream()), "bya_router_mlp_fused")
+    _end(tok)
+    return out
+
+
+def router_group_attn_out(x, pack, pack_out, L, n_outer, n_inner, outer_stride, seq_stride, eps=1e-5, scale=0.125, out=None,
+                          tiles_pass0=0):
+    """x += to_out(attention over groups of L rows of LayerNorm(x)) in ONE launch (reference models/router.py:482-483,
+    :486-487; include/bya.h bya_router_group_attn_out): ``router_group_attn`` followed by the out-projection + residual, the
+    attention output in registers.  L <= 16.  Bit-identical to the two launches."""
+    lib = _hip.load()
+    M, K = x.shape
+    out = x if out is None else out
+    assert K == 512 and pack["ln"] and pack["w"].shape == (1536, 512) and not pack_out["ln"] and pack_out["w"].shape == (512, 512)
+    assert x.stride(1) == 1 and out.stride(1) == 1 and out.shape == x.shape
+    tok = _begin("bya_router_group_attn_out", 2.0 * M * 2048 * K + 4.0 * M * L * 512)
+    check(lib.bya_router_group_attn_out(_p(x), _p(pack["w"]), _p(pack["colsum"]), _p(pack["cvec"]), _p(pack_out["w"]),
+                                        _p(pack_out["cvec"]), _p(out), M, x.stride(0), out.stride(0), int(L), int(n_outer),
+                                        int(n_inner), int(outer_stride), int(seq_stride), float(eps), float(scale),
+                                        int(tiles_pass0), _stream()), "bya_router_group_attn_out")
     _end(tok)
     return out
 

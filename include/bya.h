@@ -40,6 +40,37 @@ enum { BYA_ACT_NONE = 0, BYA_ACT_GELU_TANH = 1, BYA_ACT_GELU_ERF = 2, BYA_ACT_RE
 int bya_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
+ * Process-wide options (round 6).  The entry points below are functions of their arguments and of THIS table only: the
+ * library never reads the environment.  The host sets what it wants once, after loading the library (the Python module
+ * maps its BYA_* environment variables onto these keys at import, ops.apply_env_options); a launch reads the table when
+ * it is prepared, so a change applies to the launches enqueued after it.  bya_set_option returns BYA_ERR_SHAPE for an
+ * unknown key or a value outside the key's range; bya_get_option writes the current value.
+ * --------------------------------------------------------------------------------------------- */
+enum bya_option {
+    BYA_OPT_GEMM_SPLITK = 0,      /* 1 (default): bya_gemm_bf16 splits the tiles of a partial last round along K when a
+                                     workspace is registered; 0: never (strict summation order: a shard's rows round like the
+                                     whole's); 2: every split tile in two */
+    BYA_OPT_GEMM_SPLITK_MIN = 1,  /* shortest K range (in 64-wide K tiles) a split may produce; 0 = the built-in default */
+    BYA_OPT_GEMM_TILE = 2,        /* -1 (default): tile shape by the cost model; 0..4: force one (tests: every shape through
+                                     every kernel) */
+    BYA_OPT_GEMM_VARIANT = 3,     /* 0 (default): the one-wave-per-SIMD 256 x 256 kernel where eligible; 1: the 8-wave kernel */
+    BYA_OPT_ATTN_STREAMK = 4,     /* 1 (default): the joint attention cuts the items of a partial last round between
+                                     workgroups when a workspace is registered; 0: one workgroup per item */
+    BYA_OPT_FP8_KERNEL = 5,       /* 0 (default): 256 x 256 fp8 kernel where a launch fills it; 1: always the 128 x 128 one */
+    BYA_OPT_P2P_GROUPS = 6,       /* workgroups of a push / exchange launch (16..1024); 0 = the built-in default */
+    BYA_OPT_REFERENCE_FORMS = 7,  /* bit mask, tests only: take the OLDER kernel form of an A/B the docs call closed; every
+                                     form pair is bit-identical, which is what the tests that set these bits assert */
+    BYA_OPT_COUNT = 8
+};
+enum { BYA_REF_ROWGEMM_CHUNKED = 1,    /* N = 512 row GEMM: chunk-balanced kernel instead of the W-stationary one */
+       BYA_REF_KV_MIX_GENERIC = 2,     /* bya_attn_kv_mix: the generic kernel instead of the <= 32-key one */
+       BYA_REF_LN_GENERIC = 4,         /* bya_layernorm at 3072 columns: one row per wave instead of parameters in registers */
+       BYA_REF_ROUTER_SCORES_WAVE = 8, /* bya_router_scores: keys per wave instead of keys in LDS */
+       BYA_REF_ATTN_NARROW_STORE = 16  /* attention epilogues: 8-byte instead of 16-byte stores */ };
+int bya_set_option(int32_t key, int32_t value);
+int bya_get_option(int32_t key, int32_t* value);
+
+/* ---------------------------------------------------------------------------------------------
  * GEMM:  C[z][m,n] = res[z][m,n] + gate[z][row-type(m)][n] * alpha * act( sum_k A[z][m,k] * W[n,k] + rowscale[m]*bias[n] )
  * Replaces every nn.Linear / 2x2-stride Conv2d-as-GEMM on the path: attn1.to_q/k/v/to_out,
  * ff.net.0.proj/ff.net.2 (models/transformer.py:241-260), perceiver to_q/to_out (models/router.py:253,275),
@@ -365,6 +396,32 @@ int bya_rowgemm512(const void* X, const void* W, const float* colsum, const floa
 int bya_router_group_attn(const void* X, const void* Wqkv, const float* colsum, const float* cvec, void* O,
                           int32_t M, int32_t ldx, int32_t ldo, int32_t L, int64_t n_outer, int64_t n_inner,
                           int64_t outer_stride, int64_t seq_stride, float eps, float scale, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Router chains (round 6; csrc/rowchain.hip): two Linears of a SpatialTemporalAttentionBlock sub-block in ONE launch, the
+ * [M, 512] activation between them in registers, updating the router rows in place.
+ *
+ * bya_router_mlp_fused:  C = X + mlp[2]( GELU_erf( mlp[0]( LayerNorm(X) ) ) )  -- models/router.py:491 with norm4 -- i.e.
+ *   bya_rowgemm512(ln = 1, act = GELU_ERF) -> bya_rowgemm512(res = X)  without the hidden tensor.  W1 [512, 512] gamma-
+ *   folded with colsum1 / cvec1 as for bya_rowgemm512 ln = 1; W2 [512, 512] with cvec2 = its bias.  C may be X (every row
+ *   is read and written by one wave); the router's hidden width must equal 512 (mlp_ratio 1, models/router.py:318).
+ * bya_router_group_attn_out:  C = X + to_out( attention over row groups( LayerNorm(X) ) )  -- models/router.py:482-483 /
+ *   :486-487 -- i.e.  bya_router_group_attn -> bya_rowgemm512(res = X)  without the attention-output tensor.  Wqkv, colsum,
+ *   cvec, the group geometry (L, n_outer, n_inner, outer_stride, seq_stride) and scale exactly as for
+ *   bya_router_group_attn; Wo [512, 512] with cvec_o = its bias.  1 <= L <= 16 (a group is held by ONE 16-row MFMA tile;
+ *   longer groups: BYA_ERR_UNSUPPORTED, the caller keeps the two launches).  C may be X.  Rows outside every group are
+ *   neither read nor written.
+ * Both give, BIT FOR BIT, what their two launches give (same MFMA order over K, same epilogue expressions on the same
+ * rounded values).  tiles_pass0: 16-row tiles per workgroup in the first pass over the rows (1..8; 0 = 8); the remainder
+ * is dealt over all workgroups in a short second pass.  A tuning hint: results do not depend on it.
+ * --------------------------------------------------------------------------------------------- */
+int bya_router_mlp_fused(const void* X, const void* W1, const float* colsum1, const float* cvec1, const void* W2,
+                         const float* cvec2, void* C, int32_t M, int32_t ldx, int32_t ldc, float eps, int32_t tiles_pass0,
+                         hipStream_t stream);
+int bya_router_group_attn_out(const void* X, const void* Wqkv, const float* colsum, const float* cvec, const void* Wo,
+                              const float* cvec_o, void* C, int32_t M, int32_t ldx, int32_t ldc, int32_t L, int64_t n_outer,
+                              int64_t n_inner, int64_t outer_stride, int64_t seq_stride, float eps, float scale,
+                              int32_t tiles_pass0, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Classifier-free-guidance combine + scheduler step in one pass over the latents.

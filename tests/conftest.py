@@ -21,6 +21,23 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture
+def lib_options():
+    """``lib_options(gemm_splitk=0, ...)``: set options of the HIP library (ops.options, include/bya.h bya_set_option) until the
+    end of the test -- what ``monkeypatch.setenv("BYA_...")`` did while the C entry points still read the environment."""
+    from bind_your_avatar_implementation_amd import ops
+    stack = []
+
+    def set_(**kw):
+        cm = ops.options(**kw)
+        cm.__enter__()
+        stack.append(cm)
+
+    yield set_
+    for cm in reversed(stack):
+        cm.__exit__(None, None, None)
+
+
 def rel_fro(a, b):
     """relative Frobenius error of a against reference b (both converted to fp32/fp64 on CPU)."""
     import torch

@@ -111,9 +111,9 @@ def test_gemm_fp8_persistent_kernel_equals_the_128_tile_kernel(dev, monkeypatch)
     w8, sw = ops.quantize_rows_fp8(w.to(dev))
     outs = {}
     for kern in ("128", "v4"):
-        monkeypatch.setenv("BYA_FP8_KERNEL", kern)
         outs[kern] = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
-        ops.gemm_fp8(a8, sa, w8, sw, outs[kern], bias=bias, res=res)
+        with ops.options(fp8_kernel=int(kern == "128")):
+            ops.gemm_fp8(a8, sa, w8, sw, outs[kern], bias=bias, res=res)
     diff = (outs["v4"].float() - outs["128"].float()).abs()
     frac = float((diff > 0).float().mean())
     print(f"elements that differ: {frac:.2e}, max abs {float(diff.max()):.3e}")

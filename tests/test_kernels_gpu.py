@@ -111,14 +111,14 @@ def test_gemm_output_past_the_2gib_reach_of_the_epilogue_descriptors(ops, dev, f
     (4000, 1536, 1024, "plain"),          # ragged M (4000 = 15.6 tiles), 16 K-tiles: exactly 2 ranges of 8
     (2222, 3072, 12288, "gate_res"),      # one rank's FF2
 ])
-def test_gemm_split_k_last_round(ops, dev, M, N, K, epi, monkeypatch):
+def test_gemm_split_k_last_round(ops, dev, M, N, K, epi, lib_options):
     """The persistent kernel cuts the last, partial round of 256 x 256 tiles along K when the split-K workspace is
     registered (ops.gemm registers it): partial sums travel through fp32 slabs between workgroups (write-through stores,
-    agent-scope counter).  Against the fp32 product with the usual bar, against the unsplit kernel (BYA_GEMM_SPLITK=0:
+    agent-scope counter).  Against the fp32 product with the usual bar, against the unsplit kernel (option gemm_splitk = 0:
     same products, only the fp32 summation order of a split tile differs) and 12 repeats bit-identical on a busy GPU
     (a wrong wait, a stale slab or a counter that is not reset shows as rare wrong tiles).  By default only K-ranges of
-    40+ K-tiles are split (K = 12288: the exchange costs ~20 us); BYA_GEMM_SPLITK_MIN=8 makes every shape here split."""
-    monkeypatch.setenv("BYA_GEMM_SPLITK_MIN", "8")
+    40+ K-tiles are split (K = 12288: the exchange costs ~20 us); option gemm_splitk_min = 8 makes every shape here split."""
+    lib_options(gemm_splitk_min=8)
     a, w, b = rnd((M, K), dev, 31), rnd((N, K), dev, 32, K ** -0.5), rnd((N,), dev, 33, 0.5)
     kw, ref = {}, a.float() @ w.float().T + b.float()
     res = rnd((M, N), dev, 34)
@@ -142,11 +142,8 @@ def test_gemm_split_k_last_round(ops, dev, M, N, K, epi, monkeypatch):
         return out
     first = run()
     check(first, ref, what=f"split-K gemm {M}x{N}x{K} {epi}")
-    os.environ["BYA_GEMM_SPLITK"] = "0"
-    try:
+    with ops.options(gemm_splitk=0):
         unsplit = run()
-    finally:
-        del os.environ["BYA_GEMM_SPLITK"]
     d = (first.float() - unsplit.float()).abs()
     frac = (d > 0).float().mean().item()
     print(f"split vs unsplit: {frac * 100:.2f} % of the outputs differ, max {d.max().item():.3e} (one bf16 step of the value)")
@@ -453,7 +450,7 @@ def test_rowgemm512_repeatable_at_router_shape(ops, dev, N, ln, res):
 @pytest.mark.parametrize("res,act", [(False, None), (True, None), (True, "gelu_erf"), (False, "gelu_erf")])
 def test_rowgemm512_w_stationary_form_matches_chunk_balanced(ops, dev, monkeypatch, M, res, act):
     """N = 512 without LayerNorm takes the W-stationary kernel (one W quarter per workgroup, rows streamed) for
-    2048 <= M <= 65536; BYA_ROWGEMM_Q=0 keeps the chunk-balanced kernel.  Same MFMA order over K per output element, so
+    2048 <= M <= 65536; the reference form "rowgemm_chunked" (ops.options) keeps the chunk-balanced kernel.  Same MFMA order over K per output element, so
     the two agree BIT FOR BIT -- ragged tile counts (waves with 0, 1, odd numbers of 16-row tiles, a last tile of 1 or 15
     rows), strided X, residual added in place."""
     xw = rnd((M, 768), dev, 90 + M % 7)
@@ -462,12 +459,12 @@ def test_rowgemm512_w_stationary_form_matches_chunk_balanced(ops, dev, monkeypat
     pack = ops.pack_rowgemm512(w, b, None, None)
     r = rnd((M, 512), dev, 93) if res else None
     def run(flag):
-        monkeypatch.setenv("BYA_ROWGEMM_Q", flag)
         out = r.clone() if res else torch.full((M, 512), 7.0, dtype=torch.bfloat16, device=dev)
-        ops.rowgemm512(x, pack, out, res=out if res else None, act=act)
+        with ops.options(reference_forms=[] if flag else "rowgemm_chunked"):
+            ops.rowgemm512(x, pack, out, res=out if res else None, act=act)
         torch.cuda.synchronize()
         return out
-    assert torch.equal(run("1"), run("0"))
+    assert torch.equal(run(True), run(False))
 
 
 def _group_attn_inputs(dev, M, seed):
@@ -571,6 +568,99 @@ def test_router_group_attn_repeatable_and_masks_exact(ops, dev):
         part = ops.router_group_attn(shard, pack, torch.zeros(3 * n, 512, dtype=torch.bfloat16, device=dev), 3, 1, n, 3 * n, n)
         want = torch.cat([whole[i * N3 + lo:i * N3 + hi] for i in range(3)])
         assert torch.equal(part, want), (lo, hi)
+
+
+@pytest.mark.parametrize("M,tp0", [(35100, 0), (35100, 5), (4388, 0), (2049, 3), (300, 0), (15, 1), (70200, 0)])
+def test_router_mlp_chain_is_bit_identical_to_its_two_launches(ops, dev, M, tp0):
+    """bya_router_mlp_fused (csrc/rowchain.hip: LayerNorm -> mlp[0] -> GELU -> mlp[2] -> + x in one launch, the hidden
+    activation in registers) against the two bya_rowgemm512 launches it replaces: same MFMA order over K, same epilogue
+    expressions on the same rounded values => torch.equal, for one pass, a pass + remainder (35100 rows = 2194 tiles on 256
+    workgroups), three passes (70200), ragged last tiles, every first-pass size.  Strided rows, in place.  And against the
+    fp32 chain at the row GEMM's bar ("no further from it than the reference's own bf16 op chain")."""
+    g = torch.Generator().manual_seed(M)
+    xw = bf(torch.randn(M, 640, generator=g) * (0.3 + 2.7 * torch.rand(M, 1, generator=g)) + torch.randn(M, 1, generator=g) * 2).to(dev)
+    x = xw[:, 64:576]                                                 # row stride 640
+    w1, b1 = rnd((512, 512), dev, 70, 512 ** -0.5), rnd((512,), dev, 71, 0.2)
+    w2, b2 = rnd((512, 512), dev, 72, 512 ** -0.5), rnd((512,), dev, 73, 0.2)
+    gam, bet = bf(1 + 0.3 * torch.randn(512, generator=g)).to(dev), bf(0.2 * torch.randn(512, generator=g)).to(dev)
+    p1, p2 = ops.pack_rowgemm512(w1, b1, gam, bet), ops.pack_rowgemm512(w2, b2)
+    h = torch.empty(M, 512, dtype=torch.bfloat16, device=dev)
+    two = x.clone()
+    ops.rowgemm512(x, p1, h, act="gelu_erf")
+    ops.rowgemm512(h, p2, two, res=two)
+    keep = xw.clone()
+    ops.router_mlp_fused(x, p1, p2, tiles_pass0=tp0)                  # in place, through the strided view
+    assert torch.equal(x, two)
+    assert torch.equal(xw[:, :64], keep[:, :64]) and torch.equal(xw[:, 576:], keep[:, 576:]), "columns outside the view were written"
+    x0 = keep[:, 64:576].float()
+    def chain(rounded):
+        r_ = (lambda v: bf(v).float()) if rounded else (lambda v: v)
+        y = r_(F.layer_norm(x0, (512,), gam.float(), bet.float(), 1e-5))
+        y = r_(F.gelu(r_(y @ w1.float().T + b1.float())))
+        return r_(x0 + r_(y @ w2.float().T + b2.float()))
+    truth, ref16 = chain(False), chain(True)
+    e, e16 = rel_fro(x.float(), truth), rel_fro(ref16, truth)
+    print(f"router MLP chain M={M}: vs fp32 {e:.3e} (reference bf16 chain {e16:.3e})")
+    assert e <= 1.25 * e16 + 2e-4 and torch.isfinite(x.float()).all()
+
+
+@pytest.mark.parametrize("name,L,n_outer,n_inner,outer_stride,seq_stride,M,tp0", [
+    ("temporal 13 frames x 2 ids", 13, 2, 1350, 17550, 1350, 35100, 0),        # 2700 tiles: 8 per workgroup + a remainder pass of 3
+    ("temporal, first pass of 6", 13, 2, 1350, 17550, 1350, 35100, 6),
+    ("multi-ID 2 ids", 2, 1, 17550, 35100, 17550, 35100, 0),                    # 8 groups per tile, 2194 tiles
+    ("multi-ID 3 ids", 3, 1, 1111, 3333, 1111, 3333, 0),                        # 4-slot cells, ragged tail
+    ("temporal, one rank's location range", 13, 2, 169, 13 * 169, 169, 2 * 13 * 169, 0),
+    ("temporal 16 frames, CFG batch", 16, 4, 77, 16 * 77, 77, 4 * 16 * 77 + 5, 2),
+    ("single rows", 1, 1, 300, 0, 0, 300, 0),
+])
+def test_router_attn_chain_is_bit_identical_to_its_two_launches(ops, dev, name, L, n_outer, n_inner, outer_stride, seq_stride, M, tp0):
+    """bya_router_group_attn_out (LayerNorm -> q|k|v -> group attention -> to_out -> + x in one launch, the attention output
+    in registers) against bya_router_group_attn + bya_rowgemm512(res = x): torch.equal on the rows of the groups; rows
+    outside every group keep their values (the pair's out-projection would have touched them: compared on group rows only).
+    Groups longer than one tile are refused."""
+    x, w, b, gam, bet = _group_attn_inputs(dev, M, 190 + L)
+    wo, bo = rnd((512, 512), dev, 191, 512 ** -0.5), rnd((512,), dev, 192, 0.2)
+    pack, po = ops.pack_rowgemm512(w, b, gam, bet), ops.pack_rowgemm512(wo, bo)
+    rows = _group_rows(L, n_outer, n_inner, outer_stride, seq_stride, dev).reshape(-1)
+    a = torch.zeros(M, 512, dtype=torch.bfloat16, device=dev)
+    ops.router_group_attn(x, pack, a, L, n_outer, n_inner, outer_stride, seq_stride)
+    two = x.clone()
+    ops.rowgemm512(a, po, two, res=two)
+    one = x.clone()
+    ops.router_group_attn_out(one, pack, po, L, n_outer, n_inner, outer_stride, seq_stride, tiles_pass0=tp0)
+    assert torch.equal(one[rows], two[rows]), name
+    touched = torch.zeros(M, dtype=torch.bool, device=dev)
+    touched[rows] = True
+    assert torch.equal(one[~touched], x[~touched]), "rows outside the groups were written"
+    assert torch.isfinite(one.float()).all()
+    with pytest.raises(Exception):
+        ops.router_group_attn_out(one, pack, po, 17, 1, 1, 0, 1)
+
+
+def test_router_chains_repeatable_on_a_busy_gpu(ops, dev):
+    """The chains' W ring is synchronised with counted waits that differ by phase (none, then two output stores per chunk)
+    and by wave (waves without a tile in the remainder pass issue no stores): 15 launches each at the router's full size on
+    a busy GPU, every result bit-identical to the first."""
+    M = 35100
+    x, w, b, gam, bet = _group_attn_inputs(dev, M, 300)
+    wo, bo = rnd((512, 512), dev, 301, 512 ** -0.5), rnd((512,), dev, 302, 0.2)
+    w1, b1 = rnd((512, 512), dev, 303, 512 ** -0.5), rnd((512,), dev, 304, 0.2)
+    pack, po = ops.pack_rowgemm512(w, b, gam, bet), ops.pack_rowgemm512(wo, bo)
+    p1 = ops.pack_rowgemm512(w1, b1, gam, bet)
+    runs = {"temporal": lambda: ops.router_group_attn_out(x.clone(), pack, po, 13, 2, 1350, 17550, 1350),
+            "multi-ID": lambda: ops.router_group_attn_out(x.clone(), pack, po, 2, 1, 17550, 35100, 17550),
+            "mlp": lambda: ops.router_mlp_fused(x.clone(), p1, po)}
+    first = {k: f() for k, f in runs.items()}
+    torch.cuda.synchronize()
+    aa, bb = rnd((8192, 8192), dev, 86), rnd((8192, 8192), dev, 87)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            aa @ bb
+    outs = {k: [f() for _ in range(15)] for k, f in runs.items()}
+    torch.cuda.synchronize()
+    for k in runs:
+        assert all(torch.equal(first[k], o) for o in outs[k]), k
 
 
 @pytest.mark.parametrize("variant", ["v4", "w8"])
@@ -731,7 +821,7 @@ def test_layernorm_adaln_zero(ops, dev):
 
 def test_layernorm_adaln_rows_kernel(ops, dev, monkeypatch):
     """The AdaLN LayerNorm of the DiT width keeps A = w (1 + scale), B = b (1 + scale) + shift in registers and walks several
-    rows per wave (BYA_LN_ROWS=0: one row per wave, parameters re-read per row).  Against fp32 at the usual bar; bit-identical
+    rows per wave (reference form "ln_generic": one row per wave, parameters re-read per row).  Against fp32 at the usual bar; bit-identical
     to the one-row-per-wave kernel (which evaluates the same fma); and INDEPENDENT of how the rows
     are cut into launches -- a shard of the sequence must round exactly like the whole (ranges that cross the text / video
     split and a batch boundary, strided input and output)."""
@@ -751,16 +841,14 @@ def test_layernorm_adaln_rows_kernel(ops, dev, monkeypatch):
     ref = torch.cat([ln[:, :T] * (1 + m[:, None, 4 * D:5 * D]) + m[:, None, 3 * D:4 * D],
                      ln[:, T:] * (1 + m[:, None, D:2 * D]) + m[:, None, 0:D]], 1)
     check(rows, ref, what="AdaLN rows kernel")
-    monkeypatch.setenv("BYA_LN_ROWS", "0")
-    ops.layernorm(x, out, w, b, split=T, **kw)
-    monkeypatch.delenv("BYA_LN_ROWS")
+    with ops.options(reference_forms="ln_generic"):
+        ops.layernorm(x, out, w, b, split=T, **kw)
     assert torch.equal(out, rows)                              # both kernels evaluate the same fma
     # without modulation the rows kernel is the plain affine LayerNorm, bit for bit the one-row-per-wave kernel
     a1, a0 = torch.empty(B, S, D, dtype=torch.bfloat16, device=dev), torch.empty(B, S, D, dtype=torch.bfloat16, device=dev)
     ops.layernorm(x, a1, w, b, eps=1e-5)
-    monkeypatch.setenv("BYA_LN_ROWS", "0")
-    ops.layernorm(x, a0, w, b, eps=1e-5)
-    monkeypatch.delenv("BYA_LN_ROWS")
+    with ops.options(reference_forms="ln_generic"):
+        ops.layernorm(x, a0, w, b, eps=1e-5)
     assert torch.equal(a1, a0)
     # any cut of the rows into launches gives the same bits
     for lo, hi in ((0, 100), (100, 226), (226, 227), (227, 900), (900, S)):
@@ -938,7 +1026,7 @@ def test_linear_small_m_and_timestep(ops, dev):
 @pytest.mark.parametrize("NID,N", [(2, 150), (2, 17550), (3, 4099), (4, 6001)])
 def test_router_scores(ops, dev, monkeypatch, NID, N):
     """From 4096 tokens on the identity's 32 keys are resident in LDS (one workgroup per CU, whole identities, every wave on
-    its own 16-token tiles); BYA_ROUTER_SCORES_LDS=0 keeps the kernel that re-reads them per wave.  Same MFMA order:
+    its own 16-token tiles); the reference form "router_scores_wave" keeps the kernel that re-reads them per wave.  Same MFMA order:
     bit-identical, ragged last tile and 2-4 identities included."""
     qr, kr = rnd((N, 2048), dev, 90), rnd((NID, 32, 2048), dev, 91, 0.2)
     w, b = rnd((512,), dev, 92, 0.2) + 1, rnd((512,), dev, 93, 0.2)
@@ -950,9 +1038,9 @@ def test_router_scores(ops, dev, monkeypatch, NID, N):
     s = (qh @ kh.transpose(-2, -1)).permute(0, 2, 3, 1).reshape(NID, N, 512)
     ref = bf(F.layer_norm(s, (512,), w.float(), b.float(), 1e-5)).float() + pos.float()
     check(out, ref, tol=2e-3, what="router_scores")
-    monkeypatch.setenv("BYA_ROUTER_SCORES_LDS", "0")
     out0 = torch.empty_like(out)
-    ops.router_scores(qr, kr, w, b, pos, out0, NID, N)
+    with ops.options(reference_forms="router_scores_wave"):
+        ops.router_scores(qr, kr, w, b, pos, out0, NID, N)
     assert torch.equal(out, out0)
 
 
@@ -1175,7 +1263,7 @@ def test_attn_static_bound_softmax_is_shift_tolerant(ops, dev, S):
 @pytest.mark.parametrize("S,H", [(17776, 48), (5000, 16), (33976, 8), (17776, 12)])
 def test_attn_stream_k_matches_one_workgroup_per_item(ops, dev, S, H, monkeypatch):
     """The joint attention as 256 persistent workgroups over evenly cut (item, key-tile) ranges (stream-K; workspace
-    registered by ops.attention) against the one-workgroup-per-item launch of the same kernel (BYA_ATTN_STREAMK=0).
+    registered by ops.attention) against the one-workgroup-per-item launch of the same kernel (option attn_streamk = 0).
     Partials of the static-bound softmax are additive, so an item cut between two workgroups differs from the uncut form by
     fp32 summation order only: (1) every row outside the <= 248 cut items is bit-identical, (2) cut rows agree to bf16
     rounding, (3) both agree with the fp32 softmax on sampled heads, (4) 8 launches on a busy GPU are bit-identical (the
@@ -1198,9 +1286,8 @@ def test_attn_stream_k_matches_one_workgroup_per_item(ops, dev, S, H, monkeypatc
         ops.self_attention(q, k, v, out, heads=H, prescaled=True, score_bound=bound, tag="joint")
         return out
     sk = run()
-    monkeypatch.setenv("BYA_ATTN_STREAMK", "0")
-    plain = run()
-    monkeypatch.delenv("BYA_ATTN_STREAMK")
+    with ops.options(attn_streamk=0):
+        plain = run()
     diff_rows = (sk != plain).view(S, H, D).any(dim=-1)                       # [S, H]
     n_diff_tiles = int(diff_rows.view(-1, H).float().sum().item())
     # a cut item is one (head, 512-row q-tile): at most 248 of them
@@ -1234,7 +1321,7 @@ def test_attn_stream_k_matches_one_workgroup_per_item(ops, dev, S, H, monkeypatc
 @pytest.mark.parametrize("o_off", [0, 4])
 def test_attn_wide_epilogue_stores_match_the_8_byte_ones(ops, dev, monkeypatch, D, H, Sq, Skv, kw, o_off):
     """The attention epilogues store 16 bytes per lane after a v_permlane32_swap exchange between the half-waves (32
-    contiguous bytes per row and instruction instead of 16); BYA_ATTN_WIDE_STORE=0, or an output that is only 8-byte
+    contiguous bytes per row and instruction instead of 16); the reference form "attn_narrow_store", or an output that is only 8-byte
     aligned (o_off = 4 elements), keeps the 8-byte stores.  Same values, same addresses: bit-identical, ragged last
     q tile included, and nothing written outside the heads' columns (generic d64 / d128 kernels and the joint w4 kernel)."""
     E = H * D
@@ -1245,14 +1332,14 @@ def test_attn_wide_epilogue_stores_match_the_8_byte_ones(ops, dev, monkeypatch, 
     W = E + 16
     buf = torch.empty(Sq * W + 8, dtype=torch.bfloat16, device=dev)
     def run(flag):
-        monkeypatch.setenv("BYA_ATTN_WIDE_STORE", flag)
         buf.fill_(5.0)
         o = buf[o_off:o_off + Sq * W].view(1, Sq, W)[..., 8:8 + E]
-        ops.attention(q, k, v, o, head_dim=D, heads=H, nb1=1, nb2=1, Sq=Sq, Skv=Skv, q_strides=(0, 0, E), k_strides=(0, 0, E),
-                      v_strides=(0, 0, E), o_strides=(0, 0, W), scale=D ** -0.5, **kw)
+        with ops.options(reference_forms=[] if flag else "attn_narrow_store"):
+            ops.attention(q, k, v, o, head_dim=D, heads=H, nb1=1, nb2=1, Sq=Sq, Skv=Skv, q_strides=(0, 0, E), k_strides=(0, 0, E),
+                          v_strides=(0, 0, E), o_strides=(0, 0, W), scale=D ** -0.5, **kw)
         torch.cuda.synchronize()
         return buf.clone()
-    a, b = run("1"), run("0")
+    a, b = run(True), run(False)
     assert torch.equal(a, b)
     rows = a[o_off:o_off + Sq * W].view(Sq, W)
     assert bool((rows[:, :8] == 5.0).all()) and bool((rows[:, 8 + E:] == 5.0).all()) and not bool((rows[:, 8:8 + E] == 5.0).all())
@@ -1333,7 +1420,7 @@ def test_attn_kv_mix_equals_attention_then_routed_mix(ops, dev, mode, D, H, n_id
                                                       ("face", 128, 2, 1, 1, 31, 32), ("face", 128, 3, 4, 2, 1000, 9)])
 def test_attn_kv_mix_32_key_form_matches_one_tile_per_workgroup(ops, dev, monkeypatch, mode, D, H, n_id, grp, Sq, Skv):
     """Up to 32 keys per identity bya_attn_kv_mix runs the persistent form (K / V of every identity resident in LDS, every
-    wave walking its own 32-row tiles, z stored as whole head segments through LDS); BYA_KV_MIX32=0 keeps the
+    wave walking its own 32-row tiles, z stored as whole head segments through LDS); the reference form "kv_mix_generic" keeps the
     one-128-row-tile-per-workgroup kernel on 64-key tiles.  Same arithmetic per element -> BIT-IDENTICAL z and weight
     sums, at the step's two shapes, with ragged row counts, 1-4 identities, fewer than 32 keys, strided q / k / v / z."""
     E = H * D
@@ -1345,16 +1432,16 @@ def test_attn_kv_mix_32_key_form_matches_one_tile_per_workgroup(ops, dev, monkey
     af = None if mode == "face" else torch.roll(torch.eye(n_id), 1, dims=1).to(torch.bfloat16).to(dev)
     W = E + pad
     def run(flag):
-        monkeypatch.setenv("BYA_KV_MIX32", flag)
         zw.fill_(3.0)
         ws = torch.full((grp * Sq,), -1.0, dtype=torch.float32, device=dev)
-        ops.attn_kv_mix(qw[..., pad:], kw[..., :E], vw[..., 8:], r, af, zw[..., 16:], ws, head_dim=D, heads=H, n_id=n_id, n_grp=grp,
-                        Sq=Sq, Skv=Skv, q_strides=(Sq * W, W), k_strides=(grp * Skv * W, Skv * W, W),
-                        v_strides=(grp * Skv * W, Skv * W, W), z_strides=(Sq * W, W), scale=D ** -0.5)
+        with ops.options(reference_forms=[] if flag else "kv_mix_generic"):
+            ops.attn_kv_mix(qw[..., pad:], kw[..., :E], vw[..., 8:], r, af, zw[..., 16:], ws, head_dim=D, heads=H, n_id=n_id, n_grp=grp,
+                            Sq=Sq, Skv=Skv, q_strides=(Sq * W, W), k_strides=(grp * Skv * W, Skv * W, W),
+                            v_strides=(grp * Skv * W, Skv * W, W), z_strides=(Sq * W, W), scale=D ** -0.5)
         torch.cuda.synchronize()
         return zw.clone(), ws
-    z1, w1 = run("1")
-    z0, w0 = run("0")
+    z1, w1 = run(True)
+    z0, w0 = run(False)
     assert torch.equal(z1, z0) and torch.equal(w1, w0)
     assert bool((z1[..., :16] == 3.0).all()) and bool((z1[..., 16 + E:] == 3.0).all())     # nothing outside the heads' columns
 
