@@ -98,9 +98,8 @@ SIGNATURES = {
     "bya_allgather_kv": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "bya_alltoall_router": [_vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "bya_p2p_push": [_vp, _i32, _i64, _vp, _i32, _i32, _vp, _vp],
-    "bya_p2p_wait": [_vp, _i32, _vp],
-    "bya_p2p_exchange": [_vp, _i32, _i64, _vp, _i32, _i32, _vp, _vp],
-    "bya_p2p_set_wait_limit_ms": [_i64],
+    "bya_p2p_wait": [_vp, _i32, _vp, _i64, _vp],
+    "bya_p2p_exchange": [_vp, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _vp],
     "bya_p2p_poison": [_vp, _i32, _vp, _i64, _vp],
     "bya_p2p_alloc": [_i64, _i32, _c.POINTER(_vp)],
     "bya_p2p_free": [_vp],

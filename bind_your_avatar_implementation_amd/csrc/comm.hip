@@ -117,21 +117,26 @@ extern "C" int bya_alltoall_router(const void* send, void* recv, const int64_t* 
 // before a consumer -- a later kernel on the stream -- reads them (round 4 waited with ONE wave: one XCD).  A peer may only
 // overwrite a receive buffer after this rank has consumed it: the step's own data dependencies guarantee that for every
 // exchange the engine issues (multi-GPU section, lists them).
-// A wait is bounded by WALL time (s_memrealtime, bya_p2p_set_wait_limit_ms, default 30 s): when it gives up it counts the
-// event in the channel's word 35, which is STICKY; bya_p2p_poison -- the last launch of a sharded step -- overwrites the
-// step's output with NaN if any channel of the group carries one, so a result made from a stale buffer cannot be used.
+// A wait is bounded by WALL time (s_memrealtime; the limit is an argument of the launch, default 30 s): when it gives up it
+// counts the event in the channel's word 35 AND in word 37 of the group's first control block, both STICKY.  A wait that
+// finds the group's word set does not poll at all (round 5 bounded every wait separately: with ~280 exchanges per
+// rank-step a dead peer stalled each STEP for hours before anything was reported); it counts itself as timed out and
+// returns, so the remaining launches of the step -- and of the clip -- run through at full speed on garbage.
+// bya_p2p_poison -- the last launch of a sharded step -- overwrites the step's output with NaN if any channel of the group
+// carries a time-out, so a result made from a stale buffer cannot be used, and the host raises at the next check.
 namespace {
 
 constexpr int P2P_CHUNK = 64 * 1024;                 // bytes per workgroup iteration
 constexpr int P2P_CTRL_WORDS = 64;                   // per channel: [0..31] flags by source rank, [32] sent, [33] expected,
 constexpr int P2P_SENT = 32, P2P_EXPECT = 33, P2P_DONE = 34, P2P_TIMEOUTS = 35, P2P_WAITED = 36;   // [34] push workgroups done,
                                                                                                    // [35] time-outs, [36] wait workgroups done
+constexpr int P2P_GROUP_TIMEOUTS = 37;               // in the group's FIRST control block only: time-outs of any channel
 constexpr int P2P_WAIT_GROUPS = 16;                  // workgroups of a wait: two per XCD under round-robin dispatch
 constexpr int P2P_THREADS = 256;                    // lanes of a push workgroup: 16 waves x 4 loads of 16 bytes in flight per lane (a 4-wave
                                                      // workgroup per CU kept 16 KB in flight: 11 GB/s per CU at HBM latency)
 constexpr int P2P_MAX_GROUPS = 128;                  // workgroups of a push (BYA_P2P_GROUPS: probe switch, read per call)
 
-std::atomic<long long> g_wait_limit_ticks{30ll * 100000000ll};          // s_memrealtime ticks (100 MHz)
+constexpr long long P2P_DEFAULT_LIMIT_TICKS = 30ll * 100000000ll;        // s_memrealtime ticks (100 MHz): 30 s
 
 // the copy loop of one workgroup.  A table entry is a 2-D piece: `rows` rows of `row_bytes` bytes, `src_pitch` / `dst_pitch`
 // bytes apart (a contiguous piece is one row).  Its chunks: a row longer than P2P_CHUNK is cut into P2P_CHUNK-byte chunks
@@ -218,17 +223,22 @@ __device__ __forceinline__ void p2p_copy_chunks(const bya_p2p_copy* __restrict__
 // one workgroup's wait: lanes < world poll the local flags until all carry `expect` (signed distance: sequence numbers wrap
 // after 4 G exchanges) or the wall-clock limit passes; then a system-scope acquire; the workgroup that finishes last
 // advances the channel's expect counter.  `groups` = workgroups taking part.
-__device__ __forceinline__ void p2p_wait_flags(unsigned* __restrict__ ctrl, int world, unsigned expect, long long limit_ticks,
-                                               unsigned groups) {
+__device__ __forceinline__ void p2p_wait_flags(unsigned* __restrict__ ctrl, unsigned* __restrict__ group_ctrl, int world, unsigned expect,
+                                               long long limit_ticks, unsigned groups) {
     const int lane = threadIdx.x;
     if (lane < world) {
+        unsigned* const gt = group_ctrl ? group_ctrl + P2P_GROUP_TIMEOUTS : ctrl + P2P_TIMEOUTS;     // (no group block: the channel's own word)
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while ((int)(__hip_atomic_load(ctrl + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - expect) < 0) {
+        // a wait of this group has already given up: the peers are late or gone, this one would only add its full limit
+        bool dead = __hip_atomic_load(gt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        while (!dead && (int)(__hip_atomic_load(ctrl + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - expect) < 0) {
             __builtin_amdgcn_s_sleep(16);
-            if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > limit_ticks) {
-                __hip_atomic_fetch_add(ctrl + P2P_TIMEOUTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
+            dead = __hip_atomic_load(gt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                   (long long)(__builtin_amdgcn_s_memrealtime() - t0) > limit_ticks;
+        }
+        if (dead) {
+            __hip_atomic_fetch_add(ctrl + P2P_TIMEOUTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (group_ctrl) __hip_atomic_fetch_add(group_ctrl + P2P_GROUP_TIMEOUTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // system scope: this CU's L1 and this XCD's L2 drop stale lines
@@ -247,7 +257,7 @@ __device__ __forceinline__ void p2p_wait_flags(unsigned* __restrict__ ctrl, int 
 template <bool WAIT>
 __global__ __launch_bounds__(P2P_THREADS) void p2p_push_kernel(const bya_p2p_copy* __restrict__ copies, int n_copies, long long total_chunks,
                                                         unsigned* const* __restrict__ peer_ctrl, int world, int rank,
-                                                        unsigned* __restrict__ ctrl, long long limit_ticks) {
+                                                        unsigned* __restrict__ ctrl, unsigned* __restrict__ group_ctrl, long long limit_ticks) {
     const int tid = threadIdx.x;
     unsigned expect = 0;
     if (WAIT) expect = __hip_atomic_load(ctrl + P2P_EXPECT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;   // (before anybody can advance it)
@@ -269,13 +279,14 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_push_kernel(const bya_p2p_cop
         // the first P2P_WAIT_GROUPS workgroups (two per XCD under round-robin dispatch, like the wait kernel's) stay to wait;
         // with all 128 polling the exchange of an 8-rank step took 8 us longer than push + a separate wait launch
         __syncthreads();
-        if (tid < 64) p2p_wait_flags(ctrl, world, expect, limit_ticks, gridDim.x < P2P_WAIT_GROUPS ? gridDim.x : P2P_WAIT_GROUPS);
+        if (tid < 64) p2p_wait_flags(ctrl, group_ctrl, world, expect, limit_ticks, gridDim.x < P2P_WAIT_GROUPS ? gridDim.x : P2P_WAIT_GROUPS);
     }
 }
 
-__global__ __launch_bounds__(64) void p2p_wait_kernel(unsigned* __restrict__ ctrl, int world, long long limit_ticks) {
+__global__ __launch_bounds__(64) void p2p_wait_kernel(unsigned* __restrict__ ctrl, unsigned* __restrict__ group_ctrl, int world,
+                                                      long long limit_ticks) {
     const unsigned expect = __hip_atomic_load(ctrl + P2P_EXPECT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    p2p_wait_flags(ctrl, world, expect, limit_ticks, gridDim.x);
+    p2p_wait_flags(ctrl, group_ctrl, world, expect, limit_ticks, gridDim.x);
 }
 
 // out[0 .. n) := NaN (bf16) if any of the n_channels control blocks starting at ctrl_base carries a time-out
@@ -287,6 +298,8 @@ __global__ __launch_bounds__(256) void p2p_poison_kernel(const unsigned* __restr
     if (!__syncthreads_or(bad)) return;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = 0x7fc0u;
 }
+
+inline long long p2p_limit_ticks(int64_t ms) { return ms > 0 ? (long long)ms * 100000ll : P2P_DEFAULT_LIMIT_TICKS; }
 
 inline long long p2p_max_groups() {
     const int v = bya_opt(BYA_OPT_P2P_GROUPS);
@@ -310,35 +323,31 @@ extern "C" int bya_p2p_push(const bya_p2p_copy* copies_dev, int32_t n_copies, in
     // enough workgroups to keep every xGMI link and the local HBM busy, few enough to leave CUs to the compute stream
     const long long cap = p2p_max_groups(), want = total_chunks < cap ? total_chunks : cap;
     BYA_LAUNCH(p2p_push_kernel<false>, dim3((unsigned)want), dim3(P2P_THREADS), 0, stream, copies_dev, n_copies, (long long)total_chunks,
-               reinterpret_cast<unsigned* const*>(peer_ctrl_dev), world, rank, static_cast<unsigned*>(ctrl), 0ll);
+               reinterpret_cast<unsigned* const*>(peer_ctrl_dev), world, rank, static_cast<unsigned*>(ctrl), static_cast<unsigned*>(nullptr), 0ll);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
-extern "C" int bya_p2p_wait(void* ctrl, int32_t world, hipStream_t stream) {
+extern "C" int bya_p2p_wait(void* ctrl, int32_t world, void* group_ctrl, int64_t wait_limit_ms, hipStream_t stream) {
     if (!ctrl || world <= 0 || world > 32) return BYA_ERR_SHAPE;
-    BYA_LAUNCH(p2p_wait_kernel, dim3(P2P_WAIT_GROUPS), dim3(64), 0, stream, static_cast<unsigned*>(ctrl), world,
-               g_wait_limit_ticks.load(std::memory_order_relaxed));
+    if (((uintptr_t)ctrl | (uintptr_t)group_ctrl) & 3) return BYA_ERR_ALIGN;
+    BYA_LAUNCH(p2p_wait_kernel, dim3(P2P_WAIT_GROUPS), dim3(64), 0, stream, static_cast<unsigned*>(ctrl), static_cast<unsigned*>(group_ctrl),
+               world, p2p_limit_ticks(wait_limit_ms));
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
 extern "C" int bya_p2p_exchange(const bya_p2p_copy* copies_dev, int32_t n_copies, int64_t total_chunks, void* const* peer_ctrl_dev,
-                                int32_t world, int32_t rank, void* ctrl, hipStream_t stream) {
+                                int32_t world, int32_t rank, void* ctrl, void* group_ctrl, int64_t wait_limit_ms, hipStream_t stream) {
     const int rc = p2p_check(copies_dev, peer_ctrl_dev, ctrl, n_copies, total_chunks, world, rank);
     if (rc != BYA_OK) return rc;
+    if ((uintptr_t)group_ctrl & 3) return BYA_ERR_ALIGN;
     // at least P2P_WAIT_GROUPS workgroups, so that the acquire at the end of the wait reaches every XCD
     const long long cap = p2p_max_groups();
     long long want = total_chunks < cap ? total_chunks : cap;
     if (want < P2P_WAIT_GROUPS) want = P2P_WAIT_GROUPS;
     BYA_LAUNCH(p2p_push_kernel<true>, dim3((unsigned)want), dim3(P2P_THREADS), 0, stream, copies_dev, n_copies, (long long)total_chunks,
-               reinterpret_cast<unsigned* const*>(peer_ctrl_dev), world, rank, static_cast<unsigned*>(ctrl),
-               g_wait_limit_ticks.load(std::memory_order_relaxed));
+               reinterpret_cast<unsigned* const*>(peer_ctrl_dev), world, rank, static_cast<unsigned*>(ctrl), static_cast<unsigned*>(group_ctrl),
+               p2p_limit_ticks(wait_limit_ms));
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
-}
-
-extern "C" int bya_p2p_set_wait_limit_ms(int64_t ms) {
-    if (ms <= 0) return BYA_ERR_SHAPE;
-    g_wait_limit_ticks.store((long long)ms * 100000ll, std::memory_order_relaxed);
-    return BYA_OK;
 }
 
 extern "C" int bya_p2p_poison(const void* ctrl_base, int32_t n_channels, void* out, int64_t n_elems, hipStream_t stream) {

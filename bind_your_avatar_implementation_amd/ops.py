@@ -365,11 +365,13 @@ def gemm_qkv_norm_rope(a, w, out, bias, split, qw, qb, kw, kb, cos, sin, text_ro
     if cos is not None:
         assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
         assert cos.shape == (M - text_rows, 64)
-    tok = _begin("bya_gemm_bf16" if M >= 1024 else "bya_gemm_bf16_small_m", 2.0 * ab * M * N * K)
+    tok = _begin("bya_gemm_bf16" if M >= 1024 else "bya_gemm_bf16_small_m")
     rc = lib.bya_gemm_qkv_norm_rope(_p(a), _p(w), _p(bias), _p(out), ctypes.byref(d), ctypes.byref(n), _stream())
-    if rc == -4:                       # BYA_ERR_UNSUPPORTED: not this kernel's shape
-        return False
+    if rc == -4:                       # BYA_ERR_UNSUPPORTED: not this kernel's shape -- nothing was launched, nothing is counted
+        return False                   # (the caller's plain GEMM counts the FLOPs; round 5 counted them here as well)
     check(rc, "bya_gemm_qkv_norm_rope")
+    if tok is not None:
+        _FLOPS[tok[0]] = _FLOPS.get(tok[0], 0.0) + 2.0 * ab * M * N * K
     _end(tok)
     return True
 

@@ -47,6 +47,25 @@ LIVE_GROUPS = weakref.WeakSet()  # every P2PGroup of this process (ops.check_gem
 _RETIRED = []                    # buffers of closed groups (P2PGroup.close: never freed while peers might still store into them)
 
 
+class PhaseMismatch(RuntimeError):
+    """The ranks of a group were not at the same point of a collective set-up (see ``gather_tagged``)."""
+
+
+def gather_tagged(group, world, tag, value):
+    """``all_gather_object`` of ``value`` with a tag that names the point of the set-up the caller is at.  Object
+    collectives pair up by ORDER, not by meaning: a rank that raised locally between two of them (and went on to the
+    caller's next collective) would silently pair that one with its peers' previous one -- from then on everybody reads
+    somebody else's answers.  With the tag every rank sees the slip in the SAME collective and raises ``PhaseMismatch``;
+    ``parallel.shard_sequence`` (the only caller that survives a failed set-up) then repeats its own gather once, which
+    pairs with the gather its peers reach after THEIR raise: the ranks are in step again."""
+    got = [None] * world
+    dist.all_gather_object(got, (tag, value), group=group)
+    tags = [g[0] for g in got]
+    if any(t != tag for t in tags):
+        raise PhaseMismatch(f"ranks at different points of the set-up: {tags}")
+    return [g[1] for g in got]
+
+
 class _FineUnavailable(RuntimeError):
     """This platform (or one rank of the group) did not hand out fine-grained / uncached device memory."""
 
@@ -116,10 +135,11 @@ class Channel:
         self.cur = ent
         return self
 
-    def _launch(self, fn, stream):
+    def _launch(self, fn, stream, wait=False):
         g = self.grp
         table, n, total_chunks = self.cur[:3]
-        _hip.check(fn(table.data_ptr(), n, total_chunks, self.peer_ctrl.data_ptr(), g.kworld, g.krank, self.ctrl_ptr,
+        tail = (g.ctrl.data_ptr(), g.wait_limit_ms) if wait else ()     # the group's first control block, this launch's wait limit
+        _hip.check(fn(table.data_ptr(), n, total_chunks, self.peer_ctrl.data_ptr(), g.kworld, g.krank, self.ctrl_ptr, *tail,
                       stream.cuda_stream), fn.__name__)
         g.pushes += 1
 
@@ -145,14 +165,14 @@ class Channel:
         if self._join is not None:
             cur.wait_event(self._join)              # (also rejoins the side stream into a graph capture)
             self._join = None
-        _hip.check(_hip.load().bya_p2p_wait(self.ctrl_ptr, g.kworld, cur.cuda_stream), "bya_p2p_wait")
+        _hip.check(_hip.load().bya_p2p_wait(self.ctrl_ptr, g.kworld, g.ctrl.data_ptr(), g.wait_limit_ms, cur.cuda_stream), "bya_p2p_wait")
         return self
 
     def exchange(self):
         """push + wait in one launch (``P2PGroup.MERGED = False``: as two, the round-4 form)."""
         if not self.grp.MERGED:
             return self.push().wait()
-        self._launch(_hip.load().bya_p2p_exchange, torch.cuda.current_stream(self.grp.dev))
+        self._launch(_hip.load().bya_p2p_exchange, torch.cuda.current_stream(self.grp.dev), wait=True)
         return self
 
 
@@ -186,9 +206,9 @@ class P2PGroup:
         self.pushes = 0
         self.closed = False
         self.side_stream = torch.cuda.Stream(self.dev)
-        # seconds a wait may take before it gives up (wall clock; library-wide setting)
+        # seconds a wait of THIS group may take before it gives up (wall clock); handed to every wait / exchange launch -- a
+        # launch captured into a hipGraph keeps the limit it was captured with
         self.wait_limit_ms = int(float(os.environ.get("BYA_P2P_TIMEOUT", "30")) * 1000)
-        _hip.check(_hip.load().bya_p2p_set_wait_limit_ms(self.wait_limit_ms), "bya_p2p_set_wait_limit_ms")
         # the control block: peers store flags into it while this GPU's wait kernels poll them -> fine-grained memory
         # where the platform hands it out (RCCL allocates its flags that way for the same reason); coarse otherwise
         try:
@@ -208,8 +228,7 @@ class P2PGroup:
         every step that can fail on one rank alone ends here."""
         errs = [err]
         if self.world > 1 and self.solo is None:
-            errs = [None] * self.world
-            dist.all_gather_object(errs, None if err is None else str(err), group=self.group)
+            errs = gather_tagged(self.group, self.world, ("agree", what), None if err is None else str(err))
         bad = [(j, e) for j, e in enumerate(errs) if e is not None]
         if bad:
             raise RuntimeError(f"P2P exchange engine, {what}: failed on rank(s) {bad}")
@@ -218,7 +237,9 @@ class P2PGroup:
         """Retire the group (a rung of the transport ladder that did not pass, or a model that is re-sharded): its sticky
         time-out counters no longer count for ``ops.check_gemm_workspace``, its copy tables go.  The buffers are kept for the
         life of the process ON PURPOSE -- a peer that fell behind may still store into them, and memory handed back to the
-        allocator would be somebody else's by then."""
+        allocator would be somebody else's by then.  What that pins: everything the rung had allocated -- for a sharded
+        42-layer model ~0.5 GB of receive buffers per rank, the self-test's W x 256 KB, ``exchange_probe``'s 2 x W x 6 MB --
+        once per rung LEFT (at most two per process: the ladder has three rungs), of 288 GB."""
         LIVE_GROUPS.discard(self)
         for ch in self._channels.values():
             ch.tables.clear()
@@ -279,8 +300,7 @@ class P2PGroup:
                 info = local.untyped_storage()._share_cuda_()
             except Exception as e:                      # noqa: BLE001  (no hipIpc export on this platform)
                 err = f"_share_cuda_: {e!r}"
-            infos = [None] * self.world
-            dist.all_gather_object(infos, (info, local.storage_offset(), tuple(shape)), group=self.group)
+            infos = gather_tagged(self.group, self.world, "handles (torch)", (info, local.storage_offset(), tuple(shape)))
             try:
                 for j, (inf, off, shp) in enumerate(infos):
                     if j == self.rank or err is not None or inf is None:
@@ -327,8 +347,7 @@ class P2PGroup:
                 err = f"torch.as_tensor over device memory: {e!r}"
         infos = [(err, bytes(handle), tuple(shape))]
         if self.world > 1:
-            infos = [None] * self.world
-            dist.all_gather_object(infos, (err, bytes(handle), tuple(shape)), group=self.group)
+            infos = gather_tagged(self.group, self.world, f"handles ({kind})", (err, bytes(handle), tuple(shape)))
         bad = [(j, i[0]) for j, i in enumerate(infos) if i[0] is not None]
         if bad:
             if ptr.value and local is None:
@@ -437,8 +456,7 @@ class P2PGroup:
         ack = self.channel("__selftest_ack__", [(empty, j, "__selftest__", 0) for j in range(W)])
         src = torch.arange(W, dtype=torch.int32, device=self.dev)[:, None]
         bad = torch.zeros((), dtype=torch.int64, device=self.dev)
-        lib = _hip.load()
-        _hip.check(lib.bya_p2p_set_wait_limit_ms(2000), "bya_p2p_set_wait_limit_ms")      # a dead link shows in seconds, not minutes
+        keep_limit, self.wait_limit_ms = self.wait_limit_ms, 2000                      # a dead link shows in seconds, not minutes
         try:
             for it in range(rounds):
                 for j in range(W):
@@ -453,7 +471,7 @@ class P2PGroup:
                 if it % 4 == 3 and self.timeouts():          # (synchronises) nothing arrives: do not sit through every round
                     break
         finally:
-            _hip.check(lib.bya_p2p_set_wait_limit_ms(self.wait_limit_ms), "bya_p2p_set_wait_limit_ms")
+            self.wait_limit_ms = keep_limit
         torch.cuda.synchronize(self.dev)
         err = None
         if self.timeouts() or int(bad.item()):

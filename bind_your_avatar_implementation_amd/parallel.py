@@ -532,9 +532,18 @@ def shard_sequence(model, group=None, transport=None):
             p2p.self_test()
         except Exception as e:              # no hipIpc on this platform, peer access refused, stale words, ...
             err = repr(e)                   # (the text only: the traceback would keep the failed group alive)
-        # every rank must agree: one rank on collectives and another on push kernels would deadlock
-        ok = [None] * model._seq_world
-        dist.all_gather_object(ok, err is None, group=model._seq_group)
+        # every rank must agree: one rank on collectives and another on push kernels would deadlock.  A rank that raised
+        # LOCALLY inside the set-up arrives here one object collective early: the tag shows it to everybody, the peers raise
+        # out of their set-up (PhaseMismatch, caught above) and come here too, this rank asks again (p2p.gather_tagged)
+        from .p2p import PhaseMismatch, gather_tagged
+        for _ in range(3):
+            try:
+                ok = gather_tagged(model._seq_group, model._seq_world, ("ladder", rung), err is None)
+                break
+            except PhaseMismatch as e:
+                err = err or repr(e)
+        else:
+            raise RuntimeError(f"sequence-parallel set-up: the ranks did not get back in step on rung {rung!r}")
         if all(ok):
             model._seq_p2p, model._seq_transport = p2p, rung
             break

@@ -531,10 +531,13 @@ int bya_alltoall_router(const void* send, void* recv, const int64_t* send_counts
  * wait runs as 16 small workgroups, dealt over the XCDs, each ending in a system-scope acquire).  bya_p2p_exchange = push
  * and wait in ONE launch, for the exchanges nothing is overlapped with.
  * Sequence numbers live in the control block (words 32 / 33): a hipGraph replay advances them by itself.  A wait is bounded
- * by wall time (bya_p2p_set_wait_limit_ms; default 30 s); one that gives up counts itself in word 35 of its channel, which
- * is sticky: bya_p2p_poison(ctrl_base, n_channels, out, n) -- enqueue it behind the last consumer of a step -- overwrites
- * the bf16 tensor `out` with NaN when any of the n_channels control blocks (64 words apart) carries a time-out, so that a
- * result made from a buffer that never arrived cannot be consumed.  The caller guarantees that a receive buffer is not
+ * by wall time: `wait_limit_ms` of the launch (<= 0: 30 s; a captured launch keeps the limit it was captured with).  One
+ * that gives up counts itself in word 35 of its channel and in word 37 of `group_ctrl` -- the FIRST control block of the
+ * group the channel belongs to (may be NULL: then only the channel's own word is used) -- both sticky.  A wait that finds
+ * the group's word set returns at once, counted as timed out: after the first time-out of a group the rest of the step runs
+ * through without polling.  bya_p2p_poison(ctrl_base, n_channels, out, n) -- enqueue it behind the last consumer of a step --
+ * overwrites the bf16 tensor `out` with NaN when any of the n_channels control blocks (64 words apart) carries a time-out, so
+ * that a result made from a buffer that never arrived cannot be consumed.  The caller guarantees that a receive buffer is not
  * pushed into again before its owner has consumed it (the step's data dependencies do).
  * --------------------------------------------------------------------------------------------- */
 typedef struct bya_p2p_copy {      /* a 2-D piece: `rows` rows of `row_bytes` bytes (a contiguous piece is ONE row) */
@@ -549,10 +552,9 @@ typedef struct bya_p2p_copy {      /* a 2-D piece: `rows` rows of `row_bytes` by
 
 int bya_p2p_push(const bya_p2p_copy* copies_dev, int32_t n_copies, int64_t total_chunks, void* const* peer_ctrl_dev,
                  int32_t world, int32_t rank, void* ctrl, hipStream_t stream);
-int bya_p2p_wait(void* ctrl, int32_t world, hipStream_t stream);
+int bya_p2p_wait(void* ctrl, int32_t world, void* group_ctrl, int64_t wait_limit_ms, hipStream_t stream);
 int bya_p2p_exchange(const bya_p2p_copy* copies_dev, int32_t n_copies, int64_t total_chunks, void* const* peer_ctrl_dev,
-                     int32_t world, int32_t rank, void* ctrl, hipStream_t stream);
-int bya_p2p_set_wait_limit_ms(int64_t ms);
+                     int32_t world, int32_t rank, void* ctrl, void* group_ctrl, int64_t wait_limit_ms, hipStream_t stream);
 int bya_p2p_poison(const void* ctrl_base, int32_t n_channels, void* out, int64_t n_elems, hipStream_t stream);
 /* Set-up only (the ONLY entry points of this library that allocate; never called inside a step): device memory a peer may
  * store into or a running kernel polls, by kind -- 0 coarse-grained (hipMalloc), 1 fine-grained, 2 uncached

@@ -123,6 +123,7 @@ def _timeout_worker(rank, world, port, ret):
         recv = g.symmetric("r", (world, n), torch.bfloat16, zero=True)
         send = torch.full((world, n), float(rank + 1), dtype=torch.bfloat16, device=dev)
         ch = g.channel("x", [(send[j], j, "r", rank * n) for j in range(world)])
+        ch2 = g.channel("y", [(send[j], j, "r", rank * n) for j in range(world)])       # a second exchange of the "step"
         ch.exchange()                                     # a healthy exchange first
         out = torch.ones(1000, dtype=torch.bfloat16, device=dev)
         g.poison(out)
@@ -134,6 +135,15 @@ def _timeout_worker(rank, world, port, ret):
             ch.exchange()
             g.poison(out)
             torch.cuda.synchronize()
+            # ... and from then on no wait of the GROUP polls its limit again (the advisor's round-5 finding: ~280 exchanges per
+            # rank-step, each bounded separately, made a dead peer stall every step for hours): 40 exchanges on ANOTHER channel
+            # whose peer never pushes return at once -- 40 x 0.3 s otherwise
+            import time
+            t0 = time.time()
+            for _ in range(40):
+                ch2.exchange()
+            torch.cuda.synchronize()
+            fast = time.time() - t0 < 3.0
             raised = False
             try:
                 ops.check_gemm_workspace()
@@ -146,9 +156,9 @@ def _timeout_worker(rank, world, port, ret):
                 ops.check_gemm_workspace()
             except _hip.ByaError:
                 clean = False
-            ret[rank] = (healthy, g.timeouts(), bool(torch.isnan(out.float()).all()), raised, clean)
+            ret[rank] = (healthy, g.timeouts(), bool(torch.isnan(out.float()).all()), raised, clean, fast)
         else:
-            ret[rank] = (healthy, 0, True, True, True)
+            ret[rank] = (healthy, 0, True, True, True, True)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -158,7 +168,7 @@ def test_p2p_wait_that_gives_up_is_loud(dev):
     """A wait whose peer never pushes gives up after BYA_P2P_TIMEOUT seconds (wall clock) instead of hanging the GPU, and
     that is not silent: the channel's time-out word is sticky, ``bya_p2p_poison`` turns the step's output into NaN, and
     ``ops.check_gemm_workspace`` (pipeline end, bench end) raises -- until the group is retired (``close``: what the transport
-    ladder does with a rung it leaves)."""
+    ladder does with a rung it leaves).  After the first time-out the group's later waits return without polling."""
     import torch.multiprocessing as mp
     ret = mp.Manager().dict()
     mp.spawn(_timeout_worker, args=(2, 32700 + os.getpid() % 200, ret), nprocs=2, join=True)
@@ -166,6 +176,7 @@ def test_p2p_wait_that_gives_up_is_loud(dev):
     for r in (0, 1):
         assert ret[r][0] == (True, True), ret[r]          # healthy run: no time-out, output untouched
     assert ret[0][1] > 0 and ret[0][2] and ret[0][3] and ret[0][4], ret[0]
+    assert ret[0][5], "waits behind the group's first time-out polled their limit again"
 
 
 @pytest.mark.gpu

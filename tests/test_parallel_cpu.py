@@ -200,3 +200,49 @@ def test_transport_ladder_walks_down_together_without_a_gpu():
     ret = mp.Manager().dict()
     mp.spawn(_ladder_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+def _slip_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bind_your_avatar_implementation_amd.p2p import PhaseMismatch, gather_tagged
+        g = dist.group.WORLD
+        log = []
+        # a rung of the transport ladder: set-up collectives ("handles", "agree"), then the ladder's own gather.  Rank 1
+        # raises LOCALLY before the first set-up collective (a launch error, a refused mapping) and goes straight to the ladder.
+        err = None
+        try:
+            if rank == 1:
+                raise RuntimeError("local failure inside the set-up")
+            gather_tagged(g, world, "handles", rank)
+            gather_tagged(g, world, ("agree", "self-test"), None)
+        except Exception as e:                       # noqa: BLE001  (shard_sequence catches everything a rung may raise)
+            err = repr(e)
+            log.append(type(e).__name__)
+        for _ in range(3):
+            try:
+                ok = gather_tagged(g, world, ("ladder", "p2p"), err is None)
+                break
+            except PhaseMismatch as e:
+                err = err or repr(e)
+                log.append("retry")
+        # in step again: the next collective pairs up and carries what it should on every rank
+        nxt = gather_tagged(g, world, ("ladder", "torch"), rank * 10)
+        ret[rank] = (ok, nxt, log)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_set_up_collectives_get_back_in_step_after_a_local_failure():
+    """The advisor's round-5 finding: a rank that raises locally inside the P2P set-up reaches the ladder's object collective
+    one collective early and from then on every rank reads somebody else's answers.  With tagged gathers every rank sees
+    the slip in the same collective: the peers raise out of their set-up, the early rank repeats its gather, all agree that
+    the rung failed, and the following collective is in step."""
+    ret = mp.Manager().dict()
+    mp.spawn(_slip_worker, args=(2, 29650 + os.getpid() % 300, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        ok, nxt, log = ret[r]
+        assert ok == [False, False] and nxt == [0, 10], ret[r]
+    assert ret[0][2] == ["PhaseMismatch"] and ret[1][2] == ["RuntimeError", "retry"]
