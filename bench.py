@@ -192,7 +192,11 @@ def main():
     ap.add_argument("--cpu-baseline-config0", action="store_true",
                     help="time the config-0 form (1 block + every injection) instead of the block alone: minutes of CPU")
     ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N = 1)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N = 1; N > 1 on the P2P rungs does by default)")
+    ap.add_argument("--eager", action="store_true", help="N > 1: keep the timed steps eager (default on the P2P rungs: hipGraph replay)")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the board calibration (bare-MFMA loop, ~0.7 s) before the timed region")
+    ap.add_argument("--no-cfg-pair-variant", action="store_true",
+                    help="N >= 4: skip the extra measurement of the CFG pair (batch 2 on 2 x N/2 ranks) beside the headline")
     ap.add_argument("--latent-hw", type=int, nargs=2, default=[60, 90], metavar=("H", "W"),
                     help="latent height / width; anything but 60 90 (= 480x720) is not the headline config")
     ap.add_argument("--batch", type=int, default=1, help="2 = the CFG pair of BASELINE config 3 (not the headline)")
@@ -262,16 +266,35 @@ def main():
                 blk.attn1.norm_k.weight.mul_(g)
     if args.qk_gain != 1.0:
         scale_qk_gains(args.qk_gain)
-    inp = synth_inputs(batch=args.batch, frames=lt, height=lh, width=lw, n_id=nid, seed=0, device="cpu",
-                       uncond_first=args.batch == 2)
-    inp = {k: (v.to(dev, torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else
-               (v.to(dev) if torch.is_tensor(v) else v)) for k, v in inp.items()}
-    inp["image_rotary_emb"] = tuple(t.to(dev, torch.float32) for t in inp["image_rotary_emb"])
-    inp["id_cond"] = [t.to(dev, torch.bfloat16) for t in inp["id_cond"]]
-    inp["id_vit_hidden"] = [[t.to(dev, torch.bfloat16) for t in l] for l in inp["id_vit_hidden"]]
+
+    def make_inputs(batch):
+        d = synth_inputs(batch=batch, frames=lt, height=lh, width=lw, n_id=nid, seed=0, device="cpu", uncond_first=batch == 2)
+        d = {k: (v.to(dev, torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else
+                 (v.to(dev) if torch.is_tensor(v) else v)) for k, v in d.items()}
+        d["image_rotary_emb"] = tuple(t.to(dev, torch.float32) for t in d["image_rotary_emb"])
+        d["id_cond"] = [t.to(dev, torch.bfloat16) for t in d["id_cond"]]
+        d["id_vit_hidden"] = [[t.to(dev, torch.bfloat16) for t in l] for l in d["id_vit_hidden"]]
+        return d
+
+    inp = make_inputs(args.batch)
 
     def step():
         return model(return_dict=False, denoise_step=0, **inp)[0]
+
+    def timed_alone(fn, n):
+        """seconds per call on THIS rank's GPU, no barrier (the unsharded references of an N > 1 run); -> (s, last output)"""
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            o = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, o
+
+    # ---- what THIS board sustains (round 6): a loop of nothing but the GEMM's MFMA on gaussian operands, ~0.7 s, before any
+    # warm-up.  The pool's boxes differ by +-3 % in the clock they hold under load; `frac_of_board` reads the same kernels
+    # against the board they ran on, `frac` (the headline) against the spec peak.
+    calibration = None if args.no_calibration else ops.board_calibration(dev)
 
     # strict summation order = options gemm_splitk = 0, attn_streamk = 0 of the library (ops.strict_summation)
     if share and world > 1:
@@ -291,6 +314,18 @@ def main():
             step()
             ref_strict = step().clone()
         torch.cuda.synchronize()
+        # ---- the same node's UNSHARDED step in the default mode, timed on every rank's own GPU: what the N-rank number is a
+        # speed-up OF (a line from one box of the pool cannot be divided by a line from another: +-3 %)
+        n_ref = max(1, min(3, args.steps))
+        unsharded_s, _ = timed_alone(step, n_ref)
+        cfg_variant = world >= 4 and world % 2 == 0 and args.batch == 1 and not args.no_cfg_pair_variant
+        unsharded_b2_s, ref_b2, inp2 = None, None, None
+        if cfg_variant:
+            # the reference's real workload is the CFG pair (models/pipeline_bindyouravatar.py:897,924-933): batch 2 on 2 x N/2
+            # ranks, measured after the headline, against the batch-2 step of one GPU measured here
+            inp2 = make_inputs(2)
+            unsharded_b2_s, ref_b2 = timed_alone(lambda: model(return_dict=False, denoise_step=0, **inp2)[0], max(1, min(2, args.steps)))
+            ref_b2 = ref_b2.clone()
         model.invalidate_engine()              # (drops the unsharded workspace)
         fake = os.environ.get("BYA_BENCH_FAKE_MISMATCH", "")           # test hook: "1" = both P2P rungs fail, or a list of rungs
         fake = set(TRANSPORTS[:2]) if fake == "1" else set(f for f in fake.split(",") if f)
@@ -361,9 +396,15 @@ def main():
             out = step()
         torch.cuda.synchronize()
 
-    if args.graph and (world == 1 or getattr(model, "_seq_p2p", None) is not None):
+    # N > 1 on a P2P rung: the timed steps replay from a hipGraph by default (the exchanges are ordinary kernels; ~3000 launches
+    # per rank-step otherwise ride on the host).  The per-kernel event pass below stays eager (events cannot be recorded inside
+    # a replayed graph).
+    graph = (args.graph and world == 1) or (world > 1 and getattr(model, "_seq_p2p", None) is not None and args.batch == 1
+                                            and (args.graph or not args.eager))
+    if graph:
         model.use_hip_graph = True
-        args.no_kernel_timers = True          # events cannot be recorded per kernel inside a replayed graph
+        if world == 1:
+            args.no_kernel_timers = True      # (N = 1 --graph: an A/B run, no second pass)
         for _ in range(max(1, args.warmup)):
             out = step()
         torch.cuda.synchronize()
@@ -389,13 +430,51 @@ def main():
     # Per-kernel HIP-event timing runs in a SECOND pass of the same K steps: an event pair around every one of the
     # ~3000 launches of a step costs ~5 % of wall time, which must not leak into `value`.
     ktimes = {}
+    launch = "hipGraph replay" if (getattr(model, "use_hip_graph", False) and model._graph_capturable()) else "eager"
     if not args.no_kernel_timers:
+        if getattr(model, "use_hip_graph", False):
+            model.use_hip_graph = False
+            step()
         ops.enable_kernel_timers()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         ktimes = ops.collect_kernel_timers()
     ops.check_gemm_workspace()        # no split-K / stream-K hand-off and no P2P wait of the run timed out (raises otherwise: the numbers would be void)
+
+    # ---- N >= 4: the CFG pair beside the headline -- batch 2 as [uncond, cond] on two halves of the ranks, each half
+    # sequence-parallel over N/2 (parallel.shard_cfg), against the batch-2 step one GPU of this node ran above
+    cfg_pair, calibrations, unsharded_all = None, None, None
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, (calibration, unsharded_s, unsharded_b2_s))
+        calibrations, unsharded_all = [g[0] for g in got], [g[1] for g in got]
+        if cfg_variant:
+            model.use_hip_graph = False
+            shard_cfg(model, dist.group.WORLD, transport=tried[-1]["transport"])
+            step2 = lambda: model(return_dict=False, denoise_step=0, **inp2)[0]
+            for _ in range(max(2, args.warmup)):
+                out2 = step2()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out2 = step2()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d2 = ((out2.float() - ref_b2.float()).norm() / ref_b2.float().norm()).item()
+            ops.check_gemm_workspace()
+            b2 = [g[2] for g in got]
+            cfg_pair = {"parallelism": f"CFG batch split x2, each half sequence-parallel x{world // 2}", "batch": 2,
+                        "ms_per_step": t.item() / args.steps * 1e3, "steps_per_s": args.steps / t.item(),
+                        "unsharded_batch2_step_ms_same_node": sum(b2) / len(b2) * 1e3,
+                        "speedup_vs_unsharded_batch2_same_node": (sum(b2) / len(b2)) / (t.item() / args.steps),
+                        "rel_fro_vs_unsharded_batch2_step": d2, "launch": "eager",
+                        "transport": getattr(model, "_seq_transport", "torch")}
+            if not (d2 <= 3e-2):
+                raise SystemExit(f"the CFG pair on 2 x {world // 2} ranks is not within bf16 summation noise of the batch-2 step: {cfg_pair}")
 
     headline = (lh, lw, lt, nid) == (60, 90, 13, 2) and args.batch == 1 and not args.fp8_weights and args.qk_gain == 1.0
     if rank == 0:
@@ -418,7 +497,7 @@ def main():
                                     + (", fp8 weights" if args.fp8_weights else "")
                                     + (f", q/k-LayerNorm gains x{args.qk_gain:g}" if args.qk_gain != 1.0 else "")),
                        "layers": args.layers, "tokens": 226 + lt * (lh // 2) * (lw // 2), "batch": args.batch,
-                       "launch": "hipGraph replay" if (getattr(model, "use_hip_graph", False) and model._graph_capturable()) else "eager",
+                       "launch": launch,
                        "parallelism": "single GPU" if world == 1 else
                        (f"CFG batch split x2, each half sequence-parallel x{world // 2}" if args.batch == 2 else
                         f"sequence-parallel x{world} (head-parallel exchange around the joint attention, sharded "
@@ -427,6 +506,23 @@ def main():
                                                  if getattr(model, "_seq_p2p", None) is not None else
                                                  "; exchanges = torch.distributed collectives (RCCL)")},
         }
+        if calibration is not None:
+            res["board_calibration_tflops"] = calibration
+            res["board_calibration"] = ("bare v_mfma_f32_16x16x32_bf16 loop, gaussian bf16 operands in registers, 256 CUs x 1 wave per SIMD, "
+                                        "~0.35 s timed after an equal warm-up launch (ops.board_calibration); spec peak "
+                                        f"{PEAK_BF16_TFLOPS:.0f}")
+            if headline:
+                res["mfma_roofline_frac_of_board_whole_step"] = TFLOP_PER_STEP * (args.layers / 42) * value / (world * calibration)
+        if world > 1:
+            res["board_calibration_tflops_per_rank"] = calibrations
+            mean_un = sum(unsharded_all) / len(unsharded_all)
+            res["unsharded_step_ms_same_node"] = mean_un * 1e3
+            res["unsharded_step_ms_per_rank"] = [u * 1e3 for u in unsharded_all]
+            res["speedup_vs_unsharded_same_node"] = mean_un / sec_per_step
+            res["unsharded_step_note"] = (f"the unsharded batch-{args.batch} step in the default mode, eager, {n_ref} timed after one warm-up on "
+                                          "every rank's own GPU before the model was sharded; mean over the ranks")
+            if cfg_pair is not None:
+                res["cfg_pair_variant"] = cfg_pair
         if world > 1:
             res["config"]["transport"] = getattr(model, "_seq_transport", "torch") if getattr(model, "_seq_world", 1) > 1 else "torch (CFG pair exchange only)"
             res["config"]["validated_against_unsharded_step"] = validation
@@ -489,6 +585,8 @@ def main():
                              "ms_per_step": (sum(gemm) + sum(small)) / args.steps * 1e3}
             # headline = the kernel that dominates the step's time (the GEMM kernel when both were timed)
             cands = [r for r in (gemm_roof, attn_roof) if r]
+            for r in cands:                           # the same kernels against what THIS board sustains (board_calibration_tflops)
+                r["frac_of_board"] = r["achieved"] / calibration if calibration else None
             if cands:
                 cands.sort(key=lambda r: -r["ms_per_step"])
                 res["roofline"] = cands[0]

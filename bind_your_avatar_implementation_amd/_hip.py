@@ -53,6 +53,7 @@ SIGNATURES = {
     "bya_abi_version": [],
     "bya_set_option": [_i32, _i32],
     "bya_get_option": [_i32, _c.POINTER(_i32)],
+    "bya_mfma_calibration": [_vp, _i64, _vp, _i32, _vp],
     "bya_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
     "bya_gemm_skinny_bf16": [_vp, _vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _vp],
     "bya_gemm_qkv_norm_rope": [_vp, _vp, _vp, _vp, _c.POINTER(GemmDesc), _c.POINTER(QkNormDesc), _vp],

@@ -143,6 +143,30 @@ def strict_summation():
     return options(gemm_splitk=0, attn_streamk=0)
 
 
+def board_calibration(device=None, seconds=0.3, zeros=False):
+    """TFLOP/s THIS board sustains on a loop of nothing but the GEMM's MFMA (v_mfma_f32_16x16x32_bf16) with gaussian bf16
+    operands in registers (include/bya.h bya_mfma_calibration): the ceiling a bench line can be read against on a pool whose
+    boxes differ by a few per cent in clock under load.  Two launches of ~``seconds`` each, the second one timed (the first
+    brings the board to its steady clock).  Synchronises."""
+    lib = _hip.load()
+    device = torch.device(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    n = (256 * 256 * 16 * 16) // 2
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    src = torch.zeros(n, dtype=torch.bfloat16, device=device) if zeros else torch.randn(n, generator=g).to(torch.bfloat16).to(device)
+    sink = torch.zeros(1, dtype=torch.float32, device=device)
+    flop_per_iter = 256.0 * 4 * 2.0 * 128 * 128 * 32
+    iters = max(1000, int(seconds * 2.0e15 / flop_per_iter))
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.device(device):
+        for timed in (False, True):
+            if timed:
+                s.record()
+            check(lib.bya_mfma_calibration(src.data_ptr(), src.numel() * 2, sink.data_ptr(), iters, _stream()), "bya_mfma_calibration")
+        e.record()
+        torch.cuda.synchronize(device)
+    return iters * flop_per_iter / (s.elapsed_time(e) * 1e-3) / 1e12
+
+
 # ---- optional per-entry-point timers (HIP events recorded on the launch stream; used by bench.py) -------------
 _TIMERS = None
 _FLOPS = {}

@@ -70,6 +70,15 @@ enum { BYA_REF_ROWGEMM_CHUNKED = 1,    /* N = 512 row GEMM: chunk-balanced kerne
 int bya_set_option(int32_t key, int32_t value);
 int bya_get_option(int32_t key, int32_t* value);
 
+/* Board calibration (diagnostic; csrc/calib.hip): 256 workgroups x 4 waves run `iters` sweeps of 64 v_mfma_f32_16x16x32_bf16 each
+ * (a 128 x 128 x 32 wave tile: 2^20 FLOP per wave and sweep, BYA_CALIBRATION_FLOP_PER_ITER per launch and iteration) on the
+ * operand fragments at `operands` (>= BYA_CALIBRATION_OPERAND_BYTES of bf16: gaussian for the rate the board sustains on real
+ * data, zeros for its full clock).  The caller times the launch (HIP events) -- TFLOP/s = iters * BYA_CALIBRATION_FLOP_PER_ITER /
+ * seconds / 1e12.  `sink`: 4 bytes of device memory (never written in practice).  No reference counterpart. */
+#define BYA_CALIBRATION_OPERAND_BYTES (256LL * 256 * 16 * 16)
+#define BYA_CALIBRATION_FLOP_PER_ITER (256.0 * 4 * 2.0 * 128 * 128 * 32)
+int bya_mfma_calibration(const void* operands, int64_t operand_bytes, void* sink, int32_t iters, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GEMM:  C[z][m,n] = res[z][m,n] + gate[z][row-type(m)][n] * alpha * act( sum_k A[z][m,k] * W[n,k] + rowscale[m]*bias[n] )
  * Replaces every nn.Linear / 2x2-stride Conv2d-as-GEMM on the path: attn1.to_q/k/v/to_out,

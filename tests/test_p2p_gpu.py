@@ -205,6 +205,11 @@ def test_bench_two_ranks_validates_against_the_unsharded_step_and_walks_the_ladd
         val = cfg["validated_against_unsharded_step"]
         assert [t["transport"] for t in val["rungs"]][-1] == want and val["rungs"][-1]["bit_identical_to_unsharded_step"]
         assert val["default_mode_rel_fro_vs_reference"] <= val["default_mode_bound"]
+        # (r6) what the line needs to be read on its own: the board's calibration, and the same node's unsharded step
+        assert d["board_calibration_tflops"] > 0 and len(d["board_calibration_tflops_per_rank"]) == 2
+        assert d["unsharded_step_ms_same_node"] > 0 and len(d["unsharded_step_ms_per_rank"]) == 2
+        assert abs(d["speedup_vs_unsharded_same_node"] - d["unsharded_step_ms_same_node"] / d["ms_per_step"]) < 1e-6
+        assert cfg["launch"] == ("hipGraph replay" if want == "p2p" else "eager")      # the P2P rungs replay by default
         if want == "p2p":
             assert "P2P push kernels" in cfg["parallelism"] and "transport_note" not in cfg and len(val["rungs"]) == 1
         else:
