@@ -15,6 +15,7 @@ zero-terminal-SNR rescale, trailing spacing); the CFG combine and the step itsel
 the reference repo, so they are "parity unpinned" like the other diffusers-owned pieces.
 """
 import math
+import os
 from types import SimpleNamespace
 from typing import Callable, List, Optional
 
@@ -266,6 +267,12 @@ class BindyouravatarPipeline:
         old_x0 = None
         # the identities and the audio do not change between steps: face tokens, audio context and their K/V once
         tr.precompute_conditioning(id_cond, id_vit_hidden, audio_embs, lat_frames)
+        # one synchronisation per step (~0.35 s of GPU work each): the hand-off counters of the split kernels (ops.heal_handoffs).
+        # Unsharded runs only -- ranks of a sharded step would have to agree to repeat it; they keep the end-of-clip check.
+        heal = (torch.device(dev).type == "cuda" and getattr(tr, "_seq_world", 1) == 1 and getattr(tr, "_cfg", None) is None
+                and os.environ.get("BYA_SELF_HEAL", "1") != "0")
+        if heal:
+            from . import ops
         for i, t in enumerate(ts):
             if self._interrupt:
                 continue
@@ -277,11 +284,17 @@ class BindyouravatarPipeline:
                 bg = torch.cat([image_bg_latents] * 2) if cfg else image_bg_latents
                 cond = torch.cat([cond, bg], dim=2)
             x = torch.cat([x, cond], dim=2)
-            noise = tr(hidden_states=x, encoder_hidden_states=prompt_embeds, timestep=t.expand(x.shape[0]),
-                       image_rotary_emb=rope, return_dict=False, id_vit_hidden=id_vit_hidden, id_cond=id_cond,
-                       audio_embeds=audio_embs, af_matrix=af_matrix, denoise_step=i,
-                       routing_logits_zeros_flag=routing_logits_zeros_flag,
-                       routing_logits_forcing=routing_logits_forcing)[0]
+            def predict():
+                return tr(hidden_states=x, encoder_hidden_states=prompt_embeds, timestep=t.expand(x.shape[0]),
+                          image_rotary_emb=rope, return_dict=False, id_vit_hidden=id_vit_hidden, id_cond=id_cond,
+                          audio_embeds=audio_embs, af_matrix=af_matrix, denoise_step=i,
+                          routing_logits_zeros_flag=routing_logits_zeros_flag,
+                          routing_logits_forcing=routing_logits_forcing)[0]
+            noise = predict()
+            if heal and ops.heal_handoffs(dev):
+                # a split-K / stream-K hand-off of this step timed out (the GPU is shared: the grids were not co-resident);
+                # the library is in its unsplit mode now -- compute the step again instead of failing the clip at its end
+                noise = predict()
             if use_dynamic_cfg:
                 self._guidance_scale = 1 + guidance_scale * (
                     (1 - math.cos(math.pi * ((num_inference_steps - t.item()) / num_inference_steps) ** 5.0)) / 2)
