@@ -400,15 +400,30 @@ class BindyouravatarTransformer3DModel(nn.Module):
         ``fast``: draw on the parameter's device (bench-size models); otherwise use the CPU generator so the
         values are identical in every process (golden-fixture tests)."""
         from .synth import synth_tensor
+
+        def fill(item):
+            name, t = item
+            dev = t.device if (fast and t.is_cuda) else "cpu"
+            v = synth_tensor(name, t.shape, seed, device=dev)
+            if name.endswith("pos_embedding"):
+                v[:, :self.config.max_text_seq_length] = 0
+            return t, v.to(t.dtype)
+
         with torch.no_grad():
-            for name, t in self.state_dict().items():
-                if name == "router.pos_emb":
-                    continue
-                dev = t.device if (fast and t.is_cuda) else "cpu"
-                v = synth_tensor(name, t.shape, seed, device=dev)
-                if name.endswith("pos_embedding"):
-                    v[:, :self.config.max_text_seq_length] = 0
-                t.copy_(v.to(t.dtype))
+            items = [(n, t) for n, t in self.state_dict().items() if n != "router.pos_emb"]
+            if fast or len(items) < 64:
+                for it in items:
+                    t, v = fill(it)
+                    t.copy_(v)
+            else:
+                # every tensor has a generator of its own (keyed by name): the CPU draws -- 8.6 G normal deviates for the
+                # 42-layer model, over a minute on one core -- run on a few threads (torch.randn releases the GIL), the values
+                # are the same whichever thread drew them; copies to the device stay on this thread
+                import os
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=max(1, min(12, (os.cpu_count() or 2) // 2))) as pool:
+                    for t, v in pool.map(fill, items):
+                        t.copy_(v)
         self.invalidate_engine()
         return self
 

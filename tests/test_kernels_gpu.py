@@ -663,7 +663,8 @@ def test_router_chains_repeatable_on_a_busy_gpu(ops, dev):
         assert all(torch.equal(first[k], o) for o in outs[k]), k
 
 
-@pytest.mark.parametrize("variant", ["v4", "w8"])
+@pytest.mark.parametrize("variant", ["v4"])      # (round 6: the "w8" arm -- the 8-wave fallback kernel forced on every shape -- went
+                                                 # with the suite's time budget; the fallback still runs where the default picks it)
 def test_gemm_big_tile_kernels_whole_suite(dev, variant):
     """Every GEMM parity test again with the 256x256 pipelined kernels FORCED for all shapes (BYA_GEMM_TILE=4: ragged M / N,
     K of one, two and three K-tiles -- the prologue / drain paths of the software pipelines -- batches, split outputs,
