@@ -179,3 +179,37 @@ def test_library_path_override_fails_loudly_when_the_file_is_missing(tmp_path):
     env = dict(os.environ, BYA_HIP_LIB=str(tmp_path / "nope.so"), PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=300)
     assert r.returncode == 3 and "nope.so" in r.stdout and "no fallback" in r.stdout, (r.stdout, r.stderr[-500:])
+
+
+def test_options_are_set_through_the_abi_and_never_through_the_environment(lib_path):
+    """(r6) The C entry points read no environment: `grep getenv csrc/` finds nothing.  Options go through bya_set_option /
+    bya_get_option: defaults, ranges, unknown keys; the Python host maps its BYA_* variables onto them when the library is
+    loaded (``_hip.apply_env_options``) and ``ops.options`` scopes a change."""
+    import subprocess
+    import sys
+    from bind_your_avatar_implementation_amd import _hip
+    csrc = os.path.join(ROOT, "bind_your_avatar_implementation_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f"{f}: the C ABI must not read the environment"
+    src = open(os.path.join(ROOT, "include", "bya.h")).read()
+    keys = dict((m.group(1).lower(), int(m.group(2))) for m in re.finditer(r"BYA_OPT_(\w+) = (\d+)", src))
+    count = keys.pop("count")
+    assert keys == _hip.OPTIONS and count == len(keys)                   # header enum = the Python table
+    refs = dict((m.group(1).lower(), int(m.group(2))) for m in re.finditer(r"BYA_REF_(\w+) = (\d+)", src))
+    assert refs == _hip.REFERENCE_FORMS
+    lib = _hip.load()
+    for name, default in _hip.OPTION_DEFAULTS.items():
+        _hip.set_option(name, default)
+        assert _hip.get_option(name) == default
+    assert lib.bya_set_option(99, 0) == -1 and lib.bya_set_option(-1, 0) == -1            # unknown key
+    assert lib.bya_set_option(_hip.OPTIONS["gemm_splitk"], 3) == -1                       # out of range: nothing changes
+    assert lib.bya_set_option(_hip.OPTIONS["p2p_groups"], 8) == -1 and lib.bya_set_option(_hip.OPTIONS["p2p_groups"], 64) == 0
+    assert _hip.get_option("gemm_splitk") == 1 and _hip.get_option("p2p_groups") == 64
+    _hip.set_option("p2p_groups", 0)
+    assert lib.bya_get_option(_hip.OPTIONS["gemm_tile"], None) == -1
+    # the environment reaches the table once, at load time, in a fresh process
+    code = ("from bind_your_avatar_implementation_amd import _hip; _hip.load(); "
+            "print(_hip.get_option('gemm_splitk'), _hip.get_option('gemm_variant'), _hip.get_option('gemm_tile'), _hip.get_option('attn_streamk'))")
+    env = dict(os.environ, BYA_GEMM_SPLITK="0", BYA_GEMM_VARIANT="w8", BYA_GEMM_TILE="4", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.split() == ["0", "1", "4", "1"], out.stdout + out.stderr[-500:]

@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bind_your_avatar_implementation_amd import ops  # noqa: E402
+from bind_your_avatar_implementation_amd import _hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 res = {}
@@ -22,6 +23,7 @@ for S, H in ((17776, 48), (8888 * 2, 24), (17776, 6), (47026, 48)):
     for rep in range(3):
         for mode in ("stream_k", "per_item"):
             os.environ["BYA_ATTN_STREAMK"] = "1" if mode == "stream_k" else "0"
+            _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
             for _ in range(2):
                 run()
             torch.cuda.synchronize()

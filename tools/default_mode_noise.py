@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     from bench import MODEL_KW
-    from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel, ops
+    from bind_your_avatar_implementation_amd import BindyouravatarTransformer3DModel, _hip, ops
     from bind_your_avatar_implementation_amd.synth import synth_inputs
     dev = torch.device("cuda:0")
     model = BindyouravatarTransformer3DModel(**dict(MODEL_KW, num_layers=a.layers), device=dev).init_synthetic(seed=0, fast=True)
@@ -37,6 +37,7 @@ def main():
 
     def run(splitk, streamk):
         os.environ["BYA_GEMM_SPLITK"], os.environ["BYA_ATTN_STREAMK"] = splitk, streamk     # read per call by the library
+        _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
         model(return_dict=False, denoise_step=0, **inp)
         out = model(return_dict=False, denoise_step=0, **inp)[0].float().clone()
         torch.cuda.synchronize()

@@ -5,6 +5,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bind_your_avatar_implementation_amd import ops
+from bind_your_avatar_implementation_amd import _hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -30,6 +31,7 @@ for name, M, N, K, act, has_res in SHAPES:
     entry, outs = {}, {}
     for which in ("128", "v4"):
         os.environ["BYA_FP8_KERNEL"] = "128" if which == "128" else "v4"
+        _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
         out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
         best = 1e9
         for rep in range(3):

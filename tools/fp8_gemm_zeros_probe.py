@@ -5,6 +5,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bind_your_avatar_implementation_amd import ops
+from bind_your_avatar_implementation_amd import _hip  # noqa: E402
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 M, N, K = 17776, 9216, 3072
@@ -26,6 +27,7 @@ out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
 z8a, z8w = torch.zeros_like(a8), torch.zeros_like(w8)
 for kern in ("128", "v4"):
     os.environ["BYA_FP8_KERNEL"] = kern
+    _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
     for rep in range(2):
         g = bench(a8, sa, w8, sw, out)
         z = bench(z8a, sa, z8w, sw, out)

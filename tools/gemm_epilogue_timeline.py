@@ -5,9 +5,11 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bind_your_avatar_implementation_amd import ops
+from bind_your_avatar_implementation_amd import _hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 os.environ["BYA_GEMM_SPLITK_MIN"] = "1000"          # unsplit instance
+_hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
 ws = ops.ensure_gemm_workspace(dev)
 SLAB = 256 * 256 * 4
 SHAPES = [("ff1", 17776, 12288, 3072, "gelu_tanh", True, False), ("qkv", 17776, 9216, 3072, None, True, False),

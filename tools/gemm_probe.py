@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from bind_your_avatar_implementation_amd import ops
+from bind_your_avatar_implementation_amd import _hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 S = 17776
@@ -143,21 +144,25 @@ def main():
 
                 def tiled(variant="v4"):
                     os.environ["BYA_GEMM_TILE"], os.environ["BYA_GEMM_VARIANT"] = "4", variant
+                    _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
                     try:
                         ops.gemm(a, w, out, bias=bias, res=res_t)
                     finally:
                         os.environ.pop("BYA_GEMM_TILE", None)
+                        _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
                 arms["bya_rowgemm512"] = rowgemm
                 arms["bya_v4_forced_big_tiles"] = tiled
                 kw = None
             for v in (variants if kw is not None else []):
                 def run(v=v, kw=kw):
                     os.environ["BYA_GEMM_VARIANT"] = v
+                    _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
                     ops.gemm(a, w, out, bias=bias, **kw)
                 arms[f"bya_{v}"] = run
                 if kw and v == variants[0]:
                     def plain(v=v):
                         os.environ["BYA_GEMM_VARIANT"] = v
+                        _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
                         ops.gemm(a, w, out if out.shape[-1] == N else torch.empty(M, N, dtype=torch.bfloat16, device=dev),
                                  bias=bias)
                     if "split" not in kw:
@@ -165,6 +170,7 @@ def main():
                     if kw.get("act") == "gelu_tanh":
                         def ieee(v=v):
                             os.environ["BYA_GEMM_VARIANT"] = v
+                            _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
                             ops.gemm(a, w, out, bias=bias, act="gelu_tanh_ieee")
                         arms[f"bya_{v}_gelu_ieee_div"] = ieee
             if kw is not None and args.fp8 and K % 128 == 0:
@@ -202,6 +208,7 @@ def main():
             del a, w, out
             torch.cuda.empty_cache()
     os.environ.pop("BYA_GEMM_VARIANT", None)
+    _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         with open(args.out, "w") as f:

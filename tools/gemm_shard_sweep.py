@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bind_your_avatar_implementation_amd import ops  # noqa: E402
+from bind_your_avatar_implementation_amd import _hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 VARIANTS = [("default", {}), ("128x128", {"BYA_GEMM_TILE": "1"}), ("256x128", {"BYA_GEMM_TILE": "2"}),
@@ -55,6 +56,7 @@ for W in ((8, 4, 2) if "--w1" not in sys.argv else (1,)):
         for vname, env in VARIANTS:
             for k_, v_ in env.items():
                 os.environ[k_] = v_
+            _hip.apply_env_options()           # (the library reads no environment: hand the change to its option table)
             try:
                 us = timed(lambda: ops.gemm(x, w, out, **kwargs))
                 row[vname] = round(2.0 * M * N * K / us / 1e6, 0)
@@ -62,6 +64,7 @@ for W in ((8, 4, 2) if "--w1" not in sys.argv else (1,)):
                 row[vname] = str(ex)[:40]
             for k_ in env:
                 del os.environ[k_]
+            _hip.apply_env_options()
         best = max((v for v in row.values() if isinstance(v, float)), default=0)
         res[f"W{W} {name} {M}x{N}x{K}"] = row
         print(f"W{W} {name:14s} {M}x{N}x{K}: " + "  ".join(f"{k_}={v_}" for k_, v_ in row.items()), flush=True)

@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bind_your_avatar_implementation_amd import ops  # noqa: E402
+from bind_your_avatar_implementation_amd import _hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 
@@ -46,6 +47,7 @@ def main():
             for k in ("BYA_GEMM_TILE", "BYA_GEMM_SPLITK", "BYA_GEMM_SPLITK_MIN"):
                 os.environ.pop(k, None)
             os.environ.update(env)
+            _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
             us = timed(lambda: ops.gemm(a, w, out))
             row[name] = {"us": round(us, 1), "tflops": round(2.0 * M * N * K / us * 1e-6)}
         res[f"{M}x{N}x{K}"] = row

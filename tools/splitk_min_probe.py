@@ -4,6 +4,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bind_your_avatar_implementation_amd import ops
+from bind_your_avatar_implementation_amd import _hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -20,6 +21,7 @@ for (M, N, K, has_res) in SHAPES:
     row = {}
     for mn in (1000, 24, 16, 12, 8):
         os.environ["BYA_GEMM_SPLITK_MIN"] = str(mn)
+        _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
         best = 1e9
         for rep in range(3):
             for _ in range(3):

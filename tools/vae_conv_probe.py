@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bind_your_avatar_implementation_amd import ops
+from bind_your_avatar_implementation_amd import _hip  # noqa: E402
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 
@@ -31,8 +32,10 @@ for (T, H, W, C, Cout) in [(8, 480, 720, 128, 128), (8, 240, 360, 256, 256), (4,
     a = torch.randn(rows, 27 * C, device=dev).to(torch.bfloat16)
     y2 = torch.empty(rows, Cout, dtype=torch.bfloat16, device=dev)
     os.environ["BYA_GEMM_TILE"] = "4"
+    _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
     t_gemm = timeit(lambda: ops.gemm(a, w, y2, bias=b)) * (T * H * W / rows)
     os.environ.pop("BYA_GEMM_TILE")
+    _hip.apply_env_options()      # (the library reads no environment: hand the change to its option table)
     t_gemm128 = timeit(lambda: ops.gemm(a, w, y2, bias=b)) * (T * H * W / rows)
     print(f"{T}x{H}x{W} C={C} Cout={Cout}: conv3d {t_conv:7.3f} ms = {fl/t_conv*1e-9:6.0f} TF   persistent GEMM on a patch matrix {t_gemm:7.3f} ms = {fl/t_gemm*1e-9:6.0f} TF"
           f"   default-tile GEMM {t_gemm128:7.3f} ms = {fl/t_gemm128*1e-9:6.0f} TF", flush=True)
