@@ -308,6 +308,7 @@ def main():
 
     transport_note, validation = None, None
     if world > 1:
+        os.environ.setdefault("BYA_SP_VERIFY", "1")     # every sharded step trades a checksum of its gathered prediction (engine.verify_exchanges)
         from bind_your_avatar_implementation_amd.parallel import TRANSPORTS, shard_cfg, shard_sequence
         # ---- the reference every transport has to reproduce: the UNSHARDED step, on this rank's own GPU
         with strict_mode():

@@ -131,6 +131,7 @@ constexpr int P2P_CTRL_WORDS = 64;                   // per channel: [0..31] fla
 constexpr int P2P_SENT = 32, P2P_EXPECT = 33, P2P_DONE = 34, P2P_TIMEOUTS = 35, P2P_WAITED = 36;   // [34] push workgroups done,
                                                                                                    // [35] time-outs, [36] wait workgroups done
 constexpr int P2P_GROUP_TIMEOUTS = 37;               // in the group's FIRST control block only: time-outs of any channel
+constexpr int P2P_MISMATCHES = 38;                   // [38] written by the host module: steps whose exchange checksum differed between the ranks
 constexpr int P2P_WAIT_GROUPS = 16;                  // workgroups of a wait: two per XCD under round-robin dispatch
 constexpr int P2P_THREADS = 256;                    // lanes of a push workgroup: 16 waves x 4 loads of 16 bytes in flight per lane (a 4-wave
                                                      // workgroup per CU kept 16 KB in flight: 11 GB/s per CU at HBM latency)
@@ -289,12 +290,14 @@ __global__ __launch_bounds__(64) void p2p_wait_kernel(unsigned* __restrict__ ctr
     p2p_wait_flags(ctrl, group_ctrl, world, expect, limit_ticks, gridDim.x);
 }
 
-// out[0 .. n) := NaN (bf16) if any of the n_channels control blocks starting at ctrl_base carries a time-out
+// out[0 .. n) := NaN (bf16) if any of the n_channels control blocks starting at ctrl_base carries a time-out (word 35) or a
+// checksum mismatch (word 38)
 __global__ __launch_bounds__(256) void p2p_poison_kernel(const unsigned* __restrict__ ctrl_base, int n_channels, uint16_t* __restrict__ out,
                                                           long long n) {
     int bad = 0;
     for (int c = threadIdx.x; c < n_channels; c += 256)
-        bad |= __hip_atomic_load(ctrl_base + (size_t)c * P2P_CTRL_WORDS + P2P_TIMEOUTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        bad |= __hip_atomic_load(ctrl_base + (size_t)c * P2P_CTRL_WORDS + P2P_TIMEOUTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+               __hip_atomic_load(ctrl_base + (size_t)c * P2P_CTRL_WORDS + P2P_MISMATCHES, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     if (!__syncthreads_or(bad)) return;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = 0x7fc0u;
 }

@@ -100,6 +100,9 @@ class DenoiseEngine:
         # remainder pass eats the gain, at an 8-rank shard 34 workgroups are too few), "0" never, "all" always.  A chain is
         # bit-identical to its two launches, so the choice by row count keeps "a rank's shard rounds like the whole clip".
         self.router_chain = os.environ.get("BYA_ROUTER_CHAIN", "1")
+        # (r6) sharded step on the P2P transport: compare a checksum of the step's gathered prediction across the ranks, every
+        # step (parallel.SeqShard.verify_gathered); bench.py --gpus N and the sharded tests switch it on
+        self.verify_exchanges = os.environ.get("BYA_SP_VERIFY", "0") == "1"
         self.router_replicated = os.environ.get("BYA_ROUTER_REPLICATED", "0") == "1"
         # q/k-norm + RoPE inside the q|k|v projection's epilogue (bya_gemm_qkv_norm_rope; bit-identical to the two launches)
         self.qkn_epilogue = os.environ.get("BYA_QKN_EPILOGUE", "1") != "0"
@@ -845,6 +848,8 @@ class DenoiseEngine:
         y = ops.gemm(xo, m.proj_out.weight, buf("y", B, N_loc, co), bias=m.proj_out.bias)
         if sh.active:                                        # every rank returns the full latent prediction
             y = sh.gather_video_rows(y, out=buf("y_full", B, N, co), in_place=True)
+            if self.verify_exchanges:
+                sh.verify_gathered(y)          # every rank holds the same gathered prediction -- or a receive buffer went stale
         out = torch.empty(B, T, co // 4, Hh, Ww, dtype=torch.bfloat16, device=self.dev)
         ops.unpatchify(y, out)
         if sh.p2p is not None:

@@ -506,8 +506,18 @@ class P2PGroup:
         torch.cuda.synchronize(self.dev)
         return int(self.ctrl[:, 35].sum().item())
 
+    def mismatches(self):
+        """Steps whose gathered prediction differed between the ranks (``SeqShard.verify_gathered``; 0 on a healthy run); synchronises."""
+        torch.cuda.synchronize(self.dev)
+        return int(self.ctrl[0, 38].item())
+
     def check(self):
-        """Raise if any wait of this group ever gave up (its consumers ran on a stale receive buffer)."""
+        """Raise if any wait of this group ever gave up (its consumers ran on a stale receive buffer), or a step's exchange
+        checksum differed between the ranks."""
+        m = self.mismatches()
+        if m:
+            raise _hip.ByaError(f"{m} step(s) ended with DIFFERENT gathered predictions on the ranks of this group (exchange checksum, "
+                                f"BYA_SP_VERIFY): a receive buffer was read stale -- results of this run are not to be trusted")
         n = self.timeouts()
         if n:
             raise _hip.ByaError(f"{n} P2P wait(s) timed out (a peer's push did not arrive within the limit, BYA_P2P_TIMEOUT): "

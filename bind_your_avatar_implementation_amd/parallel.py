@@ -221,6 +221,24 @@ class SeqShard:
         out.view(C, self.N, F).copy_(full)
         return out
 
+    def verify_gathered(self, full):
+        """Canary for the P2P transport's weakest assumption: receive buffers are ordinary cached device
+        memory a REMOTE GPU stores into, and a reader sees those stores only because the wait kernel's system-scope acquire made
+        every XCD drop what it held of them.  A line that stays stale now and then is caught by no set-up test.  ``full`` is a
+        tensor every rank holds in full after a gather (the engine passes the step's gathered prediction, a receive buffer that
+        is re-used by every step): each rank sums its copy as 16-bit integers (exact, order-independent), the sums are traded in
+        one 8-byte all-to-all, and a rank whose peers' sums differ from its own bumps word 38 of the group's first control block
+        -- sticky: ``bya_p2p_poison`` turns the step's output into NaN, ``P2PGroup.check`` raises.  ~30 us per step;
+        graph-capturable.  (The reductions are torch ops: diagnostics, not the step's arithmetic.)"""
+        g = self.p2p
+        if g is None or g.solo is not None or self.world == 1:
+            return
+        sums = g.symmetric("__verify__", (self.world,), torch.int64, zero=True)
+        mine = full.contiguous().view(torch.int16).sum(dtype=torch.int64).reshape(1)
+        g.channel(("seq", "verify", self.S, self.Tt), [(mine, j, "__verify__", self.rank) for j in range(self.world)]).exchange()
+        _count("p2p_exchange")
+        g.ctrl[0, 38] += (sums != mine).any().to(torch.int32)
+
     # ---- head-parallel ("Ulysses") exchange for the joint self-attention ---------------------------------------
     # All-gathering K and V replicates 2*S*D elements onto every rank (191 MB received per rank and layer at 8 GPUs);
     # trading rows for heads moves every element of q, k, v (and of the output) exactly once: 48 MB per rank and layer.

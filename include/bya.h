@@ -545,8 +545,9 @@ int bya_alltoall_router(const void* send, void* recv, const int64_t* send_counts
  * group the channel belongs to (may be NULL: then only the channel's own word is used) -- both sticky.  A wait that finds
  * the group's word set returns at once, counted as timed out: after the first time-out of a group the rest of the step runs
  * through without polling.  bya_p2p_poison(ctrl_base, n_channels, out, n) -- enqueue it behind the last consumer of a step --
- * overwrites the bf16 tensor `out` with NaN when any of the n_channels control blocks (64 words apart) carries a time-out, so
- * that a result made from a buffer that never arrived cannot be consumed.  The caller guarantees that a receive buffer is not
+ * overwrites the bf16 tensor `out` with NaN when any of the n_channels control blocks (64 words apart) carries a time-out or a
+ * non-zero word 38 (written by the host: "this step's exchange checksum differed between the ranks"), so that a result made
+ * from a buffer that never arrived, or arrived stale, cannot be consumed.  The caller guarantees that a receive buffer is not
  * pushed into again before its owner has consumed it (the step's data dependencies do).
  * --------------------------------------------------------------------------------------------- */
 typedef struct bya_p2p_copy {      /* a 2-D piece: `rows` rows of `row_bytes` bytes (a contiguous piece is ONE row) */
