@@ -234,7 +234,10 @@ class SeqShard:
         if g is None or g.solo is not None or self.world == 1:
             return
         sums = g.symmetric("__verify__", (self.world,), torch.int64, zero=True)
-        mine = full.contiguous().view(torch.int16).sum(dtype=torch.int64).reshape(1)
+        mine = self._bufs.get("verify_mine")         # (a fixed address: the exchange's copy table is built once, before any capture)
+        if mine is None:
+            mine = self._bufs["verify_mine"] = torch.zeros(1, dtype=torch.int64, device=full.device)
+        mine.copy_(full.contiguous().view(torch.int16).sum(dtype=torch.int64))
         g.channel(("seq", "verify", self.S, self.Tt), [(mine, j, "__verify__", self.rank) for j in range(self.world)]).exchange()
         _count("p2p_exchange")
         g.ctrl[0, 38] += (sums != mine).any().to(torch.int32)
