@@ -139,7 +139,8 @@ def committed_config0_baseline():
     ``bench.py --cpu-baseline-config0`` on a GPU box's host (profiles/r*_cpu_baseline_config0.json) is quoted beside the
     bounded sample instead."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_config0.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "history", "r*_cpu_baseline_config0.json")) +
+                   glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_config0.json")))
     if not files:
         return None
     try:
@@ -157,7 +158,8 @@ def pmc_traffic(world, *kernels):
     PMC summary (profiles/r*_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE in separate passes, MI355X_MICROARCH.md section
     HBM); single-GPU only.  Collected by tools/run_pmc.sh, not inside this run."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "history", "r*_pmc_traffic.json")) +
+                   glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if world != 1 or not files:
         return None
     with open(files[-1]) as f:

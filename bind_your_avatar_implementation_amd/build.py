@@ -15,7 +15,7 @@ SOURCES = ["gemm.hip", "gemm_v4.hip", "gemm_fp8.hip", "gemm_fp8_v4.hip", "attn.h
 # VALU-only kernels are built WITHOUT the SLP vectoriser, i.e. without packed-fp32 (v_pk_mul/fma/mov_f32) instructions:
 # with them the q/k-norm + RoPE kernel returned wrong values in lanes 48..63 of some waves whenever ANOTHER PROCESS kept
 # MFMA-heavy workgroups resident on the same CUs (19-20 of 20 runs; 0 of 20 for the same source built with
-# -fno-slp-vectorize; tools/timeslice/repro.py, profiles/r2_timeslice_repro_run*.json).  These
+# -fno-slp-vectorize; tools/timeslice/repro.py, profiles/history/r2_timeslice_repro_run*.json).  These
 # kernels are HBM-bound, the packed forms bought nothing.
 NO_SLP_SOURCES = {"norm.hip", "misc.hip", "router.hip", "gemm_fp8.hip", "vae.hip", "rowgemm.hip", "rowchain.hip"}     # (gemm_fp8: its row quantiser)
 # translation units whose kernels keep their accumulators in AGPRs (one wave per SIMD, 512 registers)

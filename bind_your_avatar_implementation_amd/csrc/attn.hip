@@ -145,7 +145,7 @@ __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase
         // ALL eight K fragments of the tile are requested before the first MFMA and every MFMA waits for its own fragment
         // only (asm reads, counted lgkmcnt).  Left to hipcc, the 128-register budget of four waves per SIMD made it
         // reuse one fragment register quad: read, wait lgkmcnt(0), MFMA, read ... -- three exposed LDS round trips per
-        // tile, 250 of the 790 cycles a wave spent per tile (ablation: tools/attn_ablate.py, profiles/r2_attn_ablation.json).
+        // tile, 250 of the 790 cycles a wave spent per tile (ablation: tools/attn_ablate.py, profiles/history/r2_attn_ablation.json).
         const uint32_t kb = (uint32_t)(uintptr_t)LDS_PTR(kt) + r * ROW_BYTES;
         const int sw = kswz<D>(r);                       // rows r and r + 32 share the swizzle (32 is a multiple of 16)
         bf16x8 kf[2][4];

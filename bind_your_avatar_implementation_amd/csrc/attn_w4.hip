@@ -511,7 +511,7 @@ int bya_launch_attn_w4(const void* args, hipStream_t s) {
     const long long nt_all = (a.Skv + KV_TILE - 1) / KV_TILE;
     const long long items = (long long)nbh * a.nqt;
     // stream-K pays when an XCD's items make at least one whole round of its 32 CUs plus a partial one.  Measured
-    // (profiles/r4_r_attn_streamk_probe.json): +1 % at 48 heads x 17776 (6.56 rounds), +8.5 % at a 2-rank shard's 24 heads
+    // (profiles/history/r4_r_attn_streamk_probe.json): +1 % at 48 heads x 17776 (6.56 rounds), +8.5 % at a 2-rank shard's 24 heads
     // (3.28 rounds), +2.7 % at 47026 tokens -- a fraction of what the round counts promise, and a grid that does not fill ONE
     // round (6 heads of an 8-rank shard: 210 items on 256 CUs) LOSES 7 % although every workgroup then has 0.81 items
     // of work.  Two forms of the cut (contiguous step ranges; mains + helpers at one key tile) measure the same, so it is

@@ -107,7 +107,7 @@ extern "C" int bya_alltoall_router(const void* send, void* recv, const int64_t* 
 //     places in W peers' q / k / v buffers -- is ONE ordinary kernel launch (~5 us) instead of one collective per tensor
 //     (~20 us each, 360 of them per rank-step in round 3);
 //   * ordinary kernels can be captured: the sharded step replays as a hipGraph (an RCCL collective under capture never
-//     returns on this stack, profiles/r3_rccl_graph_probe.txt).  Sequence numbers therefore live in DEVICE memory (the
+//     returns on this stack, profiles/history/r3_rccl_graph_probe.txt).  Sequence numbers therefore live in DEVICE memory (the
 //     push kernel bumps its channel's send counter, the wait kernel its expect counter): a replay advances them itself.
 // Ordering: every workgroup of the push kernel makes its stores visible system-wide (__threadfence_system) before it
 // counts itself done; the last one publishes the new sequence number to every peer's flag (system-scope release store).

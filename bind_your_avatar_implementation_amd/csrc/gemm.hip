@@ -437,7 +437,9 @@ extern "C" int bya_gemm_qkv_norm_rope(const void* A, const void* W, const void* 
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->K % BK != 0) return BYA_ERR_SHAPE;
     if (!n->qw || !n->qb || !n->kw || !n->kb || n->width <= 0 || n->text_rows < 0) return BYA_ERR_SHAPE;
     if (n->text_rows < d->M && (!n->cos || !n->sin)) return BYA_ERR_SHAPE;
-    if (d->N != 3 * n->width || n->width % 128 != 0 || d->n_split <= 0 || d->act != 0 || d->bias_rowscale || (d->alpha != 0.0f && d->alpha != 1.0f))
+    // N = 3 width: the packed q | k | v projection; N = 2 width (r6): q | k alone -- the sharded step computes v in a launch of
+    // its own first and pushes it to the peers underneath this one
+    if ((d->N != 3 * n->width && d->N != 2 * n->width) || n->width % 128 != 0 || d->n_split <= 0 || d->act != 0 || d->bias_rowscale || (d->alpha != 0.0f && d->alpha != 1.0f))
         return BYA_ERR_UNSUPPORTED;
     if (d->lda % 8 || d->ldw % 8) return BYA_ERR_ALIGN;
     if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)n->qw | (uintptr_t)n->qb | (uintptr_t)n->kw |
@@ -604,7 +606,7 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
         const int m0 = main_tm * 256;
         if (m0 > 0 && m0 < a.M) {
             const long long tail_blocks = (long long)((a.M - m0 + 127) / 128) * ((a.N + 127) / 128);
-            // in pipelined-kernel rounds.  0.9 since round 5 (0.6 before): same-process sweeps (profiles/r5_d_gemm_sweep_*.json)
+            // in pipelined-kernel rounds.  0.9 since round 5 (0.6 before): same-process sweeps (profiles/history/r5_d_gemm_sweep_*.json)
             // have the unsplit persistent kernel ahead of the row split wherever 0.6 chose it -- 2222 x 9216 x 3072: 1078 vs 960
             // TFLOP/s, 4444 x 9216: 1334 vs 1217, 17776 x 3072 x 3072: 1248 vs 1230 -- so the split now needs a clear win
             const double tail_cost = 0.9 * (double)((tail_blocks + 511) / 512);

@@ -101,7 +101,7 @@ extern "C" int bya_gemm_fp8(const void* A8, const float* a_scale, const void* W8
     // Two 128 x 128 workgroups per CU (4 waves, 64 KiB LDS ring each) cover each other's barrier and LDS-DMA waits; a
     // 256 x 256 form (8 waves, 128 KiB ring, one workgroup per CU, half the L2 -> LDS bytes per FLOP) measured 4-16 %
     // slower on the four DiT shapes with this simple two-barrier loop, a one-wave-per-SIMD instantiation 8-20 % slower under
-    // hipcc's schedule (profiles/r2_fp8_probe.txt; both removed from the tree in round 3).
+    // hipcc's schedule (profiles/history/r2_fp8_probe.txt; both removed from the tree in round 3).
     // ... until the loop was placed by hand: gemm_fp8_v4.hip (one wave per SIMD, persistent) takes every launch that is big
     // enough to fill its 256 x 256 tiles; BYA_FP8_KERNEL=128 (read per call: A/B runs) keeps everything on the kernel above.
     const long long tiles256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * d->batch;

@@ -299,7 +299,7 @@ __device__ __forceinline__ void epilogue_qkn(const GemmArgs& p, int z, int m_wav
 
 // SPLIT = false: the instance for launches that will not split a tile (no workspace, short K, or nothing left over): its
 // epilogue has no slab branch -- that branch alone costs the ordinary path 1.5-2.5 % on K = 3072 shapes (same-box A/B,
-// profiles/r2_gemm_epilogue_variants_same_box.txt) because it cuts the unrolled epilogue into blocks.
+// profiles/history/r2_gemm_epilogue_variants_same_box.txt) because it cuts the unrolled epilogue into blocks.
 template <bool SPLIT, bool CONV = false, bool QKN = false>
 __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_m, int tiles_n, int batch, int split_arg,
                                                           int min_seg, unsigned epoch) {
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
             // (r5, measured and NOT adopted: more of the slab in flight.  Two 64-register buffers, two 32-register buffers,
             // a straight-line one-slab form: every variant made hipcc spill 0.3-1 KB per lane around the asm-owned
             // accumulators; the slab by LDS-DMA through the ring -- no registers at all -- built with 700 B of scratch, ran
-            // 13-30 % SLOWER on every split shape and failed the split-K parity test.  profiles/r5_d_gemm_finisher_*.json)
+            // 13-30 % SLOWER on every split shape and failed the split-K parity test.  profiles/history/r5_d_gemm_finisher_*.json)
             {
                 const float* const part0 = p.ws_slabs + (size_t)cur.slab * (GEMM_WS_SLAB_BYTES / 4);
                 const int nparts = cur.parts - 1, part_step = cur.slab_step;

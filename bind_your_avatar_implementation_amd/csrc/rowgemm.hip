@@ -7,7 +7,7 @@
 // (64 KiB each, one 1-KiB W row per LDS-DMA instruction) through a 2-stage LDS ring shared by the block's 8 waves:
 // 8 LDS-DMA instructions and one barrier per 128 MFMAs of a wave.
 //
-// What bounds it (round-2 ablations, profiles/r2_rowgemm_ablation.txt): every wave reads the whole W chunk from LDS for its
+// What bounds it (round-2 ablations, profiles/history/r2_rowgemm_ablation.txt): every wave reads the whole W chunk from LDS for its
 // own 32 rows, so a chunk costs 8 waves x 64 KiB = 512 KiB of ds_read_b128 = 4096 LDS cycles at 128 B/clk -- exactly the
 // 4096 matrix-core cycles of its 1024 MFMAs: the loop is LDS-read-bound at ~60 % of that rate even with the X loads and
 // output stores compiled out (1180 of 2000 TFLOP/s).  The two build-time alternatives kept below were measured and lost:
@@ -16,15 +16,20 @@
 // the single wave loses 17 %; it would need a hand-placed loop like gemm_v4's).  Round 3 re-tried that form with 32 x 32 x 16
 // MFMAs (half the MFMA issue slots), X in AGPRs and the previous chunk's epilogue written between the MFMAs of the next
 // chunk, still compiler-scheduled: bit-identical results, 13-19 % SLOWER on all four launch shapes
-// (profiles/r3_rowgemm_w4_compiler_scheduled_probe.json; hipcc triplicated the chunk loop and put 223 s_waitcnt and 117 s_nop
+// (profiles/history/r3_rowgemm_w4_compiler_scheduled_probe.json; hipcc triplicated the chunk loop and put 223 s_waitcnt and 117 s_nop
 // into it) -- removed again.  A second attempt placed the chunk's 128 MFMAs and 64 fragment reads by hand (eight inline-asm
 // groups of 16 MFMAs with counted lgkmcnt waits, the previous chunk's epilogue in eight compiler-scheduled pieces between
 // them; clean code: no scratch in the loop, no compiler waits beyond the epilogue's LDS reads): bit-identical again and STILL
-// 12-27 % slower (profiles/r3_rowgemm_w4_hand_placed_probe.json: 83 vs 68 us on N = 1536).  A single wave issues in order,
+// 12-27 % slower (profiles/history/r3_rowgemm_w4_hand_placed_probe.json: 83 vs 68 us on N = 1536).  A single wave issues in order,
 // so the epilogue's VALU work between two MFMA groups runs with the matrix pipe idle, where the 8-wave kernel's second wave
 // per SIMD fills it -- and, the larger term, neither form overlaps the X-fragment load of a row block (all 256 workgroups
 // request theirs at the same moment: 64 MB at launch, ~15 us of a 68 us launch) with MFMAs.  The kernel is bound by that and
 // by HBM bytes (N = 512 launches: 108 MB algorithmic in 37 us), not by LDS reads alone; see DESIGN.md section 9.
+// (r6 correction, MI355X_MICROARCH.md section LDS: ds_read_b128 moves 256 B/clk/CU, not 128 -- the chunk loop of this kernel is
+// at half the LDS array's rate, not at it.  Ablations of the 16-row-per-wave chain kernels, where it IS at that rate, and of the
+// W-stationary kernel below: profiles/r6_final_rowchain_ablate.json, r6_final_rowgemm_q_ablate.json -- W staging, fragment reads,
+// barriers and the GELU cost 7-9 us each of a 53 us pass and add up instead of overlapping, because the two waves of a SIMD run
+// the same phase at the same time; the N = 512 kernel's memory side alone takes 28 of its 35 us: 108 MB at 3.9 TB/s.)
 // The product is computed transposed (W fragment = A operand, X fragment = B operand), so a lane ends up with 16
 // consecutive output columns of one token: 16-byte stores, no LDS transpose.
 //
@@ -39,7 +44,8 @@
 #include "options.h"
 
 #ifndef BYA_ROWGEMM_ABLATE
-#define BYA_ROWGEMM_ABLATE 0     // timing-only ablations (tools/): 1 = no X loads, 2 = no output stores
+#define BYA_ROWGEMM_ABLATE 0     // timing-only ablations (tools/rowgemm_q_ablate.py): 1 = no X loads, 2 = no output stores; W-stationary kernel
+                                 // also: 4 = no residual loads, 8 = no W preload, 16 = no MFMAs, 32 = no W fragment reads
 #endif
 
 namespace {
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) 
         (void*)p.C, 0, (int)(((long long)(p.M - 1) * p.ldc + p.N) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(RES ? p.res : p.C), 0, (int)(((long long)(p.M - 1) * (RES ? p.ldres : p.ldc) + p.N) * 2), 0x00020000);
-    {   // the W quarter: stage st holds columns col_base + 64 st .. + 63 in the ring's row order (see stage_chunk above)
+    if (!(BYA_ROWGEMM_ABLATE & 8)) {   // the W quarter: stage st holds columns col_base + 64 st .. + 63 in the ring's row order (see stage_chunk above)
         const uint32_t l16 = (uint32_t)lane << 4;
 #pragma unroll
         for (int st = 0; st < 2; ++st)
@@ -355,7 +361,11 @@ __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) 
     // (hand-counted s_waitcnt around asm loads was tried: the register copies hipcc makes at the pair loop's back edge read
     // slots whose loads are still in flight.  With builtin loads hipcc drains the ring at the head of every pair; measured,
     // that costs nothing -- the kernel is bound by its LDS reads of W, one fragment per two MFMAs.)
+#if BYA_ROWGEMM_ABLATE & 1
+#define XLOAD(DST, VOFF, OFF) { u32x4 t_ = {(VOFF) + (OFF), (VOFF), 0x3f803f80u, 0x3f803f80u}; asm volatile("" : "+v"(t_)); DST = __builtin_bit_cast(bf16x8, t_); }
+#else
 #define XLOAD(DST, VOFF, OFF) DST = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, (VOFF) + (OFF), 0, 0))
+#endif
     uint32_t xo[2][HB];                                    // X row offsets of the pair being computed / the next one
 #pragma unroll
     for (int h = 0; h < HB; ++h) {
@@ -387,11 +397,28 @@ __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) 
         for (int ks = 0; ks < 16; ++ks) {
             const int slot = ks % D;
             bf16x8 wf[2][NJ];
+#if BYA_ROWGEMM_ABLATE & 32
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { u32x4 t_ = {wa[st][0] + j, wa[st][1], 0x3f803f80u, 0x3f803f80u}; asm volatile("" : "+v"(t_)); wf[st][j] = __builtin_bit_cast(bf16x8, t_); }
+            const bf16x8 x0 = xr[slot][0], x1 = xr[slot][1];
+#else
 #pragma unroll
             for (int st = 0; st < 2; ++st) read_kstep(wf[st], wa[st], ks);
             const bf16x8 x0 = xr[slot][0], x1 = xr[slot][1];
             lgkm_wait<0>(wf[0]);
             lgkm_wait<0>(wf[1]);
+#endif
+#if BYA_ROWGEMM_ABLATE & 16
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    asm volatile("" : "+v"(acc[st][0][j]) : "v"(wf[st][j]), "v"(x0));
+                    asm volatile("" : "+v"(acc[st][1][j]) : "v"(wf[st][j]), "v"(x1));
+                }
+#else
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -399,6 +426,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) 
                     acc[st][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st][j], x0, acc[st][0][j], 0, 0, 0);
                     acc[st][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[st][j], x1, acc[st][1][j], 0, 0, 0);
                 }
+#endif
             // refill the slot 8 k-steps ahead: the second half of a pair prefetches the first half of the next pair
             if (ks + D < 16) {
                 XLOAD(xr[slot][0], xo[0][0], (ks + D) * 64);
@@ -407,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) 
                 XLOAD(xr[slot][0], xo[1][0], (ks + D - 16) * 64);
                 XLOAD(xr[slot][1], xo[1][1], (ks + D - 16) * 64);
             }
-            if (RES && ks == 7) {                          // the residual of this pair, under the second half of its MFMAs
+            if (RES && ks == 7 && !(BYA_ROWGEMM_ABLATE & 4)) {                          // the residual of this pair, under the second half of its MFMAs
 #pragma unroll
                 for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -447,6 +475,9 @@ __global__ __launch_bounds__(64 * NW, 2) void rowgemm512q_kernel(RowGemmArgs p) 
                     u32x4 ov;
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) ov[w2] = pack2bf(v[2 * w2], v[2 * w2 + 1]);
+#if BYA_ROWGEMM_ABLATE & 2
+                    if (ov[0] == 0x12345678u && ov[3] == 0x9abcdef0u)
+#endif
                     __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, co[h] + (64 * st + (CH / 2) * u) * 2, 0, 0);
                 }
             }
@@ -817,7 +848,7 @@ extern "C" int bya_rowgemm512(const void* X, const void* W, const float* colsum,
     const bool gelu = act == BYA_ACT_GELU_ERF;
     // N = 512: the W-stationary, barrier-free form (one W quarter per workgroup).  The rows M * ld must stay below 2 GiB like
     // everywhere here; tiles outside a wave's range are addressed outside the descriptors.
-    // measured (profiles/r4_v_rowgemm_q_probe.json): -4 % at 35100 rows, -22 % at 17550, -47 % at 8788, -29 % at 4394 and
+    // measured (profiles/history/r4_v_rowgemm_q_probe.json): -4 % at 35100 rows, -22 % at 17550, -47 % at 8788, -29 % at 4394 and
     // 2194, level at 70200 -- above that the chunk-balanced kernel's finer work units win back what its barriers cost
     if (N == 512 && !ln && M >= 2048 && M <= 65536 && !bya_ref_form(BYA_REF_ROWGEMM_CHUNKED)) {
         // (the LayerNorm-folding instance -- mlp[0] -- keeps the chunk-balanced kernel: accumulating the row statistics from

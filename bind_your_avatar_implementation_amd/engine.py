@@ -37,7 +37,7 @@ FP8_LINEARS = ("qkv", "out", "ff1", "ff2", "pq", "aq")
 # ... and the ones that do by default: the four DiT Linears.  The two query projections feed the Embedding Router and the
 # cross-attentions, whose sigmoid routing amplifies their error: in e4m3 the perceiver to_q ALONE doubles the 42-layer output
 # error (3.7e-2 against the bf16 engine's 1.8e-2; any one DiT Linear: 1.9-2.0e-2) for 1 % of the step time
-# (tools/fp8_error_by_linear.py, profiles/r3_fp8_error_by_linear.json).
+# (tools/fp8_error_by_linear.py, profiles/history/r3_fp8_error_by_linear.json).
 FP8_DEFAULT = ("qkv", "out", "ff1", "ff2")
 
 
@@ -103,6 +103,11 @@ class DenoiseEngine:
         # (r6) sharded step on the P2P transport: compare a checksum of the step's gathered prediction across the ranks, every
         # step (parallel.SeqShard.verify_gathered); bench.py --gpus N and the sharded tests switch it on
         self.verify_exchanges = os.environ.get("BYA_SP_VERIFY", "0") == "1"
+        # (r6) sharded step, P2P transport: exchange A's v third on the side stream underneath the q | k projection
+        # ("1" where a rank has at least SP_OVERLAP_V_MIN_ROWS rows, "0" never, "all" always)
+        self.sp_overlap_v = os.environ.get("BYA_SP_OVERLAP_V", "1") != "0"
+        if os.environ.get("BYA_SP_OVERLAP_V") == "all":
+            self.SP_OVERLAP_V_MIN_ROWS = 0
         self.router_replicated = os.environ.get("BYA_ROUTER_REPLICATED", "0") == "1"
         # q/k-norm + RoPE inside the q|k|v projection's epilogue (bya_gemm_qkv_norm_rope; bit-identical to the two launches)
         self.qkn_epilogue = os.environ.get("BYA_QKN_EPILOGUE", "1") != "0"
@@ -223,7 +228,7 @@ class DenoiseEngine:
                         if name == "spatial_attn":
                             # softmax scale * log2(e) folded into to_k (weights and bias, in fp32 before the one bf16 rounding
                             # of the packed weight): the 1350 x 1350 attention's scores are born in exp2 units, like the joint
-                            # attention's (-9 % on that launch, profiles/r4_m_spatial_attn_probe.json)
+                            # attention's (-9 % on that launch, profiles/history/r4_m_spatial_attn_probe.json)
                             c = (64 ** -0.5) * 1.4426950408889634
                             F_ = r.feat_dim
                             w, b = w.float().clone(), b.float().clone()
@@ -675,9 +680,27 @@ class DenoiseEngine:
                             # (device bound: this rank's rows give its partial maxima for ALL heads; the tables travel with
                             # the q|k|v exchange and the attention takes the maximum over the ranks' tables for its heads)
                             sb, st = self._attn_bound(i, H, slots=max(1, 64 // W))
-                            self._qkv_norm_rope(i, at, xn[0], qkvb[0], (Dl, S_loc * Dl), None if xq is None else (xq[0][0], xq[1][0]),
-                                                cos, sin, qk_kw["text_rows"], H // W, qkvb[:W], qkvb[W:2 * W], st)
-                            qh_, kh_, vh_, st_all = sh.rows_to_heads_qkv(qkvb, st)
+                            if (self.sp_overlap_v and st is None and xq is None and (self.w8 is None or "qkv" not in self.w8)
+                                    and S_loc >= self.SP_OVERLAP_V_MIN_ROWS):
+                                # (r6) v FIRST: v needs no norm -- its projection is a launch of its own, its column blocks travel
+                                # on the side stream while the q | k projection (with the norm in its epilogue) runs; only the
+                                # q | k exchange is exposed.  Same bits: every output element is summed over K in the same order
+                                ops.gemm(xn[0], self.qkv_w[i][2 * D:], qkvb[2 * W], bias=self.qkv_b[i][2 * D:], split=(Dl, S_loc * Dl))
+                                sh.push_v_heads(qkvb[2 * W:])
+                                if not (self.qkn_epilogue and ops.gemm_qkv_norm_rope(
+                                        xn[0], self.qkv_w[i][:2 * D], qkvb[0], self.qkv_b[i][:2 * D], (Dl, S_loc * Dl), at.norm_q.weight,
+                                        at.norm_q.bias, at.norm_k.weight, at.norm_k.bias, cos, sin, qk_kw["text_rows"], eps=at.norm_q.eps,
+                                        k_scale=self.k_scale, tensors=2)):
+                                    ops.gemm(xn[0], self.qkv_w[i][:2 * D], qkvb[0], bias=self.qkv_b[i][:2 * D], split=(Dl, S_loc * Dl))
+                                    ops.qknorm_rope(qkvb[:W], qkvb[W:2 * W], at.norm_q.weight, at.norm_q.bias, at.norm_k.weight,
+                                                    at.norm_k.bias, cos, sin, heads=H // W, text_rows=qk_kw["text_rows"],
+                                                    eps=at.norm_q.eps, k_scale=self.k_scale)
+                                qh_, kh_, vh_ = sh.rows_to_heads_qk(qkvb[:2 * W])
+                                st_all = None
+                            else:
+                                self._qkv_norm_rope(i, at, xn[0], qkvb[0], (Dl, S_loc * Dl), None if xq is None else (xq[0][0], xq[1][0]),
+                                                    cos, sin, qk_kw["text_rows"], H // W, qkvb[:W], qkvb[W:2 * W], st)
+                                qh_, kh_, vh_, st_all = sh.rows_to_heads_qkv(qkvb, st)
                             ops.self_attention(qh_[None], kh_[None], vh_[None], oh[None], heads=H // W, tag="joint", prescaled=True,
                                                score_bound=sb, bound=None if st is None else (st_all, sh.rank * (H // W), self._ws["qk_flags"]))
                             xo = sh.heads_to_rows(oh)              # (the symmetric receive buffer, already in [rows, heads] order)
@@ -881,6 +904,10 @@ class DenoiseEngine:
     # row ranges in which a chain beats its two launches (profiles/r6_a_router_chain_probe.json, same box, us: MLP 50.5 -> 39.0 at
     # 17550 rows, 37.8 -> 28.9 at 8788, 69.2 -> 69.8 at 35100, 23.8 -> 26.8 at 4394; multi-ID 64.3 -> 60.2, 47.1 -> 43.2, 93.4 ->
     # 109, 28.6 -> 41.4; temporal level or slower everywhere)
+    # below this many rows per rank the two smaller projection launches cost more than the hidden link time buys (2222 rows of
+    # an 8-rank step: 108 + 216 tiles of 256 x 256 on 256 CUs instead of 324)
+    SP_OVERLAP_V_MIN_ROWS = 4096
+
     ROUTER_CHAIN_ROWS = {"mlp": (6000, 24000), "multi_id_attn": (6000, 24000), "temporal_attn": (1, 0)}
 
     def _chain_ok(self, rows, kind):

@@ -401,7 +401,7 @@ def gemm(a, w, out, bias=None, res=None, gate0=None, gate1=None, gate_split=0, g
     return out
 
 
-def gemm_qkv_norm_rope(a, w, out, bias, split, qw, qb, kw, kb, cos, sin, text_rows, eps=1e-6, k_scale=1.0):
+def gemm_qkv_norm_rope(a, w, out, bias, split, qw, qb, kw, kb, cos, sin, text_rows, eps=1e-6, k_scale=1.0, tensors=3):
     """The packed q|k|v projection with the q/k LayerNorm(64) + RoPE in its epilogue (bya_gemm_qkv_norm_rope): equals
     ``gemm(..., split=split)`` followed by ``qknorm_rope`` bit for bit, in one launch.  Returns False (nothing launched) when
     the library does not take the shape -- the caller then issues the two launches."""
@@ -409,8 +409,10 @@ def gemm_qkv_norm_rope(a, w, out, bias, split, qw, qb, kw, kb, cos, sin, text_ro
     ab, M, K, a_bs, lda = _mat(a, "a")
     ob, Mo, _, c_bs, ldc = _mat(out, "out")
     N = w.shape[0]
-    if w.dim() != 2 or w.shape[1] != K or w.stride(1) != 1 or w.dtype != torch.bfloat16 or N % 3 or (ab, M) != (ob, Mo):
-        raise ValueError("gemm_qkv_norm_rope: a [(B,) M, K], w [3 * width, K], out = the first of the split outputs")
+    if w.dim() != 2 or w.shape[1] != K or w.stride(1) != 1 or w.dtype != torch.bfloat16 or tensors not in (2, 3) or N % tensors \
+            or (ab, M) != (ob, Mo):
+        raise ValueError("gemm_qkv_norm_rope: a [(B,) M, K], w [3 * width, K] (or [2 * width, K]: q | k alone, tensors=2), "
+                         "out = the first of the split outputs")
     d = GemmDesc()
     d.M, d.N, d.K, d.batch = M, N, K, ab
     d.lda, d.ldw, d.ldc = lda, w.stride(0), ldc
@@ -419,7 +421,7 @@ def gemm_qkv_norm_rope(a, w, out, bias, split, qw, qb, kw, kb, cos, sin, text_ro
     d.alpha = 1.0
     n = _hip.QkNormDesc()
     n.qw, n.qb, n.kw, n.kb, n.cos, n.sin = _p(qw), _p(qb), _p(kw), _p(kb), _p(cos), _p(sin)
-    n.text_rows, n.width, n.eps, n.k_scale = int(text_rows), N // 3, float(eps), float(k_scale)
+    n.text_rows, n.width, n.eps, n.k_scale = int(text_rows), N // tensors, float(eps), float(k_scale)
     if cos is not None:
         assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
         assert cos.shape == (M - text_rows, 64)

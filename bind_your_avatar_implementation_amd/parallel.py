@@ -289,6 +289,27 @@ class SeqShard:
         self._exchange(("qkvh", stats is not None), pieces)
         return full[0], full[1], full[2], st_all
 
+    def push_v_heads(self, blocks_v):
+        """(r6) Exchange A with v FIRST: the v projection's column blocks [world, S_loc, Dl] go to the v third of every
+        destination's [3, S, Dl] buffer on the SIDE stream (``Channel.push(side=True)``), underneath the q | k projection the
+        caller launches next; ``rows_to_heads_qk`` then exchanges q | k and waits for this push as well."""
+        W, S_loc, Dl = blocks_v.shape
+        name = f"qkvh:{(3, self.S, Dl)}"
+        self.p2p.symmetric(name, (3, self.S, Dl), blocks_v.dtype)
+        self._v_push = self._push(("vh",), [(blocks_v[j], j, name, (2 * self.S + self.r0) * Dl) for j in range(W)], side=True)
+
+    def rows_to_heads_qk(self, blocks_qk):
+        """The q | k column blocks [2 * world, S_loc, Dl] in one exchange, then the wait for the v push that has been running
+        underneath the q | k projection.  Returns (q_heads, k_heads, v_heads) like ``rows_to_heads_qkv``."""
+        W2, S_loc, Dl = blocks_qk.shape
+        W = self.world
+        name = f"qkvh:{(3, self.S, Dl)}"
+        full = self.p2p.symmetric(name, (3, self.S, Dl), blocks_qk.dtype)
+        self._exchange(("qkh",), [(blocks_qk[t * W + j], j, name, (t * self.S + self.r0) * Dl) for j in range(W) for t in range(2)])
+        self._v_push.wait()
+        self._v_push = None
+        return full[0], full[1], full[2]
+
     def heads_to_rows(self, o_heads, out=None):
         """o_heads [S, Dl] (all rows, this rank's heads) -> [S_loc, world*Dl] (this rank's rows, all heads).  The
         exchange is enqueued on the communicator's own stream like every other one here (``async_op``) and the compute

@@ -474,7 +474,7 @@ class BindyouravatarTransformer3DModel(nn.Module):
         resident sequence numbers: bya_p2p_push / bya_p2p_wait), replay from a hipGraph.  With the ``torch`` transport the
         sharded step stays eager: capturing it needs RCCL collectives inside a stream capture, and on this stack (PyTorch
         2.10-ROCm 7.0, RCCL of ROCm 7.2) even a lone ``all_to_all_single`` under ``torch.cuda.graph`` never returns
-        (tools/rccl_graph_probe.py, profiles/r3_rccl_graph_probe.txt)."""
+        (tools/rccl_graph_probe.py, profiles/history/r3_rccl_graph_probe.txt)."""
         group = getattr(self, "_seq_group", None)
         if getattr(self, "_seq_world", 1) == 1 and group is None:
             return True

@@ -114,7 +114,8 @@ int bya_gemm_bf16(const void* A, const void* W, const void* bias, void* C, const
  * normalised from the bf16-ROUNDED projection and with the arithmetic of csrc/qknorm_math.h, so the result equals
  * bya_gemm_bf16 followed by bya_qknorm_rope BIT FOR BIT -- q and k are just written once instead of written, read and written
  * again.  rows >= text_rows are rotated with cos / sin [rows - text_rows, 64] fp32 (row index = row of the launch, per batch
- * entry); k_scale as for bya_qknorm_rope.  Constraints: no activation / residual / gates, width % 128 == 0, the persistent
+ * entry); k_scale as for bya_qknorm_rope.  N = 3 width (q | k | v) or, since round 6, N = 2 width (q | k alone: the sharded step
+ * computes v first and pushes it to the peers underneath this launch).  Constraints: no activation / residual / gates, width % 128 == 0, the persistent
  * kernel's alignment rules; BYA_ERR_UNSUPPORTED otherwise (the caller then issues the two launches). */
 typedef struct bya_qknorm_desc {
     const void* qw; const void* qb; const void* kw; const void* kb;   /* bf16 [64] each */

@@ -150,10 +150,10 @@ def test_valu_only_kernels_hold_no_packed_fp32(lib_path):
         # The MFMA translation units DO hold packed-fp32 instructions (epilogues, softmax): if the multi-process finding of
         # DESIGN.md section 5 is what it looks like, they are exposed in the same setting (several processes on one GPU).
         # That finding is a workaround, not a closed root cause; the exposure is recorded here so that it is a number and
-        # not a guess (profiles/r3_packed_fp32_counts.json, rewritten with BYA_RECORD_PACKED_COUNTS=1), and must not grow
+        # not a guess (profiles/history/r3_packed_fp32_counts.json, rewritten with BYA_RECORD_PACKED_COUNTS=1), and must not grow
         # unnoticed.
         import json
-        rec_path = os.path.join(ROOT, "profiles", "r3_packed_fp32_counts.json")
+        rec_path = os.path.join(ROOT, "profiles", "history", "r3_packed_fp32_counts.json")
         counts = {src: len(packed.findall(device_asm(src, tmp))) for src in ("gemm.hip", "gemm_v4.hip", "gemm_fp8_v4.hip", "attn.hip", "rowgemm.hip")}
         print("packed-fp32 instructions in the MFMA translation units:", counts)
         if os.environ.get("BYA_RECORD_PACKED_COUNTS") == "1":

@@ -1,5 +1,5 @@
 """The bench.py contract (one JSON line; metric / config of BASELINE.json; roofline and cpu_baseline objects) checked on the
-committed output of the end-of-round run (profiles/r5_final_bench.json = stdout of ``python bench.py --steps 10 --warmup 3``
+committed output of the end-of-round run (profiles/r6_final_bench.json = stdout of ``python bench.py --steps 20 --warmup 5``
 on an MI355X) and on the script's command line, without a GPU."""
 import json
 import os
@@ -17,7 +17,7 @@ def _line(path):
 
 def test_committed_bench_line_meets_the_contract():
     import glob
-    d = _line(os.path.join(ROOT, "profiles", "r5_final_bench.json"))                             # the end-of-round line of round 5
+    d = _line(os.path.join(ROOT, "profiles", "r6_final_bench.json"))                             # the end-of-round line of round 6
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     # BASELINE.json: "denoise-steps/sec + latent frames/sec, 49x480x720 bf16, 1/2/4/8 MI355X"
     assert base["metric"].startswith(d["metric"]) and d["unit"] == "steps/s" and "latent_frames_per_sec" in d
@@ -50,7 +50,38 @@ def test_committed_bench_line_meets_the_contract():
     assert d["large_qk_gain_variant"]["attention_variants"] == {"joint:d64_static_bound_w4": 168} and d["large_qk_gain_variant"]["finite"]
     assert d["fp8_weights_variant"]["value"] > d["value"]
     # the SURVEY 8(d) form of the CPU baseline is quoted from its committed run
-    assert c["config0_reference"]["file"].startswith("profiles/r5_") and c["config0_reference"]["value"] > 0
+    assert c["config0_reference"]["file"].startswith("profiles/history/r5_") and c["config0_reference"]["value"] > 0
+    # (r6) the line can be read on a pool whose boxes differ by +-3 %: what THIS board sustains on a bare-MFMA loop, and the
+    # two big kernels against it beside the spec-peak fractions (which stay the headline); the router's share; the hand-off mode
+    cal = d["board_calibration_tflops"]
+    assert 1500 < cal < 2500 and abs(r["frac_of_board"] - r["achieved"] / cal) < 1e-9 and r["frac_of_board"] > r["frac"]
+    assert abs(d["attn_roofline"]["frac_of_board"] - d["attn_roofline"]["achieved"] / cal) < 1e-9
+    assert abs(d["mfma_roofline_frac_of_board_whole_step"] - d["mfma_roofline_frac_whole_step"] * 2500.0 / cal) < 1e-9
+    from bench import ROUTER_TIMERS
+    assert abs(d["router_ms_per_step"] - sum(km.get(k, 0.0) for k in ROUTER_TIMERS)) < 0.01
+    assert d["handoff_mode"].startswith("split-K")
+
+
+def test_committed_rehearsal_lines_of_the_n_gpu_path_carry_their_own_reference():
+    """(r6) A line of `bench.py --gpus N` names the same node's UNSHARDED step and the speed-up over it (a 1-GPU line from another
+    box of the pool cannot be divided into it), validates the transport before it times, replays from a hipGraph on the P2P rungs
+    and, for N >= 4, measures the CFG pair as well.  Checked on the committed one-GPU rehearsals (all ranks on one GPU: the code
+    path, not a measurement)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r6_final_bench_*_ranks_on_one_gpu_42_layers.json")))
+    assert files, "no committed rehearsal of the N > 1 bench path"
+    for f in files:
+        d = _line(f)
+        n = d["n_gpus"]
+        assert n in (2, 4, 8) and d["config"]["layers"] == 42 and d["config"]["launch"] == "hipGraph replay"
+        val = d["config"]["validated_against_unsharded_step"]
+        assert val["rungs"][-1]["bit_identical_to_unsharded_step"] and val["default_mode_rel_fro_vs_reference"] <= val["default_mode_bound"]
+        assert len(d["unsharded_step_ms_per_rank"]) == n and len(d["board_calibration_tflops_per_rank"]) == n
+        assert abs(d["speedup_vs_unsharded_same_node"] - d["unsharded_step_ms_same_node"] / d["ms_per_step"]) < 1e-6
+        if n >= 4:
+            cp = d["cfg_pair_variant"]
+            assert cp["batch"] == 2 and cp["rel_fro_vs_unsharded_batch2_step"] <= 3e-2
+            assert abs(cp["speedup_vs_unsharded_batch2_same_node"] - cp["unsharded_batch2_step_ms_same_node"] / cp["ms_per_step"]) < 1e-6
 
 
 def test_bench_command_line_parses_without_a_gpu():

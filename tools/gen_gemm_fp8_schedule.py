@@ -17,7 +17,7 @@ PLACEMENTS = {
     8: (7, list(range(8, 31, 3)) + list(range(33, 55, 3)), True),  # W(4..7) reads spread over MFMAs 0..3, B1 behind MFMA 7
     9: (9, list(range(10, 31, 3)) + list(range(32, 57, 3)), True), # ... B1 behind MFMA 9 (368 us): SHIPPED
     10: (11, list(range(12, 31, 3)) + list(range(32, 59, 3))[:9], True),   # ... B1 behind MFMA 11
-    # measured and dropped (profiles/r3_fp8_gemm_probe.json): every 2nd MFMA (385), every 3rd (386), two
+    # measured and dropped (profiles/history/r3_fp8_gemm_probe.json): every 2nd MFMA (385), every 3rd (386), two
     # behind every 4th (396), B1 four MFMAs later (370), nine in phase 0 + seven densely at the start of phase 1 (367)
 }
 PLACE_DEFAULT = 9
