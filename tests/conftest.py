@@ -21,6 +21,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def _release_cached_gpu_memory():
+    """After every test: hand the caching allocator's free blocks back to the driver.  The multi-process tests (2-8 workers on
+    the ONE test GPU, each with its own model) need that memory; late in the suite this process's cache alone was tens of GB."""
+    yield
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.empty_cache()
+
+
 @pytest.fixture
 def lib_options():
     """``lib_options(gemm_splitk=0, ...)``: set options of the HIP library (ops.options, include/bya.h bya_set_option) until the
