@@ -26,16 +26,10 @@ namespace {
 #ifndef BYA_ATTN_ABLATE
 #define BYA_ATTN_ABLATE 0
 #endif
-#ifndef BYA_ATTN_KPREFETCH
-#define BYA_ATTN_KPREFETCH 0      // 1 = all K fragment reads of a tile up front, counted waits (tools/attn_ablate.py: +-1 % on the
-                                  // static-bound kernel, -30 % on the running-maximum kernel whose registers are tighter: off)
-#endif
-#ifndef BYA_ATTN_OCC
-#define BYA_ATTN_OCC 4
-#endif
-#ifndef BYA_ATTN_RING
-#define BYA_ATTN_RING 2          // K/V stages in LDS for head_dim 64 (3 = staging two tiles ahead; experiment switch)
-#endif
+// (The build knobs BYA_ATTN_KPREFETCH / OCC / RING of rounds 2-4 -- all K fragment reads of a tile up front: +-1 % on the static-bound
+// kernel, -30 % on the running-maximum one (profiles/history/r2_attn_ablation.json); a third K/V stage: no gain -- are gone since
+// round 6; 2 is the ring depth they left.)
+constexpr int ATTN_RING = 2;     // K/V stages in LDS
 constexpr int Q_PER_WAVE = 32;
 constexpr int Q_PER_BLOCK = 128;
 
@@ -141,38 +135,6 @@ __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase
     const float thr = PRESCALED ? RESCALE_THR : RESCALE_THR / c;
     constexpr int ROW_BYTES = D * 2, DSTEPS = D / 16, DT = D / 32;
     f32x16 sacc[2];
-    if constexpr (D == 64 && BYA_ATTN_KPREFETCH) {
-        // ALL eight K fragments of the tile are requested before the first MFMA and every MFMA waits for its own fragment
-        // only (asm reads, counted lgkmcnt).  Left to hipcc, the 128-register budget of four waves per SIMD made it
-        // reuse one fragment register quad: read, wait lgkmcnt(0), MFMA, read ... -- three exposed LDS round trips per
-        // tile, 250 of the 790 cycles a wave spent per tile (ablation: tools/attn_ablate.py, profiles/history/r2_attn_ablation.json).
-        const uint32_t kb = (uint32_t)(uintptr_t)LDS_PTR(kt) + r * ROW_BYTES;
-        const int sw = kswz<D>(r);                       // rows r and r + 32 share the swizzle (32 is a multiple of 16)
-        bf16x8 kf[2][4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const uint32_t a = kb + (((2 * s + hf) ^ sw) << 4);
-            kf[0][s] = lds_read128<0>(a);
-            kf[1][s] = lds_read128<32 * ROW_BYTES>(a);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[u][i] = 0.f;
-        if (!BOUNDED) {
-            sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mfrag, sacc[0], 0, 0, 0);
-            sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, mfrag, sacc[1], 0, 0, 0);
-        }
-        lgkm_wait<6>(); sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][0], qf[0], sacc[0], 0, 0, 0);
-        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][0], qf[0], sacc[1], 0, 0, 0);
-        lgkm_wait<4>(); sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][1], qf[1], sacc[0], 0, 0, 0);
-        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][1], qf[1], sacc[1], 0, 0, 0);
-        lgkm_wait<2>(); sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][2], qf[2], sacc[0], 0, 0, 0);
-        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][2], qf[2], sacc[1], 0, 0, 0);
-        lgkm_wait<0>(); sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][3], qf[3], sacc[0], 0, 0, 0);
-        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][3], qf[3], sacc[1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    } else {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -187,11 +149,9 @@ __device__ __forceinline__ void attn_tile(const char* kt, const uint32_t (&vbase
             sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[u], 0, 0, 0);
         }
     }
-    }
     // first V fragments can fly while the softmax runs
     VFrag<D> fa, fb;
     v_issue<D, 0>(fa, vbase);
-    if constexpr (D == 64 && BYA_ATTN_KPREFETCH) __builtin_amdgcn_sched_barrier(0);      // ... issued HERE, ahead of the softmax
 
     float mx = -INFINITY;
 #pragma unroll
@@ -271,7 +231,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& p, char* smem) {
     constexpr int TILE_BYTES = KV_TILE * ROW_BYTES;
     constexpr int DSTEPS = D / 16;   // k-steps of the QK^T product
     constexpr int DT = D / 32;       // 32-row tiles of O^T
-    constexpr int RING = D == 64 ? BYA_ATTN_RING : 2;
+    constexpr int RING = ATTN_RING;
     // LDS ring: stage b holds K at smem + b*2*TILE_BYTES and V right behind it
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -752,7 +712,7 @@ template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     const int nbh = a.nb1 * a.nb2 * a.heads;
     dim3 grid((nbh * a.nqt + 7) / 8 * 8);          // whole groups of 8 (one block per XCD); surplus blocks exit at once
-    const size_t lds = (size_t)(D == 64 ? BYA_ATTN_RING : 2) * 2 * KV_TILE * D * 2;
+    const size_t lds = (size_t)ATTN_RING * 2 * KV_TILE * D * 2;
     if (D == 64 && a.prescaled && a.bound_dev) {
         // data-dependent bound: the static kernel serves every head whose bound is usable and flags the others, the
         // running-maximum kernel right behind it serves exactly those (its other workgroups exit at once)
