@@ -270,7 +270,9 @@ HANDOFF_MODE = {}      # device index -> why the split forms are off on that dev
 
 
 def _handoff_counts(device=None):
-    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    idx = None if device is None else torch.device(device).index
+    if idx is None:                      # (None, "cuda": the current device)
+        idx = torch.cuda.current_device()
     g = gemm_workspace_status(idx) if idx in _GEMM_WS else 0
     a = attn_workspace_status(idx) if idx in _ATTN_WS else 0
     seen = _HEALED.get(idx, [0, 0])
