@@ -106,6 +106,7 @@ class DenoiseEngine:
         # (r6) sharded step, P2P transport: exchange A's v third on the side stream underneath the q | k projection
         # ("1" where a rank has at least SP_OVERLAP_V_MIN_ROWS rows, "0" never, "all" always)
         self.sp_overlap_v = os.environ.get("BYA_SP_OVERLAP_V", "1") != "0"
+        self.sp_shard_mods = os.environ.get("BYA_SP_SHARD_MODS", "1") != "0"      # (r6) the AdaLN vector in column slices, one per rank
         if os.environ.get("BYA_SP_OVERLAP_V") == "all":
             self.SP_OVERLAP_V_MIN_ROWS = 0
         self.router_replicated = os.environ.get("BYA_ROUTER_REPLICATED", "0") == "1"
@@ -615,7 +616,21 @@ class DenoiseEngine:
         e1 = ops.linear_small_m(tfeat, te.linear_1.weight, te.linear_1.bias, buf("e1", B, te.linear_1.weight.shape[0]),
                                 act_out="silu")
         emb = ops.linear_small_m(e1, te.linear_2.weight, te.linear_2.bias, buf("emb", B, te.linear_2.weight.shape[0]))
-        mods = ops.linear_small_m(emb, self.mod_w, self.mod_b, buf("mods", B, self.mod_w.shape[0]), silu_in=True)
+        Nm = self.mod_w.shape[0]
+        if sh.active and sh.p2p is not None and B == 1 and self.sp_shard_mods:
+            # (r6) sharded step: the AdaLN vector -- 1.55 M outputs against a 1.6 GB weight, 0.6 ms of weight streaming that every
+            # rank used to repeat before its first LayerNorm -- is computed in column slices, one per rank, and gathered by ONE
+            # exchange (3 MB).  Same bits: the weight-streaming kernel's outputs are independent of one another.  The receive
+            # buffer is re-used every step: a peer starts its next step only behind its output gather, which this rank joins
+            # after its last use of the vector.
+            W, r = sh.world, sh.rank
+            cut = [(Nm * j // W) // 8 * 8 for j in range(W)] + [Nm]
+            part = buf("mods_part", 1, cut[r + 1] - cut[r])
+            ops.linear_small_m(emb, self.mod_w[cut[r]:cut[r + 1]], self.mod_b[cut[r]:cut[r + 1]], part, silu_in=True)
+            mods = sh.p2p.symmetric(f"mods:{(1, Nm)}", (1, Nm), torch.bfloat16)
+            sh._exchange(("mods", Nm), [(part[0], j, f"mods:{(1, Nm)}", cut[r]) for j in range(W)])
+        else:
+            mods = ops.linear_small_m(emb, self.mod_w, self.mod_b, buf("mods", B, Nm), silu_in=True)
         mbs = mods.stride(0)
 
         # ---- D1: patch embed into the joint stream x = [text | video] (this rank's rows only)
