@@ -22,6 +22,7 @@ struct GemmArgs {
     // 1024 counters; null = the last, partial round of tiles is not split
     float* ws_slabs;
     unsigned* ws_counters;
+    int gm = 4;                   // persistent kernel: group-M width of the tile order (gemm_v4.hip; chosen per shape by its launchers)
     // Implicit-GEMM 3 x 3 x 3 convolution on the persistent kernel (bya_vae_conv3d; gemm_v4.hip, CONV instance): A is the
     // zero-padded channels-last input [To + 2, Hp, Wp, C] seen as a matrix of pixels x C (lda = C), row m of the product is
     // the padded pixel m of the OUTPUT grid [To, Hp, Wp] (rows with h >= H or w >= W are computed and dropped), K-tile t is

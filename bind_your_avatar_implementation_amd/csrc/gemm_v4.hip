@@ -360,11 +360,15 @@ __global__ __launch_bounds__(256, 1) void gemm256p_kernel(GemmArgs p, int tiles_
         const int idz = c.valid ? id : base;
         c.z = idz / per_z;
         const int idt = idz - c.z * per_z;
-#ifndef BYA_GEMM_GM
-#define BYA_GEMM_GM 4
+        // group-M order: GM row tiles sweep a column tile before the order moves on -- what the 32 concurrent tiles of an XCD share
+        // in its L2.  Chosen per SHAPE by the launchers (gemm_group_m below; round 3 had one compromise, 4): same-box sweep of
+        // round 6 (tools/gemm_gm_probe.py, profiles/r6_k_gemm_gm_probe.json): FF2 (K = 12288) 1283 TFLOP/s at 2, 1268 at 4, 1244
+        // at 8; FF1 (N = 12288) 1244 / 1265 / 1278; QKV 1250 / 1295 / 1302; 16 loses everywhere.  (-DBYA_GEMM_GM=n pins it: the probe's builds.)
+#ifdef BYA_GEMM_GM
+        constexpr int GM = BYA_GEMM_GM;
+#else
+        const int GM = p.gm;
 #endif
-        constexpr int GM = BYA_GEMM_GM;            // group-M order: 4 row tiles sweep a column tile before moving on (A/B, round 3:
-                                                   // 2 gains 1.5 % on K = 12288 and loses 2-3 % on QKV / FF1; 8 the reverse; 16 loses)
         const int per_group = GM * tiles_n;
         const int group = idt / per_group, first_m = group * GM;
         const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
@@ -1179,8 +1183,13 @@ int bya_launch_conv256p(const void* args, hipStream_t s) {
 }
 
 // q|k|v projection with the q/k-norm + RoPE epilogue (bya_gemm_qkv_norm_rope): the QKN instance, never split
+// group-M width by shape: a long K sweep wants few row tiles per group (the W panel of a column tile is re-read by fewer row tiles,
+// but each stays in flight longer), wide outputs want more
+static int gemm_group_m(const GemmArgs& a) { return a.K >= 8192 ? 2 : (a.N >= 8192 ? 8 : 4); }
+
 int bya_launch_gemm256p_qkn(const void* args, int batch, hipStream_t s) {
-    const GemmArgs& a = *static_cast<const GemmArgs*>(args);
+    GemmArgs a = *static_cast<const GemmArgs*>(args);
+    a.gm = gemm_group_m(a);
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
     const long long total = (long long)tiles_m * tiles_n * batch;
     const int blocks = (int)(total < 256 ? (total + 7) / 8 * 8 : 256);
@@ -1198,7 +1207,8 @@ int bya_gemm_split_min_ktiles() {
 }
 
 int bya_launch_gemm256p(const void* args, int batch, hipStream_t s) {
-    const GemmArgs& a = *static_cast<const GemmArgs*>(args);
+    GemmArgs a = *static_cast<const GemmArgs*>(args);
+    a.gm = gemm_group_m(a);
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
     const long long total = (long long)tiles_m * tiles_n * batch;
     // split the last partial round along K when a workspace is registered (BYA_GEMM_SPLITK=0 switches it off, read per call)
