@@ -308,6 +308,9 @@ inline bool v4_eligible(const GemmArgs& a) {
         a.c_bs % 8 == 0 && a.res_bs % 8 == 0 && a.gate_bs % 8 == 0 && a.c_split_stride % 8 == 0;
 }
 
+// ... and the 128 x 256 persistent kernel (gemm_v5.hip) needs four K-tiles for its three-stage ring to run across tiles
+inline bool p128_eligible(const GemmArgs& a) { return v4_eligible(a) && a.K >= 4 * BK && a.conv_cpg_log2 < 0; }
+
 int launch256(const GemmArgs& a, int batch, hipStream_t s) {
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
     dim3 grid(tiles_m * tiles_n, 1, batch);
@@ -336,8 +339,25 @@ int launch(const GemmArgs& a, int batch, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
+// 128 x 256 tiles (gemm_v5.hip) or 256 x 256 (gemm_v4.hip)?  In units of one 256 x 256 tile's time on a CU: the rounds of the
+// 256-row grid (its last, partial round costs its fill fraction when it is cut along K) against rounds of half tiles at the
+// 128-row kernel's relative speed per unit of tile area.
+constexpr double P128_REL_SPEED = 0.80;     // measured on full grids (tools/gemm_p128_probe.py): the 128-row tile moves 1.5x the bytes per FLOP
+inline double rounds_128p(int M, int N, int batch) {
+    const long long t = (long long)((M + 127) / 128) * ((N + 255) / 256) * batch;
+    return 0.5 * (double)((t + 255) / 256) / P128_REL_SPEED;
+}
+inline bool prefer_128_rows(int M, int N, int K, int batch, bool splitk) {
+    const int forced = bya_opt(BYA_OPT_GEMM_TILE);
+    if (forced >= 0) return forced == 5;
+    (void)K;
+    const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
+    const double r256 = splitk ? (double)t256 / 256.0 + 0.12 : (double)((t256 + 255) / 256);
+    return rounds_128p(M, N, batch) < 0.97 * r256;
+}
+
 // Tile choice: fewest "CU rounds" (wave quantisation on 256 CUs) weighted by the tile's relative efficiency.
-inline int pick_tile(int M, int N, int K, int batch, int forced, int act, bool splitk) {
+inline int pick_tile(int M, int N, int K, int batch, int forced, int act, bool splitk, bool p128_ok) {
     if (forced >= 0) return (forced >= 4 && !act_on_big_tiles(act)) ? 1 : forced;
     if (N <= 64) return 0;
     auto rounds = [&](int bm, int bn, int per_cu) {
@@ -353,6 +373,8 @@ inline int pick_tile(int M, int N, int K, int batch, int forced, int act, bool s
     (void)t256x128;
     if (M < 1024 || N < 512 || K < 1024 || !act_on_big_tiles(act)) return 1;     // short K loops: the pipelined kernel's prologue/epilogue dominate
     // the pipelined 256x256 kernel is ~1.2x the 128x128 one per unit of tile area when its grid fills the CUs
+    const double best = t256 / 1.2 <= t128 ? t256 / 1.2 : t128;
+    if (p128_ok && rounds_128p(M, N, batch) * 65536.0 / 1.2 < 0.97 * best) return 5;
     return (t256 / 1.2 <= t128) ? 4 : 1;
 }
 
@@ -457,6 +479,7 @@ extern "C" int bya_gemm_qkv_norm_rope(const void* A, const void* W, const void* 
     a.qkn_cos = n->cos; a.qkn_sin = n->sin; a.qkn_text_rows = n->text_rows; a.qkn_width = n->width;
     a.qkn_eps = n->eps; a.qkn_kscale = n->k_scale == 0.0f ? 1.0f : n->k_scale;
     if (!v4_eligible(a) || !gemm_rows_reachable(a, a.M)) return BYA_ERR_UNSUPPORTED;
+    if (p128_eligible(a) && prefer_128_rows(a.M, a.N, a.K, d->batch, false)) return bya_launch_gemm128p_qkn(&a, d->batch, stream);
     return bya_launch_gemm256p_qkn(&a, d->batch, stream);
 }
 
@@ -587,11 +610,12 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
     const int forced = bya_opt(BYA_OPT_GEMM_TILE);              // tuning / test option
     const bool splitk = ws && bya_opt(BYA_OPT_GEMM_SPLITK) != 0 && a.K / BK >= 2 * bya_gemm_split_min_ktiles() && v4_eligible(a) &&
         !bya_opt(BYA_OPT_GEMM_VARIANT);
-    switch (pick_tile(d->M, d->N, d->K, d->batch, forced, d->act, splitk)) {
+    switch (pick_tile(d->M, d->N, d->K, d->batch, forced, d->act, splitk, p128_eligible(a))) {
         case 0: return launch<128, 64, 2, 2>(a, d->batch, stream);
         case 1: return launch<128, 128, 2, 2>(a, d->batch, stream);
         case 2: return launch<256, 128, 4, 2>(a, d->batch, stream);
         case 3: return launch<256, 256, 2, 4>(a, d->batch, stream);
+        case 5: if (p128_eligible(a)) return bya_launch_gemm128p(&a, d->batch, stream); break;     // (else: the 256 x 256 path below)
         default: break;
     }
     // Pipelined 256x256 tiles, one workgroup per CU.  When the last round of tiles would leave most CUs idle

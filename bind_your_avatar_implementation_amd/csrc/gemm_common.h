@@ -223,6 +223,11 @@ int gemm_row_chunks(const GemmArgs& a, int batch, int a_elem_bytes, F&& run) {
         }
     return BYA_OK;
 }
+// Persistent kernels: group-M width of the tile order, in 256-row tiles, by shape: a long K sweep wants few row tiles per group
+// (the W panel of a column tile is re-read by fewer row tiles, but each stays in flight longer), wide outputs want more
+// (same-box sweep: tools/gemm_gm_probe.py, profiles/r6_k_gemm_gm_probe.json)
+inline int gemm_group_m(const GemmArgs& a) { return a.K >= 8192 ? 2 : (a.N >= 8192 ? 8 : 4); }
+
 }  // namespace
 
 // defined in gemm_v4.hip (compiled with its own register-allocation flags: accumulators in AGPRs), called from
@@ -230,3 +235,7 @@ int gemm_row_chunks(const GemmArgs& a, int batch, int a_elem_bytes, F&& run) {
 int bya_launch_gemm256p(const void* args, int batch, hipStream_t stream);
 int bya_launch_gemm256p_qkn(const void* args, int batch, hipStream_t stream);    // ... its QKN instance (bya_gemm_qkv_norm_rope)
 int bya_gemm_split_min_ktiles();     // K-tiles per K-range below which the persistent kernel does not split a tile
+// defined in gemm_v5.hip: the persistent kernel with 128 x 256 tiles (three-stage ring) for row counts that leave the 256 x 256
+// grid half empty; callers have checked v4_eligible() and K >= 4 K-tiles
+int bya_launch_gemm128p(const void* args, int batch, hipStream_t stream);
+int bya_launch_gemm128p_qkn(const void* args, int batch, hipStream_t stream);

@@ -51,7 +51,7 @@ enum bya_option {
                                      workspace is registered; 0: never (strict summation order: a shard's rows round like the
                                      whole's); 2: every split tile in two */
     BYA_OPT_GEMM_SPLITK_MIN = 1,  /* shortest K range (in 64-wide K tiles) a split may produce; 0 = the built-in default */
-    BYA_OPT_GEMM_TILE = 2,        /* -1 (default): tile shape by the cost model; 0..4: force one (tests: every shape through
+    BYA_OPT_GEMM_TILE = 2,        /* -1 (default): tile shape by the cost model; 0..5: force one (tests: every shape through
                                      every kernel) */
     BYA_OPT_GEMM_VARIANT = 3,     /* 0 (default): the one-wave-per-SIMD 256 x 256 kernel where eligible; 1: the 8-wave kernel */
     BYA_OPT_ATTN_STREAMK = 4,     /* 1 (default): the joint attention cuts the items of a partial last round between

@@ -362,6 +362,52 @@ def test_gemm_pipelined_256(ops, dev, M, N, K):
     check(out, res.float() + F.gelu(a.float() @ w.float().T + b.float(), approximate="tanh"), what=f"gemm256 {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("B,M,N,K,epi", [(1, 2222, 3072, 3072, "gate+res"), (1, 2193, 2048, 2048, "bias"), (2, 700, 520, 256, "gelu+res"),
+                                         (1, 129, 264, 832, "plain"), (1, 2222, 768, 1024, "split"), (1, 130, 256, 192, "short-k")])
+def test_gemm_128_row_persistent_tile_equals_the_256_row_one(ops, dev, B, M, N, K, epi):
+    """The 128 x 256 persistent kernel (gemm_v5.hip: three-stage ring that runs across output tiles, one barrier per K-tile) is
+    the 256 x 256 one's twin for row counts that leave its grid half empty -- a rank's 2222 rows of the 8-way sharded step.  Same
+    K order, same epilogue code (gemm_wide_epilogue.h), so FORCED on a shape (option gemm_tile = 5) it must equal the forced
+    256-row kernel (gemm_tile = 4) BIT FOR BIT and sit within the fp32 reference's tolerance: ragged M and N tiles (129 rows = a
+    second, one-row tile; 264 = a column tile of eight columns), a batch, gates + residual in place, GELU, split outputs, several
+    tiles per workgroup (2222 x 3072 is 216 tiles; 700 x 520 x 2 is 36), and K of three K-tiles (below the ring's minimum of four:
+    the 256-row path must take it).  The library's own choice picks the 128-row tile for the first two shapes."""
+    a = rnd((B, M, K), dev, 41)
+    w, b = rnd((N, K), dev, 42, K ** -0.5), rnd((N,), dev, 43, 0.3)
+    x = rnd((B, M, N), dev, 44)
+    mods = rnd((B, 2, N), dev, 45, 0.5)
+    outs = {}
+    for tile in (4, 5, -1):
+        with ops.options(gemm_tile=tile, gemm_splitk=0):
+            if epi == "gate+res":
+                o = x.clone()
+                ops.gemm(a, w, o, bias=b, res=o, gate0=mods[:, 0], gate1=mods[:, 1], gate_split=226, gate_batch_stride=mods.stride(0))
+            elif epi == "gelu+res":
+                o = torch.empty_like(x)
+                ops.gemm(a, w, o, bias=b, res=x, act="gelu_tanh")
+            elif epi == "split":
+                o = torch.zeros(3, B, M, N // 3, dtype=torch.bfloat16, device=dev)
+                ops.gemm(a, w, o[0], bias=b, split=(N // 3, B * M * (N // 3)))
+            else:
+                o = torch.empty_like(x)
+                ops.gemm(a, w, o, bias=b if epi != "plain" else None)
+        outs[tile] = o
+    torch.cuda.synchronize()
+    assert torch.equal(outs[5], outs[4]), int((outs[5] != outs[4]).sum())
+    assert torch.equal(outs[-1], outs[4])
+    y = a.float() @ w.float().T + (b.float() if epi != "plain" else 0.0)
+    if epi == "gate+res":
+        gate = torch.cat([mods[:, 0:1].float().expand(-1, 226, -1), mods[:, 1:2].float().expand(-1, M - 226, -1)], 1)
+        ref = x.float() + gate * y
+    elif epi == "gelu+res":
+        ref = x.float() + F.gelu(y, approximate="tanh")
+    elif epi == "split":
+        ref = torch.stack([y[..., i * (N // 3):(i + 1) * (N // 3)] for i in range(3)])
+    else:
+        ref = y
+    check(outs[5], ref, what=f"gemm 128-row tile {M}x{N}x{K} {epi}")
+
+
 @pytest.mark.parametrize("gate_split", [226, 16500])
 def test_gemm_quantisation_tail_split(ops, dev, gate_split):
     """17776 x 3072 is 3.28 rounds of 256x256 tiles: rows [0, 16384) run on the pipelined kernel and the last 1392
@@ -928,6 +974,12 @@ def test_qkv_projection_with_the_norm_in_its_epilogue_is_bit_identical(ops, dev,
     assert torch.equal(one, two), (float((one.float() - two.float()).abs().max()),
                                    int((one != two).sum()), [int((one[t] != two[t]).sum()) for t in range(3 * blocks)])
     assert float(one[:2 * blocks].float().abs().sum()) > 0
+    # ... on either persistent tile: 256 x 256 (gemm_v4.hip) and 128 x 256 (gemm_v5.hip; the library's choice at 2222 rows)
+    for tile in (4, 5):
+        forced = outputs()
+        with ops.options(gemm_tile=tile):
+            assert ops.gemm_qkv_norm_rope(x, w, forced[0], bias, (Dl, B * M * Dl), qw, qb, kw, kb, cos, sin, text, eps=1e-6, k_scale=0.18)
+        assert torch.equal(forced, two), (tile, int((forced != two).sum()))
 
 
 def test_qknorm_rope_statistics_bound_every_row(ops, dev):
