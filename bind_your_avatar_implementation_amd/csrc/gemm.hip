@@ -633,7 +633,15 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
             // in pipelined-kernel rounds.  0.9 since round 5 (0.6 before): same-process sweeps (profiles/history/r5_d_gemm_sweep_*.json)
             // have the unsplit persistent kernel ahead of the row split wherever 0.6 chose it -- 2222 x 9216 x 3072: 1078 vs 960
             // TFLOP/s, 4444 x 9216: 1334 vs 1217, 17776 x 3072 x 3072: 1248 vs 1230 -- so the split now needs a clear win
-            const double tail_cost = 0.9 * (double)((tail_blocks + 511) / 512);
+            double tail_cost = 0.9 * (double)((tail_blocks + 511) / 512);
+            // (r6) ... or to the 128 x 256 persistent kernel: one round of half tiles (17776 x 3072: the 1392 rows behind three
+            // full rounds are 132 of them) plus the second launch
+#ifdef BYA_GEMM_NO_P128_TAIL            // (the A/B build of tools/gemm_tail_probe.py)
+            const bool tail_128p = false;
+#else
+            const bool tail_128p = p128_eligible(a) && act_on_big_tiles(a.act) && rounds_128p(a.M - m0, a.N, 1) + 0.05 < tail_cost;
+#endif
+            if (tail_128p) tail_cost = rounds_128p(a.M - m0, a.N, 1) + 0.05;
             const double main_cost = (double)(((long long)main_tm * tn + 255) / 256);
             if (main_cost + tail_cost < (double)((tiles + 255) / 256) - 0.15) {
                 GemmArgs lo = a, hi = a;
@@ -646,7 +654,7 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
                 hi.gate_split = a.gate_split > m0 ? a.gate_split - m0 : 0;
                 const int rc = launch256(lo, 1, stream);
                 if (rc != BYA_OK) return rc;
-                return launch<128, 128, 2, 2>(hi, 1, stream);
+                return tail_128p ? bya_launch_gemm128p(&hi, 1, stream) : launch<128, 128, 2, 2>(hi, 1, stream);
             }
         }
     }
