@@ -582,8 +582,8 @@ def main():
                 # FIXED NAMES, every round: `frac` / `achieved` = every Linear of the step (the definition of rounds 1-3, and of
                 # round 4's `all_linears_frac`); `token_stream_frac` = the Linears with >= 1024 rows only (round 4's `frac`): the
                 # step-invariant conditioning's small-row Linears stream their weights and are HBM-bound, not MFMA-bound
-                gemm_roof = {"kernel": "bya_gemm_bf16, every Linear of the step (gemm256p_kernel 256x256 tiles + the 128x128 kernel for "
-                                       "tail rows; the conditioning's Linears with < 1024 rows against 2048..49152-wide weights -- "
+                gemm_roof = {"kernel": "bya_gemm_bf16, every Linear of the step (gemm256p_kernel 256x256 tiles + gemm128p_kernel 128x256 tiles "
+                                       "for the rows behind the last full round; the conditioning's Linears with < 1024 rows against 2048..49152-wide weights -- "
                                        "weight-streaming, HBM-bound -- are counted in `frac` and listed in `small_m_linears`; "
                                        "`token_stream_frac` leaves them out; `traffic` is gemm256p_kernel's, per launch of that kernel)",
                              "small_m_linears": {"launches": len(small), "ms_per_step": sum(small) / args.steps * 1e3,

@@ -119,7 +119,7 @@ ENV_OPTIONS = {
     "BYA_GEMM_SPLITK": ("gemm_splitk", int),
     "BYA_GEMM_SPLITK_MIN": ("gemm_splitk_min", int),
     "BYA_GEMM_TILE": ("gemm_tile", int),
-    "BYA_GEMM_VARIANT": ("gemm_variant", lambda v: 1 if v == "w8" else 0),
+    "BYA_GEMM_VARIANT": ("gemm_variant", lambda v: {"w8": 1, "no128": 2}.get(v, 0)),
     "BYA_ATTN_STREAMK": ("attn_streamk", int),
     "BYA_FP8_KERNEL": ("fp8_kernel", lambda v: 1 if v.startswith("1") else 0),
     "BYA_P2P_GROUPS": ("p2p_groups", int),

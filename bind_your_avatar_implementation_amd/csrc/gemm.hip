@@ -309,7 +309,7 @@ inline bool v4_eligible(const GemmArgs& a) {
 }
 
 // ... and the 128 x 256 persistent kernel (gemm_v5.hip) needs four K-tiles for its three-stage ring to run across tiles
-inline bool p128_eligible(const GemmArgs& a) { return v4_eligible(a) && a.K >= 4 * BK && a.conv_cpg_log2 < 0; }
+inline bool p128_eligible(const GemmArgs& a) { return v4_eligible(a) && a.K >= 4 * BK && a.conv_cpg_log2 < 0 && bya_opt(BYA_OPT_GEMM_VARIANT) == 0; }
 
 int launch256(const GemmArgs& a, int batch, hipStream_t s) {
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
@@ -322,7 +322,7 @@ int launch256(const GemmArgs& a, int batch, hipStream_t s) {
     // BYA_GEMM_VARIANT (read per call so one process can A/B them, tools/gemm_probe.py): "w8" = this file's 8-wave
     // kernel (the fallback), anything else = gemm_v4.hip.
     const bool v4_ok = v4_eligible(a);
-    if (v4_ok && !bya_opt(BYA_OPT_GEMM_VARIANT)) return bya_launch_gemm256p(&a, batch, s);
+    if (v4_ok && bya_opt(BYA_OPT_GEMM_VARIANT) != 1) return bya_launch_gemm256p(&a, batch, s);
     BYA_LAUNCH(gemm256_kernel, grid, dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
@@ -609,7 +609,7 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
     const auto* d = &dd;
     const int forced = bya_opt(BYA_OPT_GEMM_TILE);              // tuning / test option
     const bool splitk = ws && bya_opt(BYA_OPT_GEMM_SPLITK) != 0 && a.K / BK >= 2 * bya_gemm_split_min_ktiles() && v4_eligible(a) &&
-        !bya_opt(BYA_OPT_GEMM_VARIANT);
+        bya_opt(BYA_OPT_GEMM_VARIANT) != 1;
     switch (pick_tile(d->M, d->N, d->K, d->batch, forced, d->act, splitk, p128_eligible(a))) {
         case 0: return launch<128, 64, 2, 2>(a, d->batch, stream);
         case 1: return launch<128, 128, 2, 2>(a, d->batch, stream);

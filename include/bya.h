@@ -53,7 +53,8 @@ enum bya_option {
     BYA_OPT_GEMM_SPLITK_MIN = 1,  /* shortest K range (in 64-wide K tiles) a split may produce; 0 = the built-in default */
     BYA_OPT_GEMM_TILE = 2,        /* -1 (default): tile shape by the cost model; 0..5: force one (tests: every shape through
                                      every kernel) */
-    BYA_OPT_GEMM_VARIANT = 3,     /* 0 (default): the one-wave-per-SIMD 256 x 256 kernel where eligible; 1: the 8-wave kernel */
+    BYA_OPT_GEMM_VARIANT = 3,     /* 0 (default): the one-wave-per-SIMD kernels (256 x 256 tiles, 128 x 256 where that fills the CUs
+                                     better) where eligible; 1: the 8-wave kernel; 2: 256 x 256 only (A/B of the 128-row tile) */
     BYA_OPT_ATTN_STREAMK = 4,     /* 1 (default): the joint attention cuts the items of a partial last round between
                                      workgroups when a workspace is registered; 0: one workgroup per item */
     BYA_OPT_FP8_KERNEL = 5,       /* 0 (default): 256 x 256 fp8 kernel where a launch fills it; 1: always the 128 x 128 one */
