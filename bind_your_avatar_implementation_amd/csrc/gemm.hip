@@ -347,13 +347,29 @@ inline double rounds_128p(int M, int N, int batch) {
     const long long t = (long long)((M + 127) / 128) * ((N + 255) / 256) * batch;
     return 0.5 * (double)((t + 255) / 256) / P128_REL_SPEED;
 }
-inline bool prefer_128_rows(int M, int N, int K, int batch, bool splitk) {
+// Rows [0, m0) on 256 x 256 tiles and rows [m0, M) on 128 x 256 tiles as a second launch: m0 = the rows of the full rounds of
+// 256-row tiles (2222 x 9216: seven row tiles = 252 tiles, then 430 rows = 144 half tiles; all-128-row would be three rounds of
+// half tiles, all-256-row two whole rounds).  0 = no such split; its cost in *cost.
+inline int hybrid_rows(int M, int N, int batch, double* cost) {
+    const long long tn = (N + 255) / 256, tiles = (long long)((M + 255) / 256) * tn, full = tiles / 256;
+    if (batch != 1 || full < 1 || tiles % 256 == 0) return 0;
+    const int main_tm = (int)(full * 256 / tn), m0 = main_tm * 256;
+    if (m0 <= 0 || m0 >= M) return 0;
+    *cost = (double)(((long long)main_tm * tn + 255) / 256) + rounds_128p(M - m0, N, 1) + 0.05;        // (+ the second launch)
+    return m0;
+}
+// 0: 256-row tiles, 1: 128-row tiles, 2: both (rows split at *m0)
+inline int plan_rows(int M, int N, int batch, bool splitk, int* m0) {
     const int forced = bya_opt(BYA_OPT_GEMM_TILE);
-    if (forced >= 0) return forced == 5;
-    (void)K;
+    if (forced >= 0) return forced == 5 ? 1 : 0;
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
     const double r256 = splitk ? (double)t256 / 256.0 + 0.12 : (double)((t256 + 255) / 256);
-    return rounds_128p(M, N, batch) < 0.97 * r256;
+    double best = r256, hc = 0.0;
+    int plan = 0;
+    if (rounds_128p(M, N, batch) < 0.97 * best) { best = rounds_128p(M, N, batch); plan = 1; }
+    const int hm = splitk ? 0 : hybrid_rows(M, N, batch, &hc);
+    if (hm > 0 && hc < (plan == 0 ? r256 - 0.15 : 0.97 * best)) { *m0 = hm; plan = 2; }
+    return plan;
 }
 
 // Tile choice: fewest "CU rounds" (wave quantisation on 256 CUs) weighted by the tile's relative efficiency.
@@ -374,7 +390,11 @@ inline int pick_tile(int M, int N, int K, int batch, int forced, int act, bool s
     if (M < 1024 || N < 512 || K < 1024 || !act_on_big_tiles(act)) return 1;     // short K loops: the pipelined kernel's prologue/epilogue dominate
     // the pipelined 256x256 kernel is ~1.2x the 128x128 one per unit of tile area when its grid fills the CUs
     const double best = t256 / 1.2 <= t128 ? t256 / 1.2 : t128;
-    if (p128_ok && rounds_128p(M, N, batch) * 65536.0 / 1.2 < 0.97 * best) return 5;
+    if (p128_ok && rounds_128p(M, N, batch) * 65536.0 / 1.2 < 0.97 * best) {
+        double hc = 0.0;              // (4: dispatch_gemm's row split sends the rows behind the full rounds to the 128-row tile)
+        if (!splitk && hybrid_rows(M, N, batch, &hc) > 0 && hc < 0.97 * rounds_128p(M, N, batch) && t256 / 1.2 <= t128) return 4;
+        return 5;
+    }
     return (t256 / 1.2 <= t128) ? 4 : 1;
 }
 
@@ -479,7 +499,24 @@ extern "C" int bya_gemm_qkv_norm_rope(const void* A, const void* W, const void* 
     a.qkn_cos = n->cos; a.qkn_sin = n->sin; a.qkn_text_rows = n->text_rows; a.qkn_width = n->width;
     a.qkn_eps = n->eps; a.qkn_kscale = n->k_scale == 0.0f ? 1.0f : n->k_scale;
     if (!v4_eligible(a) || !gemm_rows_reachable(a, a.M)) return BYA_ERR_UNSUPPORTED;
-    if (p128_eligible(a) && prefer_128_rows(a.M, a.N, a.K, d->batch, false)) return bya_launch_gemm128p_qkn(&a, d->batch, stream);
+    int m0 = 0;
+    const int plan = p128_eligible(a) ? plan_rows(a.M, a.N, d->batch, false, &m0) : 0;
+    if (plan == 1) return bya_launch_gemm128p_qkn(&a, d->batch, stream);
+    if (plan == 2) {                                             // rows [0, m0): 256-row tiles; the rest: 128-row tiles
+        GemmArgs lo = a, hi = a;
+        lo.M = m0;
+        hi.M = a.M - m0;
+        hi.A += (long long)m0 * a.lda;
+        hi.C += (long long)m0 * a.ldc;
+        // the rotary table's row of token m is m - text_rows: the second launch's token 0 is token m0
+        hi.qkn_text_rows = a.qkn_text_rows > m0 ? a.qkn_text_rows - m0 : 0;
+        if (a.qkn_cos && m0 > a.qkn_text_rows) {
+            hi.qkn_cos = a.qkn_cos + (long long)(m0 - a.qkn_text_rows) * 64;
+            hi.qkn_sin = a.qkn_sin + (long long)(m0 - a.qkn_text_rows) * 64;
+        }
+        const int rc = bya_launch_gemm256p_qkn(&lo, 1, stream);
+        return rc != BYA_OK ? rc : bya_launch_gemm128p_qkn(&hi, 1, stream);
+    }
     return bya_launch_gemm256p_qkn(&a, d->batch, stream);
 }
 
