@@ -23,7 +23,7 @@
 #include "options.h"
 
 // timing-only ablation builds (tools/gemm_p128_ablate.py; never the shipped library): 1 no epilogue, 2 no LDS-DMA inside the
-// K-loop, 4 no barriers inside the K-loop, 8 no fragment reads inside the K-loop
+// K-loop, 4 no barriers inside the K-loop, 8 no fragment reads inside the K-loop, 16 every K-tile re-reads K-tile 0 (every request an L2 hit)
 #ifndef BYA_GEMM5_ABLATE
 #define BYA_GEMM5_ABLATE 0
 #endif
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void gemm128p_kernel(GemmArgs p, int tiles_
 #if BYA_GEMM5_ABLATE & 2
 #define DP(Q) do { (void)dA; (void)dW; (void)soff; } while (0)
 #else
-#define DP(Q) do { if constexpr ((Q) < 4) DMA_A((Q) & 3, fillA, dA, soff); else DMA_W(((Q) - 4) & 7, fillW, dW, soff); } while (0)
+#define DP(Q) do { if constexpr ((Q) < 4) DMA_A((Q) & 3, fillA, dA, (BYA_GEMM5_ABLATE & 16) ? 0u : soff); else DMA_W(((Q) - 4) & 7, fillW, dW, (BYA_GEMM5_ABLATE & 16) ? 0u : soff); } while (0)
 #endif
             // A: K-tile 1 was waited for in front of the previous epilogue (or by the prologue); B: all but the 12 pieces of
             // K-tile t + 2 -- requested during K-tile t - 1 -- have landed, i.e. K-tile t + 1 has
