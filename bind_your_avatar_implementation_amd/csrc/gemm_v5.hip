@@ -23,7 +23,8 @@
 #include "options.h"
 
 // timing-only ablation builds (tools/gemm_p128_ablate.py; never the shipped library): 1 no epilogue, 2 no LDS-DMA inside the
-// K-loop, 4 no barriers inside the K-loop, 8 no fragment reads inside the K-loop, 16 every K-tile re-reads K-tile 0 (every request an L2 hit)
+// K-loop, 4 no barriers inside the K-loop, 8 no fragment reads inside the K-loop, 16 every K-tile re-reads K-tile 0 (every request an L2 hit),
+// 32 / 64 no A / no W pieces inside the K-loop (the vmcnt waits then wait for less: timing only)
 #ifndef BYA_GEMM5_ABLATE
 #define BYA_GEMM5_ABLATE 0
 #endif
@@ -152,7 +153,10 @@ __global__ __launch_bounds__(256, 1) void gemm128p_kernel(GemmArgs p, int tiles_
 #if BYA_GEMM5_ABLATE & 2
 #define DP(Q) do { (void)dA; (void)dW; (void)soff; } while (0)
 #else
-#define DP(Q) do { if constexpr ((Q) < 4) DMA_A((Q) & 3, fillA, dA, (BYA_GEMM5_ABLATE & 16) ? 0u : soff); else DMA_W(((Q) - 4) & 7, fillW, dW, (BYA_GEMM5_ABLATE & 16) ? 0u : soff); } while (0)
+#define DP(Q) do { \
+                if constexpr ((Q) < 4) { if (!(BYA_GEMM5_ABLATE & 32)) DMA_A((Q) & 3, fillA, dA, (BYA_GEMM5_ABLATE & 16) ? 0u : soff); } \
+                else if (!(BYA_GEMM5_ABLATE & 64)) DMA_W(((Q) - 4) & 7, fillW, dW, (BYA_GEMM5_ABLATE & 16) ? 0u : soff); \
+            } while (0)
 #endif
             // A: K-tile 1 was waited for in front of the previous epilogue (or by the prologue); B: all but the 12 pieces of
             // K-tile t + 2 -- requested during K-tile t - 1 -- have landed, i.e. K-tile t + 1 has
@@ -161,7 +165,13 @@ __global__ __launch_bounds__(256, 1) void gemm128p_kernel(GemmArgs p, int tiles_
 #define SYNC_B() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(12)" ::: "memory")
 #else
 #define SYNC_A() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#if BYA_GEMM5_ABLATE & 32
+#define SYNC_B() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory")
+#elif BYA_GEMM5_ABLATE & 64
+#define SYNC_B() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory")
+#else
 #define SYNC_B() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory")
+#endif
 #endif
 #define NEXT() do { \
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \

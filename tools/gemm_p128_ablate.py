@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "bind_your_avatar_implementation_amd")
 OUT = os.path.join(PKG, "build", "ablate")
 VARIANTS = {"full": 0, "no_epilogue": 1, "no_dma": 2, "no_barrier": 4, "no_frag_reads": 8, "no_dma_no_barrier": 6, "mfma_only": 15,
-            "no_epilogue_no_dma": 3, "all_l2_hits": 16}
+            "no_epilogue_no_dma": 3, "all_l2_hits": 16, "w_pieces_only": 32, "a_pieces_only": 64}
 
 
 def build():
