@@ -11,7 +11,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libbya_hip.so")
-SOURCES = ["gemm.hip", "gemm_v4.hip", "gemm_v5.hip", "gemm_fp8.hip", "gemm_fp8_v4.hip", "attn.hip", "attn_w4.hip", "norm.hip", "misc.hip", "router.hip", "rowgemm.hip", "rowchain.hip", "comm.hip", "vae.hip", "calib.hip"]
+SOURCES = ["gemm.hip", "gemm_v4.hip", "gemm_v5.hip", "gemm_v6.hip", "gemm_fp8.hip", "gemm_fp8_v4.hip", "attn.hip", "attn_w4.hip", "norm.hip", "misc.hip", "router.hip", "rowgemm.hip", "rowchain.hip", "comm.hip", "vae.hip", "calib.hip"]
 # VALU-only kernels are built WITHOUT the SLP vectoriser, i.e. without packed-fp32 (v_pk_mul/fma/mov_f32) instructions:
 # with them the q/k-norm + RoPE kernel returned wrong values in lanes 48..63 of some waves whenever ANOTHER PROCESS kept
 # MFMA-heavy workgroups resident on the same CUs (19-20 of 20 runs; 0 of 20 for the same source built with
@@ -19,7 +19,7 @@ SOURCES = ["gemm.hip", "gemm_v4.hip", "gemm_v5.hip", "gemm_fp8.hip", "gemm_fp8_v
 # kernels are HBM-bound, the packed forms bought nothing.
 NO_SLP_SOURCES = {"norm.hip", "misc.hip", "router.hip", "gemm_fp8.hip", "vae.hip", "rowgemm.hip", "rowchain.hip"}     # (gemm_fp8: its row quantiser)
 # translation units whose kernels keep their accumulators in AGPRs (one wave per SIMD, 512 registers)
-AGPR_SOURCES = {"gemm_v4.hip", "gemm_v5.hip", "gemm_fp8_v4.hip", "attn_w4.hip", "calib.hip"}
+AGPR_SOURCES = {"gemm_v4.hip", "gemm_v5.hip", "gemm_v6.hip", "gemm_fp8_v4.hip", "attn_w4.hip", "calib.hip"}
 
 
 def _hipcc():

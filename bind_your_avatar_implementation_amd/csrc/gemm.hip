@@ -339,35 +339,48 @@ int launch(const GemmArgs& a, int batch, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? BYA_OK : BYA_ERR_LAUNCH;
 }
 
-// 128 x 256 tiles (gemm_v5.hip) or 256 x 256 (gemm_v4.hip)?  In units of one 256 x 256 tile's time on a CU: the rounds of the
-// 256-row grid (its last, partial round costs its fill fraction when it is cut along K) against rounds of half tiles at the
-// 128-row kernel's relative speed per unit of tile area.
-constexpr double P128_REL_SPEED = 0.80;     // measured on full grids (tools/gemm_p128_probe.py): the 128-row tile moves 1.5x the bytes per FLOP
-inline double rounds_128p(int M, int N, int batch) {
+// 128 x 256 tiles or 256 x 256 (gemm_v4.hip)?  In units of one 256 x 256 tile's time on a CU: the rounds of the 256-row grid
+// against rounds of half tiles at the 128-row kernel's relative speed per unit of tile area -- measured on full grids
+// (tools/gemm_p128_probe.py): 0.85 with loader waves (gemm_v6.hip: every plain Linear), 0.80 without (gemm_v5.hip: the q|k|v
+// projection with the norm epilogue, which does not fit 128 arch registers); the 128-row tile moves 1.5x the bytes per FLOP.
+constexpr double REL_128S = 0.85, REL_128P = 0.80;
+inline double rounds_128(int M, int N, int batch, double rel) {
     const long long t = (long long)((M + 127) / 128) * ((N + 255) / 256) * batch;
-    return 0.5 * (double)((t + 255) / 256) / P128_REL_SPEED;
+    return 0.5 * (double)((t + 255) / 256) / rel;
+}
+// ... the 256-row grid's cost when its last, partial round is cut along K (gemm_v4.hip): an XCD's R left-over tiles in
+// p = min(32 / R, K-tiles / shortest range) K-ranges each, plus the slab exchange -- 0.3 of a tile's time measured where it is
+// a large part of the launch (2222 x 3072 x 12288: 108 tiles in two ranges each run at 0.87 of an unsplit tile's time)
+inline double rounds_256_split(int M, int N, int K, int batch) {
+    const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch, full = tiles / 256, rem = tiles % 256;
+    if (rem == 0) return (double)full;
+    const int R = (int)((rem + 7) / 8);
+    int parts = 32 / R;
+    const int by_k = (K / BK) / bya_gemm_split_min_ktiles();
+    if (parts > by_k) parts = by_k;
+    return (double)full + (parts > 1 ? 1.0 / parts + 0.3 : 1.0);
 }
 // Rows [0, m0) on 256 x 256 tiles and rows [m0, M) on 128 x 256 tiles as a second launch: m0 = the rows of the full rounds of
 // 256-row tiles (2222 x 9216: seven row tiles = 252 tiles, then 430 rows = 144 half tiles; all-128-row would be three rounds of
 // half tiles, all-256-row two whole rounds).  0 = no such split; its cost in *cost.
-inline int hybrid_rows(int M, int N, int batch, double* cost) {
+inline int hybrid_rows(int M, int N, int batch, double rel, double* cost) {
     const long long tn = (N + 255) / 256, tiles = (long long)((M + 255) / 256) * tn, full = tiles / 256;
     if (batch != 1 || full < 1 || tiles % 256 == 0) return 0;
     const int main_tm = (int)(full * 256 / tn), m0 = main_tm * 256;
     if (m0 <= 0 || m0 >= M) return 0;
-    *cost = (double)(((long long)main_tm * tn + 255) / 256) + rounds_128p(M - m0, N, 1) + 0.05;        // (+ the second launch)
+    *cost = (double)(((long long)main_tm * tn + 255) / 256) + rounds_128(M - m0, N, 1, rel) + 0.05;        // (+ the second launch)
     return m0;
 }
-// 0: 256-row tiles, 1: 128-row tiles, 2: both (rows split at *m0)
-inline int plan_rows(int M, int N, int batch, bool splitk, int* m0) {
+// The q|k|v projection with the norm epilogue (never cut along K).  0: 256-row tiles, 1: 128-row tiles, 2: both (rows split at *m0)
+inline int plan_rows_qkn(int M, int N, int batch, int* m0) {
     const int forced = bya_opt(BYA_OPT_GEMM_TILE);
-    if (forced >= 0) return forced == 5 ? 1 : 0;
+    if (forced >= 0) return forced == 5 || forced == 6 ? 1 : 0;
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
-    const double r256 = splitk ? (double)t256 / 256.0 + 0.12 : (double)((t256 + 255) / 256);
+    const double r256 = (double)((t256 + 255) / 256), r128 = rounds_128(M, N, batch, REL_128P);
     double best = r256, hc = 0.0;
     int plan = 0;
-    if (rounds_128p(M, N, batch) < 0.97 * best) { best = rounds_128p(M, N, batch); plan = 1; }
-    const int hm = splitk ? 0 : hybrid_rows(M, N, batch, &hc);
+    if (r128 < 0.97 * best) { best = r128; plan = 1; }
+    const int hm = hybrid_rows(M, N, batch, REL_128P, &hc);
     if (hm > 0 && hc < (plan == 0 ? r256 - 0.15 : 0.97 * best)) { *m0 = hm; plan = 2; }
     return plan;
 }
@@ -389,11 +402,15 @@ inline int pick_tile(int M, int N, int K, int batch, int forced, int act, bool s
     (void)t256x128;
     if (M < 1024 || N < 512 || K < 1024 || !act_on_big_tiles(act)) return 1;     // short K loops: the pipelined kernel's prologue/epilogue dominate
     // the pipelined 256x256 kernel is ~1.2x the 128x128 one per unit of tile area when its grid fills the CUs
-    const double best = t256 / 1.2 <= t128 ? t256 / 1.2 : t128;
-    if (p128_ok && rounds_128p(M, N, batch) * 65536.0 / 1.2 < 0.97 * best) {
-        double hc = 0.0;              // (4: dispatch_gemm's row split sends the rows behind the full rounds to the 128-row tile)
-        if (!splitk && hybrid_rows(M, N, batch, &hc) > 0 && hc < 0.97 * rounds_128p(M, N, batch) && t256 / 1.2 <= t128) return 4;
-        return 5;
+    if (p128_ok) {
+        // 6: the 128 x 256 persistent kernel with loader waves (gemm_v6.hip), against what a cut last round really costs
+        const double t256s = (splitk ? rounds_256_split(M, N, K, batch) * 65536.0 : t256) / 1.2;
+        const double best = t256s <= t128 ? t256s : t128, r128 = rounds_128(M, N, batch, REL_128S);
+        if (r128 * 65536.0 / 1.2 < 0.97 * best) {
+            double hc = 0.0;          // (4: dispatch_gemm's row split sends the rows behind the full rounds to the 128-row tile)
+            if (!splitk && hybrid_rows(M, N, batch, REL_128S, &hc) > 0 && hc < 0.97 * r128 && t256 / 1.2 <= t128) return 4;
+            return 6;
+        }
     }
     return (t256 / 1.2 <= t128) ? 4 : 1;
 }
@@ -500,7 +517,7 @@ extern "C" int bya_gemm_qkv_norm_rope(const void* A, const void* W, const void* 
     a.qkn_eps = n->eps; a.qkn_kscale = n->k_scale == 0.0f ? 1.0f : n->k_scale;
     if (!v4_eligible(a) || !gemm_rows_reachable(a, a.M)) return BYA_ERR_UNSUPPORTED;
     int m0 = 0;
-    const int plan = p128_eligible(a) ? plan_rows(a.M, a.N, d->batch, false, &m0) : 0;
+    const int plan = p128_eligible(a) ? plan_rows_qkn(a.M, a.N, d->batch, &m0) : 0;
     if (plan == 1) return bya_launch_gemm128p_qkn(&a, d->batch, stream);
     if (plan == 2) {                                             // rows [0, m0): 256-row tiles; the rest: 128-row tiles
         GemmArgs lo = a, hi = a;
@@ -652,7 +669,8 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
         case 1: return launch<128, 128, 2, 2>(a, d->batch, stream);
         case 2: return launch<256, 128, 4, 2>(a, d->batch, stream);
         case 3: return launch<256, 256, 2, 4>(a, d->batch, stream);
-        case 5: if (p128_eligible(a)) return bya_launch_gemm128p(&a, d->batch, stream); break;     // (else: the 256 x 256 path below)
+        case 5: if (p128_eligible(a)) return bya_launch_gemm128p(&a, d->batch, stream); break;     // (forced only; else: the 256 x 256 path below)
+        case 6: if (p128_eligible(a)) return bya_launch_gemm128s(&a, d->batch, stream); break;
         default: break;
     }
     // Pipelined 256x256 tiles, one workgroup per CU.  When the last round of tiles would leave most CUs idle
@@ -676,9 +694,9 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
 #ifdef BYA_GEMM_NO_P128_TAIL            // (the A/B build of tools/gemm_tail_probe.py)
             const bool tail_128p = false;
 #else
-            const bool tail_128p = p128_eligible(a) && act_on_big_tiles(a.act) && rounds_128p(a.M - m0, a.N, 1) + 0.05 < tail_cost;
+            const bool tail_128p = p128_eligible(a) && act_on_big_tiles(a.act) && rounds_128(a.M - m0, a.N, 1, REL_128S) + 0.05 < tail_cost;
 #endif
-            if (tail_128p) tail_cost = rounds_128p(a.M - m0, a.N, 1) + 0.05;
+            if (tail_128p) tail_cost = rounds_128(a.M - m0, a.N, 1, REL_128S) + 0.05;
             const double main_cost = (double)(((long long)main_tm * tn + 255) / 256);
             if (main_cost + tail_cost < (double)((tiles + 255) / 256) - 0.15) {
                 GemmArgs lo = a, hi = a;
@@ -691,7 +709,7 @@ int dispatch_gemm(const GemmArgs& a, int nbatch, hipStream_t stream) {
                 hi.gate_split = a.gate_split > m0 ? a.gate_split - m0 : 0;
                 const int rc = launch256(lo, 1, stream);
                 if (rc != BYA_OK) return rc;
-                return tail_128p ? bya_launch_gemm128p(&hi, 1, stream) : launch<128, 128, 2, 2>(hi, 1, stream);
+                return tail_128p ? bya_launch_gemm128s(&hi, 1, stream) : launch<128, 128, 2, 2>(hi, 1, stream);
             }
         }
     }

@@ -239,3 +239,5 @@ int bya_gemm_split_min_ktiles();     // K-tiles per K-range below which the pers
 // grid half empty; callers have checked v4_eligible() and K >= 4 K-tiles
 int bya_launch_gemm128p(const void* args, int batch, hipStream_t stream);
 int bya_launch_gemm128p_qkn(const void* args, int batch, hipStream_t stream);
+// defined in gemm_v6.hip: the same tile with loader waves (the compute waves issue no vector-memory instruction in the K-loop)
+int bya_launch_gemm128s(const void* args, int batch, hipStream_t stream);

@@ -344,7 +344,7 @@ std::atomic<int32_t> g_bya_options[BYA_OPT_COUNT] = {
 
 extern "C" int bya_set_option(int32_t key, int32_t value) {
     static const int32_t lo[BYA_OPT_COUNT] = {0, 0, -1, 0, 0, 0, 0, 0};
-    static const int32_t hi[BYA_OPT_COUNT] = {2, 1 << 20, 5, 2, 1, 1, 1024, 31};
+    static const int32_t hi[BYA_OPT_COUNT] = {2, 1 << 20, 6, 2, 1, 1, 1024, 31};
     if (key < 0 || key >= BYA_OPT_COUNT || value < lo[key] || value > hi[key]) return BYA_ERR_SHAPE;
     if (key == BYA_OPT_P2P_GROUPS && value != 0 && value < 16) return BYA_ERR_SHAPE;
     g_bya_options[key].store(value, std::memory_order_relaxed);

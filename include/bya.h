@@ -51,7 +51,7 @@ enum bya_option {
                                      workspace is registered; 0: never (strict summation order: a shard's rows round like the
                                      whole's); 2: every split tile in two */
     BYA_OPT_GEMM_SPLITK_MIN = 1,  /* shortest K range (in 64-wide K tiles) a split may produce; 0 = the built-in default */
-    BYA_OPT_GEMM_TILE = 2,        /* -1 (default): tile shape by the cost model; 0..5: force one (tests: every shape through
+    BYA_OPT_GEMM_TILE = 2,        /* -1 (default): tile shape by the cost model; 0..6: force one (tests: every shape through
                                      every kernel) */
     BYA_OPT_GEMM_VARIANT = 3,     /* 0 (default): the one-wave-per-SIMD kernels (256 x 256 tiles, 128 x 256 where that fills the CUs
                                      better) where eligible; 1: the 8-wave kernel; 2: 256 x 256 only (A/B of the 128-row tile) */

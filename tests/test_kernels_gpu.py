@@ -365,10 +365,12 @@ def test_gemm_pipelined_256(ops, dev, M, N, K):
 @pytest.mark.parametrize("B,M,N,K,epi", [(1, 2222, 3072, 3072, "gate+res"), (1, 2193, 2048, 2048, "bias"), (2, 700, 520, 256, "gelu+res"),
                                          (1, 129, 264, 832, "plain"), (1, 2222, 768, 1024, "split"), (1, 130, 256, 192, "short-k")])
 def test_gemm_128_row_persistent_tile_equals_the_256_row_one(ops, dev, B, M, N, K, epi):
-    """The 128 x 256 persistent kernel (gemm_v5.hip: three-stage ring that runs across output tiles, one barrier per K-tile) is
-    the 256 x 256 one's twin for row counts that leave its grid half empty -- a rank's 2222 rows of the 8-way sharded step.  Same
-    K order, same epilogue code (gemm_wide_epilogue.h), so FORCED on a shape (option gemm_tile = 5) it must equal the forced
-    256-row kernel (gemm_tile = 4) BIT FOR BIT and sit within the fp32 reference's tolerance: ragged M and N tiles (129 rows = a
+    """The 128 x 256 persistent kernels (three-stage ring that runs across output tiles, one barrier per K-tile; gemm_v6.hip: four
+    compute waves + four LOADER waves that issue the LDS-DMA stream, every plain Linear; gemm_v5.hip: four waves that do both, the
+    q|k|v projection's norm epilogue) are the 256 x 256 one's twins for row counts that leave its grid half empty -- a rank's 2222
+    rows of the 8-way sharded step.  Same K order, same epilogue code (gemm_wide_epilogue.h), so FORCED on a shape (option
+    gemm_tile = 6 / 5) they must equal the forced 256-row kernel (gemm_tile = 4) BIT FOR BIT and sit within the fp32
+    reference's tolerance: ragged M and N tiles (129 rows = a
     second, one-row tile; 264 = a column tile of eight columns), a batch, gates + residual in place, GELU, split outputs, several
     tiles per workgroup (2222 x 3072 is 216 tiles; 700 x 520 x 2 is 36), and K of three K-tiles (below the ring's minimum of four:
     the 256-row path must take it).  The library's own choice picks the 128-row tile for the first two shapes."""
@@ -377,7 +379,7 @@ def test_gemm_128_row_persistent_tile_equals_the_256_row_one(ops, dev, B, M, N, 
     x = rnd((B, M, N), dev, 44)
     mods = rnd((B, 2, N), dev, 45, 0.5)
     outs = {}
-    for tile in (4, 5, -1):
+    for tile in (4, 5, 6, -1):
         with ops.options(gemm_tile=tile, gemm_splitk=0):
             if epi == "gate+res":
                 o = x.clone()
@@ -394,6 +396,7 @@ def test_gemm_128_row_persistent_tile_equals_the_256_row_one(ops, dev, B, M, N, 
         outs[tile] = o
     torch.cuda.synchronize()
     assert torch.equal(outs[5], outs[4]), int((outs[5] != outs[4]).sum())
+    assert torch.equal(outs[6], outs[4]), int((outs[6] != outs[4]).sum())
     assert torch.equal(outs[-1], outs[4])
     y = a.float() @ w.float().T + (b.float() if epi != "plain" else 0.0)
     if epi == "gate+res":
@@ -405,7 +408,7 @@ def test_gemm_128_row_persistent_tile_equals_the_256_row_one(ops, dev, B, M, N, 
         ref = torch.stack([y[..., i * (N // 3):(i + 1) * (N // 3)] for i in range(3)])
     else:
         ref = y
-    check(outs[5], ref, what=f"gemm 128-row tile {M}x{N}x{K} {epi}")
+    check(outs[6], ref, what=f"gemm 128-row tile {M}x{N}x{K} {epi}")
 
 
 @pytest.mark.parametrize("gate_split", [226, 16500])

@@ -13,7 +13,7 @@ from bind_your_avatar_implementation_amd import ops  # noqa: E402
 from bind_your_avatar_implementation_amd.synth import rope_table  # noqa: E402
 
 dev = torch.device("cuda:0")
-VARIANTS = [("choice", {}), ("128x128", {"gemm_tile": 1}), ("256p", {"gemm_tile": 4}), ("128p", {"gemm_tile": 5})]
+VARIANTS = [("choice", {}), ("128x128", {"gemm_tile": 1}), ("256p", {"gemm_tile": 4}), ("128p", {"gemm_tile": 5}), ("128s", {"gemm_tile": 6})]
 
 
 def bench(fns, iters=20, rounds=4):
@@ -83,6 +83,7 @@ def main():
             row = {k: round(2.0 * M * N * K / (v * 1e-6) / 1e12, 1) for k, v in t.items()}
             row["us"] = {k: round(v, 1) for k, v in t.items()}
             row["128p_equals_256p"] = bool(torch.equal(outs["128p"], outs["256p"]))
+            row["128s_equals_256p"] = bool(torch.equal(outs["128s"], outs["256p"]))
             row["choice_equals_256p"] = bool(torch.equal(outs["choice"], outs["256p"]))
             res[f"W{W} {name} {M}x{N}x{K}"] = row
             print(f"W{W} {name:14s} {M}x{N}x{K}: " + "  ".join(f"{k}={v}" for k, v in row.items() if k != "us"), flush=True)
