@@ -23,6 +23,12 @@
 #include "gemm_wide_epilogue.h"
 #include "options.h"
 
+// timing-only ablation builds (tools/gemm_p128_ablate.py --v6; never the shipped library): 1 no epilogue, 2 the loader waves
+// request nothing inside the K-loop, 16 every K-tile re-reads K-tile 0 (every request an L2 hit)
+#ifndef BYA_GEMM6_ABLATE
+#define BYA_GEMM6_ABLATE 0
+#endif
+
 namespace {
 
 struct Tile128s { int z, m0, n0; bool valid; };
@@ -106,8 +112,10 @@ __global__ __launch_bounds__(512, 1) void gemm128s_kernel(GemmArgs p, int tiles_
         // behind B_g: K-tile g + 3 (soff / descriptors say whose) into the stage K-tile g just left
         auto refill = [&](const i32x4& dA, const i32x4& dW, uint32_t soff) {
             asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");    // B_g: my pieces of K-tile g + 1 have landed
-            ALL4(DMA_A, fillA, dA, soff);
-            ALL8(DMA_W, fillW, dW, soff);
+            if (!(BYA_GEMM6_ABLATE & 2)) {
+                ALL4(DMA_A, fillA, dA, (BYA_GEMM6_ABLATE & 16) ? 0u : soff);
+                ALL8(DMA_W, fillW, dW, (BYA_GEMM6_ABLATE & 16) ? 0u : soff);
+            }
             const uint32_t d = st == 2 ? (uint32_t)(-2 * STAGE) : (uint32_t)STAGE;
             fillA += d;
             fillW += d;
@@ -389,10 +397,15 @@ __global__ __launch_bounds__(512, 1) void gemm128s_kernel(GemmArgs p, int tiles_
         // the MFMAs are inline asm: pad their last results before the epilogue reads them
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
-        auto run = [&](auto act_tag) {
-            epilogue_wide<decltype(act_tag)::value, 1, false, false, 4>(p, cur.z, cur.m0 + wm * 64, cur.n0 + wn * 128, fr, fq, acc, wave, lane);
-        };
-        dispatch_act_big(p.act, run);
+        if constexpr (BYA_GEMM6_ABLATE & 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" :: "a"(acc[i][0]), "a"(acc[i][1]), "a"(acc[i][2]), "a"(acc[i][3]));
+        } else {
+            auto run = [&](auto act_tag) {
+                epilogue_wide<decltype(act_tag)::value, 1, false, false, 4>(p, cur.z, cur.m0 + wm * 64, cur.n0 + wn * 128, fr, fq, acc, wave, lane);
+            };
+            dispatch_act_big(p.act, run);
+        }
 
         if (!nxt.valid) break;
         ++seq;

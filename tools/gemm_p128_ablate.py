@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Ablation builds of the 128 x 256 persistent GEMM (csrc/gemm_v5.hip, -DBYA_GEMM5_ABLATE=mask): every variant is compiled into a
-side copy of the library (bind_your_avatar_implementation_amd/build/ablate/) and timed in a child process.  Results are
-meaningless, only the time is read: what is left when a piece goes away tells what that piece costs.
-python tools/gemm_p128_ablate.py --build | --run [--out gpurun_out/x.json]"""
+"""Ablation builds of the 128 x 256 persistent GEMMs (csrc/gemm_v5.hip, -DBYA_GEMM5_ABLATE=mask; with --v6: csrc/gemm_v6.hip, the
+form with loader waves, -DBYA_GEMM6_ABLATE=mask): every variant is compiled into a side copy of the library
+(bind_your_avatar_implementation_amd/build/ablate/) and timed in a child process.  Results are meaningless, only the time is read:
+what is left when a piece goes away tells what that piece costs.
+python tools/gemm_p128_ablate.py [--v6] --build | --run [--out gpurun_out/x.json]"""
 import json
 import os
 import subprocess
@@ -13,23 +14,27 @@ PKG = os.path.join(ROOT, "bind_your_avatar_implementation_amd")
 OUT = os.path.join(PKG, "build", "ablate")
 VARIANTS = {"full": 0, "no_epilogue": 1, "no_dma": 2, "no_barrier": 4, "no_frag_reads": 8, "no_dma_no_barrier": 6, "mfma_only": 15,
             "no_epilogue_no_dma": 3, "all_l2_hits": 16, "w_pieces_only": 32, "a_pieces_only": 64}
+V6 = "--v6" in sys.argv
+if V6:
+    VARIANTS = {"full": 0, "no_epilogue": 1, "no_dma": 2, "no_epilogue_no_dma": 3, "all_l2_hits": 16}
+SRC, MACRO, TILE = ("gemm_v6.hip", "BYA_GEMM6_ABLATE", 6) if V6 else ("gemm_v5.hip", "BYA_GEMM5_ABLATE", 5)
 
 
 def build():
     os.makedirs(OUT, exist_ok=True)
     sys.path.insert(0, ROOT)
     from bind_your_avatar_implementation_amd.build import SOURCES
-    objs = [os.path.join(PKG, "build", f.replace(".hip", ".o")) for f in SOURCES if f != "gemm_v5.hip"]
+    objs = [os.path.join(PKG, "build", f.replace(".hip", ".o")) for f in SOURCES if f != SRC]
     procs = []
     for name, mask in VARIANTS.items():
-        obj = os.path.join(OUT, f"gemm_v5_{name}.o")
+        obj = os.path.join(OUT, f"{SRC[:-4]}_{name}.o")
         procs.append((name, obj, subprocess.Popen(
             ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-             f"-DBYA_GEMM5_ABLATE={mask}", "-c", os.path.join(PKG, "csrc", "gemm_v5.hip"), "-o", obj])))
+             f"-D{MACRO}={mask}", "-c", os.path.join(PKG, "csrc", SRC), "-o", obj])))
     for name, obj, pr in procs:
         assert pr.wait() == 0, name
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
-                               os.path.join(OUT, f"libbya_gemm_v5_{name}.so")] + objs + [obj, "-ldl"])
+                               os.path.join(OUT, f"libbya_{SRC[:-4]}_{name}.so")] + objs + [obj, "-ldl"])
         print("built", name)
 
 
@@ -50,7 +55,7 @@ def timed(fn, n=30):
         best = min(best, e0.elapsed_time(e1) / n * 1e3)
     return best
 res = {}
-with ops.options(gemm_tile=5):
+with ops.options(gemm_tile=TILE_CODE):
     for M, N, K in ((2222, 3072, 3072), (2222, 9216, 3072), (4444, 12288, 3072), (2222, 3072, 12288)):
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
@@ -66,8 +71,8 @@ print(json.dumps(res))
 def run(out):
     res = {}
     for name in VARIANTS:
-        env = dict(os.environ, BYA_HIP_LIB=os.path.join(OUT, f"libbya_gemm_v5_{name}.so"))
-        r = subprocess.run([sys.executable, "-c", CHILD], env=env, cwd=ROOT, capture_output=True, text=True)
+        env = dict(os.environ, BYA_HIP_LIB=os.path.join(OUT, f"libbya_{SRC[:-4]}_{name}.so"))
+        r = subprocess.run([sys.executable, "-c", CHILD.replace("TILE_CODE", str(TILE))], env=env, cwd=ROOT, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         res[name] = json.loads(line[-1]) if line else {"error": r.stderr[-400:]}
         print(name, res[name], flush=True)
