@@ -1,3 +1,6 @@
+"""The two launches of a row plan timed apart (csrc/gemm.hip: rows of the full rounds of 256 x 256 tiles, then the remaining rows on
+128 x 256 tiles): whole launch on 256-row tiles, the library's choice, the main rows alone, the tail rows alone, whole launch on
+128-row tiles.  Run from the repository root:  python tools/gemm_hybrid_parts.py"""
 import sys, torch
 sys.path.insert(0, ".")
 from bind_your_avatar_implementation_amd import ops

@@ -1,3 +1,6 @@
+"""The two 128 x 256 persistent GEMMs side by side (forced tile 5 = four waves, csrc/gemm_v5.hip; 6 = loader waves, csrc/gemm_v6.hip)
+on per-rank shapes, one JSON line; BYA_HIP_LIB selects a side build (e.g. another barrier slot of the generated schedule).
+Run from the repository root:  python tools/gemm_v6_sweep.py"""
 import sys, torch, json
 sys.path.insert(0, ".")
 from bind_your_avatar_implementation_amd import ops
