@@ -110,7 +110,7 @@ def test_generated_gemm_schedules_match_their_tables():
     tools/gen_*_schedule.py from placement tables; the committed sources must be exactly what the tables generate."""
     import subprocess
     import sys
-    for gen in ("gen_gemm_v4_schedule.py", "gen_gemm_fp8_schedule.py", "gen_attn_w4_schedule.py"):
+    for gen in ("gen_gemm_v4_schedule.py", "gen_gemm_v5_schedule.py", "gen_gemm_v6_schedule.py", "gen_gemm_fp8_schedule.py", "gen_attn_w4_schedule.py"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), "--check"], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
 
