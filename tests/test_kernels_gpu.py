@@ -413,9 +413,9 @@ def test_gemm_128_row_persistent_tile_equals_the_256_row_one(ops, dev, B, M, N, 
 
 @pytest.mark.parametrize("gate_split", [226, 16500])
 def test_gemm_quantisation_tail_split(ops, dev, gate_split):
-    """17776 x 3072 is 3.28 rounds of 256x256 tiles: rows [0, 16384) run on the pipelined kernel and the last 1392
-    rows on the 128x128 kernel.  Every row-indexed operand (residual, gate switch row, per-row bias scale) must land
-    on the right rows in both parts."""
+    """17776 x 3072 is 3.28 rounds of 256x256 tiles: rows [0, 16384) run on the 256-row persistent kernel and the last 1392
+    rows as a second launch (round 6: on the 128 x 256 kernel with loader waves; before: the 128x128 kernel).  Every
+    row-indexed operand (residual, gate switch row, per-row bias scale) must land on the right rows in both parts."""
     M, N, K = 17776, 3072, 1024
     a, w, b = rnd((M, K), dev, 30), rnd((N, K), dev, 31, K ** -0.5), rnd((N,), dev, 32, 0.3)
     x = rnd((M, N), dev, 33)
@@ -712,22 +712,29 @@ def test_router_chains_repeatable_on_a_busy_gpu(ops, dev):
         assert all(torch.equal(first[k], o) for o in outs[k]), k
 
 
-@pytest.mark.parametrize("variant", ["v4"])      # (round 6: the "w8" arm -- the 8-wave fallback kernel forced on every shape -- went
-                                                 # with the suite's time budget; the fallback still runs where the default picks it)
-def test_gemm_big_tile_kernels_whole_suite(dev, variant):
-    """Every GEMM parity test again with the 256x256 pipelined kernels FORCED for all shapes (BYA_GEMM_TILE=4: ragged M / N,
-    K of one, two and three K-tiles -- the prologue / drain paths of the software pipelines -- batches, split outputs,
-    gate + residual epilogues) and, per parameter, the kernel variant BYA_GEMM_VARIANT selects: "v4" = the default
-    (persistent one-wave-per-SIMD kernel with cross-tile prefetch and 16-byte epilogue accesses, gemm_v4.hip; K >= 192, shorter
-    K falls back to the 8-wave kernel), "w8" = that 8-wave fallback kernel (gemm.hip).  Runs in a child process so the variables cannot leak into other tests."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, BYA_GEMM_TILE="4")
-    env["BYA_GEMM_VARIANT"] = variant
-    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k",
-                        "gemm and not rowgemm and not whole_suite"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+@pytest.mark.parametrize("tile", [4, 6])
+def test_gemm_big_tile_kernels_whole_suite(ops, dev, tile):
+    """The GEMM parity tests again with a persistent kernel FORCED for all their shapes (option gemm_tile = 4: the 256 x 256
+    one-wave-per-SIMD kernel of gemm_v4.hip; 6: the 128 x 256 kernel with loader waves of gemm_v6.hip): ragged M / N, K of one, two
+    and three K-tiles (shorter than a kernel's software pipeline: it must hand the launch on -- gemm_v4 needs three K-tiles,
+    gemm_v6 four), batches, strided views, split outputs, gate + residual epilogues, every activation (the ones without a
+    big-tile epilogue fall back to the 128 x 128 kernel).  In-process since round 6 (a child process with the variables set cost
+    20 s of start-up; the K-split tests force their own options).  (The "w8" arm -- the 8-wave fallback kernel forced on every
+    shape -- went with the suite's time budget in round 6; the fallback still runs where the default picks it.)"""
+    with ops.options(gemm_tile=tile):
+        for M, N, K in [(128, 128, 64), (256, 384, 192), (300, 512, 512), (17, 64, 128), (1350, 3072, 768), (2222, 2048, 3072),
+                        (130, 12288, 3072)]:
+            test_gemm_plain(ops, dev, M, N, K)
+        test_gemm_mfma_layout_asymmetric(ops, dev)
+        for act in ("gelu_tanh", "gelu_erf", "relu", "silu", "leaky_relu"):
+            test_gemm_bias_act(ops, dev, act)
+        test_gemm_gate_residual_batched(ops, dev)
+        test_gemm_strided_views(ops, dev)
+        test_gemm_split_output(ops, dev)
+        for M, N, K in [(1024, 1024, 64), (2500, 3072, 192), (4100, 768, 3072), (17776, 512, 512)]:
+            test_gemm_pipelined_256(ops, dev, M, N, K)
+        for gate_split in (226, 16500):
+            test_gemm_quantisation_tail_split(ops, dev, gate_split)
 
 
 def test_gemm_rejects_bad_shapes(ops, dev):
