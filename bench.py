@@ -518,8 +518,10 @@ def main():
                                                  if getattr(model, "_seq_p2p", None) is not None else
                                                  "; exchanges = torch.distributed collectives (RCCL)")},
         }
-        res["handoff_mode"] = ops.HANDOFF_MODE.get(dev.index, "split-K GEMM tails + stream-K joint attention (default)"
-                                                   if ops.get_option("gemm_splitk") else "unsplit (options gemm_splitk = attn_streamk = 0)")
+        res["handoff_mode"] = ops.HANDOFF_MODE.get(
+            dev.index, ("split-K GEMM tails + " if ops.get_option("gemm_splitk") else "") +
+            ("stream-K joint attention" + ("" if ops.get_option("gemm_splitk") else " (default: the GEMMs cut no tile along K)")
+             if ops.get_option("attn_streamk") else "no hand-offs (options gemm_splitk = attn_streamk = 0)"))
         if calibration is not None:
             res["board_calibration_tflops"] = calibration
             res["board_calibration"] = ("bare v_mfma_f32_16x16x32_bf16 loop, gaussian bf16 operands in registers, 256 CUs x 1 wave per SIMD, "

@@ -164,7 +164,7 @@ def get_option(name):
     return v.value
 
 
-OPTION_DEFAULTS = {"gemm_splitk": 1, "gemm_splitk_min": 0, "gemm_tile": -1, "gemm_variant": 0, "attn_streamk": 1, "fp8_kernel": 0,
+OPTION_DEFAULTS = {"gemm_splitk": 0, "gemm_splitk_min": 0, "gemm_tile": -1, "gemm_variant": 0, "attn_streamk": 1, "fp8_kernel": 0,
                    "p2p_groups": 0, "reference_forms": 0}
 
 

@@ -332,7 +332,7 @@ extern "C" int bya_abi_version(void) { return 2; }
 
 // ---- process-wide options (include/bya.h, csrc/options.h): defaults, ranges, setter ----------------------------------
 std::atomic<int32_t> g_bya_options[BYA_OPT_COUNT] = {
-    {1},      // BYA_OPT_GEMM_SPLITK
+    {0},      // BYA_OPT_GEMM_SPLITK
     {0},      // BYA_OPT_GEMM_SPLITK_MIN
     {-1},     // BYA_OPT_GEMM_TILE
     {0},      // BYA_OPT_GEMM_VARIANT

@@ -47,9 +47,10 @@ int bya_abi_version(void);
  * unknown key or a value outside the key's range; bya_get_option writes the current value.
  * --------------------------------------------------------------------------------------------- */
 enum bya_option {
-    BYA_OPT_GEMM_SPLITK = 0,      /* 1 (default): bya_gemm_bf16 splits the tiles of a partial last round along K when a
-                                     workspace is registered; 0: never (strict summation order: a shard's rows round like the
-                                     whole's); 2: every split tile in two */
+    BYA_OPT_GEMM_SPLITK = 0,      /* 0 (default since the end of round 6): bya_gemm_bf16 never cuts a tile along K -- the rows
+                                     behind the last full round of 256-row tiles run on 128-row tiles instead, as fast and without
+                                     a hand-off (a shard's rows round like the whole's); 1: the tiles of a partial last round are
+                                     split along K when a workspace is registered; 2: every split tile in two */
     BYA_OPT_GEMM_SPLITK_MIN = 1,  /* shortest K range (in 64-wide K tiles) a split may produce; 0 = the built-in default */
     BYA_OPT_GEMM_TILE = 2,        /* -1 (default): tile shape by the cost model; 0..6: force one (tests: every shape through
                                      every kernel) */

@@ -204,7 +204,7 @@ def test_options_are_set_through_the_abi_and_never_through_the_environment(lib_p
     assert lib.bya_set_option(99, 0) == -1 and lib.bya_set_option(-1, 0) == -1            # unknown key
     assert lib.bya_set_option(_hip.OPTIONS["gemm_splitk"], 3) == -1                       # out of range: nothing changes
     assert lib.bya_set_option(_hip.OPTIONS["p2p_groups"], 8) == -1 and lib.bya_set_option(_hip.OPTIONS["p2p_groups"], 64) == 0
-    assert _hip.get_option("gemm_splitk") == 1 and _hip.get_option("p2p_groups") == 64
+    assert _hip.get_option("gemm_splitk") == 0 and _hip.get_option("p2p_groups") == 64
     _hip.set_option("p2p_groups", 0)
     assert lib.bya_get_option(_hip.OPTIONS["gemm_tile"], None) == -1
     # the environment reaches the table once, at load time, in a fresh process

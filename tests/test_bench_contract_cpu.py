@@ -59,7 +59,7 @@ def test_committed_bench_line_meets_the_contract():
     assert abs(d["mfma_roofline_frac_of_board_whole_step"] - d["mfma_roofline_frac_whole_step"] * 2500.0 / cal) < 1e-9
     from bench import ROUTER_TIMERS
     assert abs(d["router_ms_per_step"] - sum(km.get(k, 0.0) for k in ROUTER_TIMERS)) < 0.01
-    assert d["handoff_mode"].startswith("split-K")
+    assert "stream-K joint attention" in d["handoff_mode"]
 
 
 def test_committed_rehearsal_lines_of_the_n_gpu_path_carry_their_own_reference():

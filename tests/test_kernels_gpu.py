@@ -112,13 +112,14 @@ def test_gemm_output_past_the_2gib_reach_of_the_epilogue_descriptors(ops, dev, f
     (2222, 3072, 12288, "gate_res"),      # one rank's FF2
 ])
 def test_gemm_split_k_last_round(ops, dev, M, N, K, epi, lib_options):
-    """The persistent kernel cuts the last, partial round of 256 x 256 tiles along K when the split-K workspace is
+    """With option gemm_splitk = 1 (the default until the end of round 6; now the row plan of gemm.hip does the same job without a
+    hand-off) the persistent kernel cuts the last, partial round of 256 x 256 tiles along K when the split-K workspace is
     registered (ops.gemm registers it): partial sums travel through fp32 slabs between workgroups (write-through stores,
     agent-scope counter).  Against the fp32 product with the usual bar, against the unsplit kernel (option gemm_splitk = 0:
     same products, only the fp32 summation order of a split tile differs) and 12 repeats bit-identical on a busy GPU
     (a wrong wait, a stale slab or a counter that is not reset shows as rare wrong tiles).  By default only K-ranges of
     40+ K-tiles are split (K = 12288: the exchange costs ~20 us); option gemm_splitk_min = 8 makes every shape here split."""
-    lib_options(gemm_splitk_min=8)
+    lib_options(gemm_splitk=1, gemm_splitk_min=8)
     a, w, b = rnd((M, K), dev, 31), rnd((N, K), dev, 32, K ** -0.5), rnd((N,), dev, 33, 0.5)
     kw, ref = {}, a.float() @ w.float().T + b.float()
     res = rnd((M, N), dev, 34)
@@ -162,10 +163,11 @@ def test_gemm_split_k_last_round(ops, dev, M, N, K, epi, lib_options):
     ops.check_gemm_workspace()
 
 
-def test_gemm_split_k_inside_a_replayed_hip_graph(ops, dev):
+def test_gemm_split_k_inside_a_replayed_hip_graph(ops, dev, lib_options):
     """The split-K hand-off keeps state in the workspace (slabs, counters the finisher puts back to zero): a captured
     hipGraph that contains a split launch must replay bit-identically, on new input values too, and interleaved with eager
     launches of another split shape."""
+    lib_options(gemm_splitk=1)
     M, N, K = 17776, 3072, 12288
     a, w = rnd((M, K), dev, 41), rnd((N, K), dev, 42, K ** -0.5)
     a2 = rnd((M, K), dev, 43)
@@ -202,13 +204,14 @@ def test_gemm_split_k_inside_a_replayed_hip_graph(ops, dev):
     ops.check_gemm_workspace()
 
 
-def test_gemm_several_split_launches_in_one_replayed_hip_graph(ops, dev):
+def test_gemm_several_split_launches_in_one_replayed_hip_graph(ops, dev, lib_options):
     """A hipGraph replays its launches with the launch epochs baked in at capture.  With several split launches in one
     graph the counter words, shared by all of them, carry the LAST launch's epoch when the next replay starts: the first
     launch's writers must still be able to claim them (an idle word is claimable whatever its epoch).  Before that rule
     every replay after the first stalled ~1 s per split launch in the finisher's bounded wait and raised
     bya_gemm_workspace_status.  Checks: bit-identical replays, status 0, and a wall-time bound far below one time-out."""
     import time
+    lib_options(gemm_splitk=1)
     M, N, K = 17776, 3072, 12288
     a = [rnd((M, K), dev, 51 + i) for i in range(3)]
     w = rnd((N, K), dev, 55, K ** -0.5)

@@ -29,8 +29,10 @@ def _split_shape(dev):
 @pytest.fixture
 def fresh_handoff_state():
     from bind_your_avatar_implementation_amd import ops
+    ops.set_option("gemm_splitk", 1)                 # (not the default since the end of round 6: the GEMMs' row plan needs no hand-off)
+    ops.set_option("attn_streamk", 1)
     yield ops
-    ops.set_option("gemm_splitk", 1)
+    ops.set_option("gemm_splitk", 0)
     ops.set_option("attn_streamk", 1)
     ops.HANDOFF_MODE.clear()
 
@@ -143,7 +145,7 @@ def test_split_gemm_survives_neighbours_on_the_same_gpu(dev, fresh_handoff_state
     with ops.options(gemm_splitk=0):
         ref = ops.gemm(a, w, torch.empty_like(out)).clone()
     torch.cuda.synchronize()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BYA_GEMM_SPLITK="1")
     kids = [subprocess.Popen([sys.executable, "-c", NEIGHBOUR, ROOT, "7"], stdout=subprocess.PIPE, text=True, env=env) for _ in range(3)]
     try:
         for k in kids:
