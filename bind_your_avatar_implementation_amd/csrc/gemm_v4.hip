@@ -17,7 +17,8 @@
 //    bytes per row and instruction -- half the memory instructions of the 8-byte epilogue, all requested in bursts
 //    (gemm_common.h explains why that matters: one serialized round trip per access otherwise).
 //
-//  * THE LAST, PARTIAL ROUND IS SPLIT ALONG K (when the caller registered a workspace, bya_set_gemm_workspace): an XCD
+//  * THE LAST, PARTIAL ROUND IS SPLIT ALONG K (when the caller registered a workspace, bya_set_gemm_workspace, and option
+//    gemm_splitk is 1 -- the default of rounds 2-6; since then gemm.hip's row plan sends those rows to 128-row tiles instead): an XCD
 //    whose tile count is not a multiple of its 32 workgroups has R < 32 tiles left after the full rounds; each of them is
 //    cut into p = min(32 / R, K-tiles / 40) K-ranges that p workgroups compute at the same time (shorter ranges do not
 //    pay for the slab exchange: K = 12288 splits, K = 3072 does not).  p - 1 of them write
