@@ -715,6 +715,37 @@ def test_router_chains_repeatable_on_a_busy_gpu(ops, dev):
         assert all(torch.equal(first[k], o) for o in outs[k]), k
 
 
+def test_gemm_loader_wave_kernel_repeatable_on_a_busy_gpu(ops, dev):
+    """gemm_v6.hip synchronises two kinds of waves through ONE barrier per K-tile: the loaders' `vmcnt` says which pieces of the
+    LDS-DMA stream have landed, the compute waves' arrival says which ring stage may be refilled, and the ring runs across a
+    workgroup's output tiles.  A protocol slip (a stage refilled before its last reader, a fragment read before its piece
+    landed) would show as rare wrong tiles when workgroups drift apart: 15 launches each of a one-round shape (216 tiles), of a
+    shape with seven tiles per workgroup and of a long K (192 K-tiles) on a busy GPU (a large GEMM queued on a second stream),
+    every result bit-identical to the first and to the 256-row kernel's."""
+    shapes = [(2222, 3072, 3072), (4444, 12288, 3072), (2222, 3072, 12288)]
+    data, first, want = {}, {}, {}
+    for M, N, K in shapes:
+        a, w, b = rnd((M, K), dev, 90), rnd((N, K), dev, 91, K ** -0.5), rnd((N,), dev, 92, 0.3)
+        data[(M, N, K)] = (a, w, b, rnd((M, N), dev, 93))
+    def run(key, tile):
+        a, w, b, x = data[key]
+        with ops.options(gemm_tile=tile, gemm_splitk=0):
+            return ops.gemm(a, w, torch.empty_like(x), bias=b, res=x)
+    for key in data:
+        first[key], want[key] = run(key, 6), run(key, 4)
+    torch.cuda.synchronize()
+    aa, bb = rnd((8192, 8192), dev, 86), rnd((8192, 8192), dev, 87)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            aa @ bb
+    outs = {key: [run(key, 6) for _ in range(15)] for key in data}
+    torch.cuda.synchronize()
+    for key in data:
+        assert torch.equal(first[key], want[key]), key
+        assert all(torch.equal(first[key], o) for o in outs[key]), key
+
+
 @pytest.mark.parametrize("tile", [4, 6])
 def test_gemm_big_tile_kernels_whole_suite(ops, dev, tile):
     """The GEMM parity tests again with a persistent kernel FORCED for all their shapes (option gemm_tile = 4: the 256 x 256
