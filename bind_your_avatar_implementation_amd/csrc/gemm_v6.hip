@@ -422,7 +422,11 @@ __global__ __launch_bounds__(512, 1) void gemm128s_kernel(GemmArgs p, int tiles_
 // and its 128-row part is the 430-row tail of a row plan: it stays on gemm_v5.hip.)
 int bya_launch_gemm128s(const void* args, int batch, hipStream_t s) {
     GemmArgs a = *static_cast<const GemmArgs*>(args);
+#ifdef BYA_GEMM6_GM                                             // (side builds of a group-M sweep)
+    a.gm = BYA_GEMM6_GM;
+#else
     a.gm = 2 * gemm_group_m(a);                                // the same rows per group as the 256-row tiles' order
+#endif
     const int tiles_m = (a.M + 127) / 128, tiles_n = (a.N + 255) / 256;
     const long long total = (long long)tiles_m * tiles_n * batch;
     const int blocks = (int)(total < 256 ? (total + 7) / 8 * 8 : 256);
