@@ -47,7 +47,8 @@ def ops():
 
 # ----------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (300, 512, 512), (17, 64, 128),
-                                   (1350, 3072, 768), (2222, 2048, 3072), (130, 12288, 3072)])
+                                   (1350, 3072, 768), (2222, 2048, 3072), (130, 12288, 3072),
+                                   (520, 87552, 512)])     # few rows, short K, 1026 tiles: the persistent kernel (a deep grid)
 def test_gemm_plain(ops, dev, M, N, K):
     a, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, K ** -0.5)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
