@@ -403,7 +403,11 @@ inline int pick_tile(int M, int N, int K, int batch, int forced, int act, bool s
     // short K loops and few rows: the pipelined kernel's prologue / epilogue dominate -- unless the grid is many rounds deep, where
     // the persistent kernel's cross-tile prefetch has no prologue to pay (the audio K/V projection of all 42 layers in one launch,
     // 832 x 258048 x 768 = 15.75 rounds: 390 us against 494 on the 128 x 128 kernel; r6)
+#ifdef BYA_GEMM_NO_DEEP_GRID                 // (A/B build)
+    const bool deep_grid = false;
+#else
     const bool deep_grid = frac_rounds >= 4.0 && M >= 512 && K >= 512;
+#endif
     if (((M < 1024 || K < 1024) && !deep_grid) || N < 512 || !act_on_big_tiles(act)) return 1;
     // the pipelined 256x256 kernel is ~1.2x the 128x128 one per unit of tile area when its grid fills the CUs
     if (p128_ok) {
