@@ -368,7 +368,7 @@ def main():
         if len(tried) > 1:
             transport_note = (f"{', '.join(t['transport'] for t in tried[:-1])} failed the comparison with the unsharded step on "
                               f"this node; running on {tried[-1]['transport']}")
-        # ---- default mode (split-K tails, stream-K attention): same numbers up to fp32 summation order
+        # ---- default mode (stream-K attention; until the end of round 6 also split-K GEMM tails): same numbers up to fp32 summation order
         for _ in range(max(1, args.warmup)):
             out = step()
         torch.cuda.synchronize()
